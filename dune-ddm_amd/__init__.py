@@ -1,0 +1,363 @@
+"""dune_ddm_amd -- MI355X-native two-level additive Schwarz + GenEO hot path (host-side mirror).
+
+The compute lives in ``libddm_hip.so`` (hand-written HIP for gfx950, C ABI in include/ddm_hip.h).
+This package is the thin host layer used by the tests and bench.py: ctypes bindings with the
+reference's class names (SchwarzPreconditioner, GalerkinPreconditioner, CombinedPreconditioner,
+NonOverlappingOperator), the flattening of DUNE-style index sets into exchange plans, and the
+synthetic problem generator.  There is no CPU fallback: importing works anywhere (so that the
+symbol table can be checked), every compute call needs a HIP device.
+
+The directory name contains a hyphen, so import it through ``__graft_entry__.import_package()``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libddm_hip.so")
+
+DDM_OK, DDM_EINVAL, DDM_EHIP, DDM_ENOTIMPL, DDM_ENUMERIC, DDM_ECOMM = 0, -1, -2, -3, -4, -5
+
+
+class DdmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ddm_hip error {code}: {msg}")
+        self.code = code
+
+
+class SolveResult(ctypes.Structure):
+    _fields_ = [("iterations", ctypes.c_int32), ("converged", ctypes.c_int32), ("def0", ctypes.c_double),
+                ("reduction", ctypes.c_double), ("elapsed_s", ctypes.c_double)]
+
+
+A2A_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
+
+_P, _I64, _I32, _D = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double
+_PP = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> (restype, argtypes); must list every symbol declared in include/ddm_hip.h
+SYMBOLS = {
+    "ddm_ctx_create": (_I32, [_I32, _P, _PP]),
+    "ddm_ctx_destroy": (None, [_P]),
+    "ddm_last_error": (ctypes.c_char_p, [_P]),
+    "ddm_ctx_sync": (_I32, [_P]),
+    "ddm_ctx_stream": (_P, [_P]),
+    "ddm_ctx_set_comm": (_I32, [_P, _I32, _I32, A2A_FN, ALLREDUCE_FN, _P]),
+    "ddm_malloc": (_I32, [_P, _I64, _PP]),
+    "ddm_free": (_I32, [_P, _P]),
+    "ddm_memcpy_h2d": (_I32, [_P, _P, _P, _I64]),
+    "ddm_memcpy_d2h": (_I32, [_P, _P, _P, _I64]),
+    "ddm_csr_create": (_I32, [_P, _I64, _I64, _P, _P, _P, _PP]),
+    "ddm_csr_destroy": (None, [_P]),
+    "ddm_csr_rows": (_I64, [_P]),
+    "ddm_csr_nnz": (_I64, [_P]),
+    "ddm_csr_mv": (_I32, [_P, _P, _P, _P]),
+    "ddm_csr_usmv": (_I32, [_P, _P, _D, _P, _P]),
+    "ddm_ilu0_create": (_I32, [_P, _P, _I64, _P, _PP]),
+    "ddm_ilu0_destroy": (None, [_P]),
+    "ddm_ilu0_solve": (_I32, [_P, _P, _P, _P]),
+    "ddm_ilu0_num_levels": (_I64, [_P, _I32]),
+    "ddm_ilu0_get_factors_host": (_I32, [_P, _P, _P]),
+    "ddm_halo_create": (_I32, [_P, _I32, _I32, _I64, _P, _P, _P, _I64, _P, _P, _P, _PP]),
+    "ddm_halo_destroy": (None, [_P]),
+    "ddm_halo_exchange": (_I32, [_P, _P, _P]),
+    "ddm_halo_sendbuf": (_P, [_P]),
+    "ddm_halo_recvbuf": (_P, [_P]),
+    "ddm_op_create": (_I32, [_P, _P, _P, _P, _PP]),
+    "ddm_op_destroy": (None, [_P]),
+    "ddm_op_apply": (_I32, [_P, _P, _P, _P]),
+    "ddm_op_applyscaleadd": (_I32, [_P, _P, _D, _P, _P]),
+    "ddm_dot": (_I32, [_P, _P, _P, _P, _P]),
+    "ddm_norm": (_I32, [_P, _P, _P, _P]),
+    "ddm_schwarz_create": (_I32, [_P, _P, _I64, _P, _I64, _P, _P, _I32, _P, _P, _PP]),
+    "ddm_schwarz_destroy": (None, [_P]),
+    "ddm_schwarz_apply": (_I32, [_P, _P, _P, _P]),
+    "ddm_galerkin_create": (_I32, [_P, _I64, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _P, _PP]),
+    "ddm_galerkin_destroy": (None, [_P]),
+    "ddm_galerkin_apply": (_I32, [_P, _P, _P, _P]),
+    "ddm_galerkin_products": (_I32, [_P, _P, _I64, _P, _I64, _P, _I64, _I64, _P]),
+    "ddm_combined_create": (_I32, [_P, _I32, _P, _P, _P, _PP]),
+    "ddm_combined_destroy": (None, [_P]),
+    "ddm_combined_apply": (_I32, [_P, _P, _P, _P]),
+    "ddm_cg_solve": (_I32, [_P, _P, _P, _P, _P, _D, _I32, _I32, _P, ctypes.POINTER(SolveResult)]),
+    "ddm_timing_enable": (_I32, [_P, _I32]),
+    "ddm_timing_get": (_I32, [_P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
+    "ddm_timing_reset": (_I32, [_P]),
+}
+
+_lib = None
+
+
+def load_library():
+    """Loads libddm_hip.so (built by __graft_entry__.build()).  Fails loudly if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no CPU fallback for the HIP hot path)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)            # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _np(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _hp(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+class Context:
+    """ddm_ctx: one per process / GPU.  ``stream``: raw hipStream_t (e.g. torch's current stream)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self.lib.ddm_ctx_create(int(device), ctypes.c_void_p(stream) if stream else None, ctypes.byref(h))
+        if rc != DDM_OK:
+            raise DdmError(rc, "ddm_ctx_create failed (no HIP device? the hot path has no CPU fallback)")
+        self.h = h
+        self._keep = []
+        self.rank, self.nranks = 0, 1
+
+    def check(self, rc):
+        if rc != DDM_OK:
+            raise DdmError(rc, self.lib.ddm_last_error(self.h).decode())
+
+    def sync(self):
+        self.check(self.lib.ddm_ctx_sync(self.h))
+
+    def set_comm(self, rank, nranks, alltoall, allreduce):
+        """alltoall(tag, send_ptr, recv_ptr) -> int ; allreduce(ptr, n) -> int (device pointers)."""
+        a = A2A_FN(lambda user, tag, s, r: int(alltoall(tag, s, r)))
+        b = ALLREDUCE_FN(lambda user, p, n: int(allreduce(p, n)))
+        self._keep += [a, b]
+        self.check(self.lib.ddm_ctx_set_comm(self.h, rank, nranks, a, b, None))
+        self.rank, self.nranks = rank, nranks
+
+    def timing(self, on=True):
+        self.check(self.lib.ddm_timing_enable(self.h, int(on)))
+
+    def timer(self, name):
+        ms, cnt = ctypes.c_double(), ctypes.c_int64()
+        self.check(self.lib.ddm_timing_get(self.h, name.encode(), ctypes.byref(ms), ctypes.byref(cnt)))
+        return ms.value, cnt.value
+
+    def timing_reset(self):
+        self.check(self.lib.ddm_timing_reset(self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.ddm_ctx_destroy(self.h)
+            self.h = None
+
+
+def _ptr(t):
+    """device pointer of a torch tensor / raw int"""
+    return ctypes.c_void_p(t if isinstance(t, int) else t.data_ptr())
+
+
+class CsrMatrix:
+    """Flattened BCRSMatrix on the device (ddm_csr)."""
+
+    def __init__(self, ctx: Context, M):
+        import scipy.sparse as sp
+        M = sp.csr_matrix(M)
+        if not M.has_sorted_indices:
+            M = M.sorted_indices()
+        self.ctx = ctx
+        self.shape = M.shape
+        rp, ci, va = _np(M.indptr, np.int64), _np(M.indices, np.int32), _np(M.data, np.float64)
+        h = ctypes.c_void_p()
+        ctx.check(ctx.lib.ddm_csr_create(ctx.h, M.shape[0], M.shape[1], _hp(rp), _hp(ci), _hp(va), ctypes.byref(h)))
+        self.h = h
+        self.nnz = int(M.nnz)
+
+    def mv(self, x, y):
+        self.ctx.check(self.ctx.lib.ddm_csr_mv(self.ctx.h, self.h, _ptr(x), _ptr(y)))
+
+    def usmv(self, alpha, x, y):
+        self.ctx.check(self.ctx.lib.ddm_csr_usmv(self.ctx.h, self.h, float(alpha), _ptr(x), _ptr(y)))
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.ctx.lib.ddm_csr_destroy(self.h)
+        except Exception:
+            pass
+
+
+class Ilu0:
+    def __init__(self, ctx: Context, A: CsrMatrix, block_ptr=None):
+        self.ctx, self.A = ctx, A
+        bp = _np([0, A.shape[0]] if block_ptr is None else block_ptr, np.int64)
+        h = ctypes.c_void_p()
+        ctx.check(ctx.lib.ddm_ilu0_create(ctx.h, A.h, len(bp) - 1, _hp(bp), ctypes.byref(h)))
+        self.h = h
+
+    def solve(self, d, x):
+        self.ctx.check(self.ctx.lib.ddm_ilu0_solve(self.ctx.h, self.h, _ptr(d), _ptr(x)))
+
+    def num_levels(self, upper=False):
+        return int(self.ctx.lib.ddm_ilu0_num_levels(self.h, int(upper)))
+
+    def factors(self):
+        out = np.empty(self.A.nnz, dtype=np.float64)
+        self.ctx.check(self.ctx.lib.ddm_ilu0_get_factors_host(self.ctx.h, self.h, _hp(out)))
+        return out
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.ctx.lib.ddm_ilu0_destroy(self.h)
+        except Exception:
+            pass
+
+
+class Halo:
+    """One DUNE interface flattened into a pack / exchange / unpack plan (ddm_halo)."""
+    COPY, ADD = 0, 1
+
+    def __init__(self, ctx: Context, tag, mode, plan):
+        self.ctx, self.tag, self.mode, self.plan = ctx, tag, mode, plan
+        a = {k: _np(plan[k], np.int64) for k in ("send_idx", "send_counts", "recv_counts", "dst_idx", "dst_ptr", "src_pos")}
+        assert len(a["send_counts"]) == ctx.nranks and len(a["recv_counts"]) == ctx.nranks
+        h = ctypes.c_void_p()
+        ctx.check(ctx.lib.ddm_halo_create(ctx.h, tag, mode, len(a["send_idx"]), _hp(a["send_idx"]), _hp(a["send_counts"]),
+                                          _hp(a["recv_counts"]), len(a["dst_idx"]), _hp(a["dst_idx"]), _hp(a["dst_ptr"]),
+                                          _hp(a["src_pos"]), ctypes.byref(h)))
+        self.h = h
+        self.send_counts = [int(c) for c in a["send_counts"]]
+        self.recv_counts = [int(c) for c in a["recv_counts"]]
+
+    def exchange(self, v):
+        self.ctx.check(self.ctx.lib.ddm_halo_exchange(self.ctx.h, self.h, _ptr(v)))
+
+    @property
+    def sendbuf(self):
+        return self.ctx.lib.ddm_halo_sendbuf(self.h)
+
+    @property
+    def recvbuf(self):
+        return self.ctx.lib.ddm_halo_recvbuf(self.h)
+
+
+class NonOverlappingOperator:
+    """dune/ddm/nonoverlapping_operator.hh:11-58 (+ the scalar product :63-89)."""
+
+    def __init__(self, ctx: Context, A: CsrMatrix, novlp_add: Halo | None, owner_mask):
+        self.ctx, self.A, self.halo = ctx, A, novlp_add
+        m = _np(owner_mask, np.uint8)
+        assert len(m) == A.shape[0]
+        h = ctypes.c_void_p()
+        ctx.check(ctx.lib.ddm_op_create(ctx.h, A.h, novlp_add.h if novlp_add else None, _hp(m), ctypes.byref(h)))
+        self.h = h
+
+    def apply(self, x, y):
+        self.ctx.check(self.ctx.lib.ddm_op_apply(self.ctx.h, self.h, _ptr(x), _ptr(y)))
+
+    def applyscaleadd(self, alpha, x, y):
+        self.ctx.check(self.ctx.lib.ddm_op_applyscaleadd(self.ctx.h, self.h, float(alpha), _ptr(x), _ptr(y)))
+
+    def dot(self, x, y):
+        r = ctypes.c_double()
+        self.ctx.check(self.ctx.lib.ddm_dot(self.ctx.h, self.h, _ptr(x), _ptr(y), ctypes.byref(r)))
+        return r.value
+
+    def norm(self, x):
+        r = ctypes.c_double()
+        self.ctx.check(self.ctx.lib.ddm_norm(self.ctx.h, self.h, _ptr(x), ctypes.byref(r)))
+        return r.value
+
+
+class SchwarzPreconditioner:
+    """dune/ddm/schwarz.hh:54-220 with the ILU(0) local solver on the device."""
+    TYPES = {"standard": 0, "restricted": 1}
+
+    def __init__(self, ctx: Context, A_dir: CsrMatrix, block_ptr, n_novlp, ext_map, pou, type, ovlp_copy: Halo | None,
+                 ovlp_add: Halo | None):
+        if type not in self.TYPES:
+            raise NotImplementedError("Unknown Schwarz type '" + str(type) + "'")   # schwarz.hh:83
+        self.ctx = ctx
+        bp = _np(block_ptr, np.int64)
+        em = _np(ext_map, np.int32)
+        pw = None if pou is None else _np(pou, np.float64)
+        h = ctypes.c_void_p()
+        ctx.check(ctx.lib.ddm_schwarz_create(ctx.h, A_dir.h, len(bp) - 1, _hp(bp), int(n_novlp), _hp(em), _hp(pw), self.TYPES[type],
+                                             ovlp_copy.h if ovlp_copy else None, ovlp_add.h if ovlp_add else None, ctypes.byref(h)))
+        self.h = h
+        self._keep = (A_dir, ovlp_copy, ovlp_add)
+
+    def apply(self, x, d):
+        self.ctx.check(self.ctx.lib.ddm_schwarz_apply(self.ctx.h, self.h, _ptr(x), _ptr(d)))
+
+
+class GalerkinPreconditioner:
+    """dune/ddm/galerkin_preconditioner.hh:40-363 (apply path; the coarse matrix is assembled by
+    ``coarse.build_coarse_matrix`` and handed over as its replicated inverse)."""
+
+    def __init__(self, ctx: Context, n, n_novlp, ext_map, sub_ptr, basis, coarse_index, a0inv, ovlp_copy, ovlp_add):
+        self.ctx = ctx
+        basis = _np(basis, np.float64)
+        kmax = basis.shape[0]
+        assert basis.shape[1] == n
+        sp_ = _np(sub_ptr, np.int64)
+        ci = _np(coarse_index, np.int64)
+        inv = _np(a0inv, np.float64)
+        K = inv.shape[0]
+        em = _np(ext_map, np.int32)
+        h = ctypes.c_void_p()
+        ctx.check(ctx.lib.ddm_galerkin_create(ctx.h, int(n), int(n_novlp), _hp(em), len(sp_) - 1, _hp(sp_), kmax, _hp(basis), _hp(ci),
+                                              K, _hp(inv), ovlp_copy.h if ovlp_copy else None, ovlp_add.h if ovlp_add else None,
+                                              ctypes.byref(h)))
+        self.h = h
+        self._keep = (ovlp_copy, ovlp_add)
+
+    def apply(self, x, d):
+        self.ctx.check(self.ctx.lib.ddm_galerkin_apply(self.ctx.h, self.h, _ptr(x), _ptr(d)))
+
+
+def galerkin_products(ctx: Context, A_dir: CsrMatrix, left, right, row0, row1):
+    """out[i, j] = <left_i, A_dir right_j> over rows [row0, row1); left/right: torch (k x n) device tensors."""
+    nl, nr = left.shape[0], right.shape[0]
+    out = np.empty((nr, nl), dtype=np.float64)      # column-major nl x nr
+    ctx.check(ctx.lib.ddm_galerkin_products(ctx.h, A_dir.h, nl, _ptr(left), nr, _ptr(right), int(row0), int(row1), _hp(out)))
+    return out.T
+
+
+class CombinedPreconditioner:
+    """dune/ddm/combined_preconditioner.hh:39-180."""
+    MODES = {"additive": 0, "multiplicative": 1}
+
+    def __init__(self, ctx: Context, mode="additive", op=None, schwarz=None, galerkin=None):
+        if mode not in self.MODES:
+            raise NotImplementedError("Unknown apply mode in CombinedPreconditioner, use either additive or multiplicative")
+        self.ctx = ctx
+        h = ctypes.c_void_p()
+        ctx.check(ctx.lib.ddm_combined_create(ctx.h, self.MODES[mode], op.h if op else None, schwarz.h if schwarz else None,
+                                              galerkin.h if galerkin else None, ctypes.byref(h)))
+        self.h = h
+        self._keep = (op, schwarz, galerkin)
+
+    def apply(self, x, d):
+        self.ctx.check(self.ctx.lib.ddm_combined_apply(self.ctx.h, self.h, _ptr(x), _ptr(d)))
+
+
+def cg_solve(ctx: Context, op: NonOverlappingOperator, prec: CombinedPreconditioner, x, b, reduction=1e-10, maxit=1000,
+             fixed_iterations=0, history=True):
+    """dune-istl CGSolver::apply as driven by examples/poisson.cc:311-319.  x, b: device tensors;
+    b is overwritten by the defect.  Returns (SolveResult, history ndarray or None)."""
+    res = SolveResult()
+    hist = np.zeros(max(maxit, fixed_iterations) + 1, dtype=np.float64) if history else None
+    ctx.check(ctx.lib.ddm_cg_solve(ctx.h, op.h, prec.h, _ptr(x), _ptr(b), float(reduction), int(maxit), int(fixed_iterations),
+                                   _hp(hist), ctypes.byref(res)))
+    return res, (hist[:res.iterations + 1] if history else None)

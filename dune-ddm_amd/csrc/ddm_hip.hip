@@ -1,0 +1,1111 @@
+// C-ABI implementation of include/ddm_hip.h: host-side runtime (contexts, plans, level schedules,
+// HIP graphs, the CG driver) around the kernels in kernels.hpp.  gfx950 only, no fallback path.
+#include "../../include/ddm_hip.h"
+#include "kernels.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace ddm;
+
+// ---------------------------------------------------------------------------------------------
+struct TimerEntry {
+  double ms = 0.0;
+  int64_t count = 0;
+};
+
+struct ddm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  int rank = 0, nranks = 1;
+  ddm_alltoall_fn a2a = nullptr;
+  ddm_allreduce_fn allreduce = nullptr;
+  void *user = nullptr;
+  double *partial = nullptr; // RED_MAX_BLOCKS doubles
+  double *scal = nullptr;    // 16 device scalars
+  bool timing = false;
+  std::map<std::string, TimerEntry> timers;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+static int fail(ddm_ctx *ctx, int code, const char *fmt, ...)
+{
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+#define HIPCHECK(ctx, call)                                                                                   \
+  do {                                                                                                        \
+    hipError_t e_ = (call);                                                                                   \
+    if (e_ != hipSuccess) return fail(ctx, DDM_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define DDMCHECK(call)            \
+  do {                            \
+    int rc_ = (call);             \
+    if (rc_ != DDM_OK) return rc_; \
+  } while (0)
+
+static inline int grid_for(int64_t n, int per_block = WG, int cap = 2048)
+{
+  int64_t g = (n + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+template <class T>
+static int upload(ddm_ctx *ctx, const T *host, int64_t n, T **dev)
+{
+  *dev = nullptr;
+  if (n <= 0) {
+    HIPCHECK(ctx, hipMalloc((void **)dev, sizeof(T)));
+    return DDM_OK;
+  }
+  HIPCHECK(ctx, hipMalloc((void **)dev, sizeof(T) * (size_t)n));
+  HIPCHECK(ctx, hipMemcpy(*dev, host, sizeof(T) * (size_t)n, hipMemcpyHostToDevice));
+  return DDM_OK;
+}
+
+struct ScopedTimer {
+  ddm_ctx *ctx;
+  const char *name;
+  ScopedTimer(ddm_ctx *c, const char *n) : ctx(c), name(n)
+  {
+    if (ctx->timing) (void)hipEventRecord(ctx->ev0, ctx->stream);
+  }
+  ~ScopedTimer()
+  {
+    if (!ctx->timing) return;
+    (void)hipEventRecord(ctx->ev1, ctx->stream);
+    (void)hipEventSynchronize(ctx->ev1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    auto &t = ctx->timers[name];
+    t.ms += ms;
+    t.count += 1;
+  }
+};
+
+// ---- context ---------------------------------------------------------------------------------
+extern "C" int ddm_ctx_create(int device, void *hip_stream, ddm_ctx **out)
+{
+  if (!out) return DDM_EINVAL;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DDM_EHIP; // no CPU fallback
+  if (device < 0 || device >= ndev) return DDM_EINVAL;
+  ddm_ctx *ctx = new ddm_ctx;
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess) {
+    delete ctx;
+    return DDM_EHIP;
+  }
+  if (hip_stream) ctx->stream = (hipStream_t)hip_stream;
+  else {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete ctx;
+      return DDM_EHIP;
+    }
+    ctx->own_stream = true;
+  }
+  if (hipMalloc((void **)&ctx->partial, sizeof(double) * RED_MAX_BLOCKS) != hipSuccess ||
+      hipMalloc((void **)&ctx->scal, sizeof(double) * 16) != hipSuccess ||
+      hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+    delete ctx;
+    return DDM_EHIP;
+  }
+  (void)hipMemset(ctx->scal, 0, sizeof(double) * 16);
+  *out = ctx;
+  return DDM_OK;
+}
+
+extern "C" void ddm_ctx_destroy(ddm_ctx *ctx)
+{
+  if (!ctx) return;
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(ctx->partial);
+  (void)hipFree(ctx->scal);
+  (void)hipEventDestroy(ctx->ev0);
+  (void)hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+extern "C" const char *ddm_last_error(const ddm_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+extern "C" int ddm_ctx_sync(ddm_ctx *ctx)
+{
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return DDM_OK;
+}
+extern "C" void *ddm_ctx_stream(ddm_ctx *ctx) { return (void *)ctx->stream; }
+extern "C" int ddm_ctx_set_comm(ddm_ctx *ctx, int rank, int nranks, ddm_alltoall_fn a2a, ddm_allreduce_fn allreduce, void *user)
+{
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, DDM_EINVAL, "bad rank %d of %d", rank, nranks);
+  if (nranks > 1 && (!a2a || !allreduce)) return fail(ctx, DDM_EINVAL, "multi-rank context needs both callbacks");
+  ctx->rank = rank;
+  ctx->nranks = nranks;
+  ctx->a2a = a2a;
+  ctx->allreduce = allreduce;
+  ctx->user = user;
+  return DDM_OK;
+}
+extern "C" int ddm_malloc(ddm_ctx *ctx, int64_t bytes, void **dptr)
+{
+  HIPCHECK(ctx, hipMalloc(dptr, (size_t)std::max<int64_t>(bytes, 8)));
+  return DDM_OK;
+}
+extern "C" int ddm_free(ddm_ctx *ctx, void *dptr)
+{
+  HIPCHECK(ctx, hipFree(dptr));
+  return DDM_OK;
+}
+extern "C" int ddm_memcpy_h2d(ddm_ctx *ctx, void *dst, const void *src, int64_t bytes)
+{
+  HIPCHECK(ctx, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return DDM_OK;
+}
+extern "C" int ddm_memcpy_d2h(ddm_ctx *ctx, void *dst, const void *src, int64_t bytes)
+{
+  HIPCHECK(ctx, hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return DDM_OK;
+}
+extern "C" int ddm_timing_enable(ddm_ctx *ctx, int on)
+{
+  ctx->timing = on != 0;
+  return DDM_OK;
+}
+extern "C" int ddm_timing_get(ddm_ctx *ctx, const char *name, double *total_ms, int64_t *count)
+{
+  auto it = ctx->timers.find(name);
+  if (it == ctx->timers.end()) {
+    if (total_ms) *total_ms = 0.0;
+    if (count) *count = 0;
+    return DDM_OK;
+  }
+  if (total_ms) *total_ms = it->second.ms;
+  if (count) *count = it->second.count;
+  return DDM_OK;
+}
+extern "C" int ddm_timing_reset(ddm_ctx *ctx)
+{
+  ctx->timers.clear();
+  return DDM_OK;
+}
+
+// ---- CSR ---------------------------------------------------------------------------------------
+struct ddm_csr {
+  int64_t nrows = 0, ncols = 0, nnz = 0;
+  std::vector<int64_t> h_rp; // host copies are kept for the ILU(0) factorisation / analysis
+  std::vector<int32_t> h_ci;
+  std::vector<double> h_va;
+  int64_t *rp = nullptr;
+  int32_t *ci = nullptr;
+  double *va = nullptr;
+  int32_t *blk_row = nullptr;
+  int nblk = 0;
+};
+
+extern "C" int ddm_csr_create(ddm_ctx *ctx, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *col,
+                              const double *val, ddm_csr **out)
+{
+  if (!ctx || !out || nrows < 0 || !rowptr) return fail(ctx, DDM_EINVAL, "ddm_csr_create: bad arguments");
+  if (nrows >= (int64_t)1 << 31 || ncols >= (int64_t)1 << 31) return fail(ctx, DDM_EINVAL, "matrix dimension exceeds int32 columns");
+  const int64_t nnz = rowptr[nrows];
+  for (int64_t i = 0; i < nrows; ++i)
+    if (rowptr[i + 1] < rowptr[i]) return fail(ctx, DDM_EINVAL, "row pointers not monotone at row %lld", (long long)i);
+  for (int64_t k = 0; k < nnz; ++k)
+    if (col[k] < 0 || col[k] >= ncols) return fail(ctx, DDM_EINVAL, "column index out of range at entry %lld", (long long)k);
+  ddm_csr *A = new ddm_csr;
+  A->nrows = nrows;
+  A->ncols = ncols;
+  A->nnz = nnz;
+  A->h_rp.assign(rowptr, rowptr + nrows + 1);
+  A->h_ci.assign(col, col + nnz);
+  A->h_va.assign(val, val + nnz);
+  // row-block schedule of the CSR-stream kernel: <= SPMV_NNZ non-zeros and <= WG rows per block,
+  // a row longer than SPMV_NNZ gets a block of its own
+  std::vector<int32_t> blk;
+  blk.push_back(0);
+  int64_t r = 0;
+  while (r < nrows) {
+    int64_t r1 = r;
+    const int64_t z0 = rowptr[r];
+    while (r1 < nrows && r1 - r < WG && rowptr[r1 + 1] - z0 <= SPMV_NNZ) ++r1;
+    if (r1 == r) r1 = r + 1; // long row
+    blk.push_back((int32_t)r1);
+    r = r1;
+  }
+  A->nblk = (int)blk.size() - 1;
+  int rc = upload(ctx, rowptr, nrows + 1, &A->rp);
+  if (!rc) rc = upload(ctx, col, nnz, &A->ci);
+  if (!rc) rc = upload(ctx, val, nnz, &A->va);
+  if (!rc) rc = upload(ctx, blk.data(), (int64_t)blk.size(), &A->blk_row);
+  if (rc) {
+    ddm_csr_destroy(A);
+    return rc;
+  }
+  *out = A;
+  return DDM_OK;
+}
+extern "C" void ddm_csr_destroy(ddm_csr *A)
+{
+  if (!A) return;
+  (void)hipFree(A->rp);
+  (void)hipFree(A->ci);
+  (void)hipFree(A->va);
+  (void)hipFree(A->blk_row);
+  delete A;
+}
+extern "C" int64_t ddm_csr_rows(const ddm_csr *A) { return A->nrows; }
+extern "C" int64_t ddm_csr_nnz(const ddm_csr *A) { return A->nnz; }
+
+static int csr_mv_impl(ddm_ctx *ctx, const ddm_csr *A, double alpha, const double *x, double *y, bool acc)
+{
+  if (A->nblk == 0) return DDM_OK;
+  if (acc)
+    hipLaunchKernelGGL(k_spmv_stream<true>, dim3(A->nblk), dim3(WG), 0, ctx->stream, A->rp, A->ci, A->va, A->blk_row, A->nblk, x, y, alpha);
+  else
+    hipLaunchKernelGGL(k_spmv_stream<false>, dim3(A->nblk), dim3(WG), 0, ctx->stream, A->rp, A->ci, A->va, A->blk_row, A->nblk, x, y, alpha);
+  HIPCHECK(ctx, hipGetLastError());
+  return DDM_OK;
+}
+extern "C" int ddm_csr_mv(ddm_ctx *ctx, const ddm_csr *A, const double *x, double *y)
+{
+  if (x == y) return fail(ctx, DDM_EINVAL, "ddm_csr_mv: x and y alias");
+  return csr_mv_impl(ctx, A, 1.0, x, y, false);
+}
+extern "C" int ddm_csr_usmv(ddm_ctx *ctx, const ddm_csr *A, double alpha, const double *x, double *y)
+{
+  if (x == y) return fail(ctx, DDM_EINVAL, "ddm_csr_usmv: x and y alias");
+  return csr_mv_impl(ctx, A, alpha, x, y, true);
+}
+
+// ---- ILU(0) -----------------------------------------------------------------------------------
+// Host factorisation: dune-istl blockILU0Decomposition semantics (IKJ in the pattern, multipliers
+// in L, inverse pivots on the diagonal), natural row order; independent diagonal blocks
+// (subdomains) are factorised by separate threads.
+static int ilu0_factor_block(const int64_t *rp, const int32_t *ci, double *lu, int64_t *diag, int64_t r0, int64_t r1)
+{
+  for (int64_t i = r0; i < r1; ++i) {
+    diag[i] = -1;
+    for (int64_t k = rp[i]; k < rp[i + 1]; ++k) {
+      if (ci[k] < r0 || ci[k] >= r1) return -2; // entry outside the diagonal block
+      if (k > rp[i] && ci[k] <= ci[k - 1]) return -3; // unsorted row
+      if (ci[k] == i) diag[i] = k;
+    }
+    if (diag[i] < 0) return -1;
+  }
+  for (int64_t i = r0; i < r1; ++i) {
+    for (int64_t kk = rp[i]; kk < diag[i]; ++kk) {
+      const int64_t k = ci[kk];
+      lu[kk] *= lu[diag[k]];
+      const double lik = lu[kk];
+      int64_t pi = kk + 1;
+      for (int64_t pk = diag[k] + 1; pk < rp[k + 1]; ++pk) {
+        const int32_t j = ci[pk];
+        while (pi < rp[i + 1] && ci[pi] < j) ++pi;
+        if (pi == rp[i + 1]) break;
+        if (ci[pi] == j) lu[pi] -= lik * lu[pk];
+      }
+    }
+    if (lu[diag[i]] == 0.0) return -1;
+    lu[diag[i]] = 1.0 / lu[diag[i]];
+  }
+  return 0;
+}
+
+struct TriSchedule { // one triangular factor, level by level in sliced ELL
+  int64_t nlev = 0;
+  std::vector<LevelDesc> desc;        // per level
+  int32_t *rows = nullptr;            // [n] rows sorted by level
+  int32_t *cols = nullptr;            // sliced ELL columns
+  double *vals = nullptr;             // sliced ELL values
+  double *dinv = nullptr;             // upper only: inverse pivots in level order
+  LevelDesc *d_desc = nullptr;        // device copy (for the small-level kernel)
+  struct Launch {                     // execution plan
+    int first, count;                 // levels [first, first+count)
+    bool small;                       // one workgroup loops over the levels
+  };
+  std::vector<Launch> plan;
+  int64_t ell_entries = 0;
+};
+
+struct ddm_ilu0 {
+  int64_t n = 0, nnz = 0;
+  std::vector<double> h_lu; // factor values in the pattern of A
+  TriSchedule L, U;
+  // HIP graph cache of the whole solve for one (d, x) pointer pair
+  hipGraphExec_t graph = nullptr;
+  const double *g_d = nullptr;
+  double *g_x = nullptr;
+};
+
+static constexpr int SMALL_LEVEL_ROWS = 2048;
+static constexpr int SMALL_LEVELS_PER_LAUNCH = 256;
+
+// Builds the level schedule of the lower (upper=false) or upper factor.
+static int build_schedule(ddm_ctx *ctx, const ddm_csr *A, const std::vector<double> &lu, const std::vector<int64_t> &diag,
+                          bool upper, TriSchedule &S)
+{
+  const int64_t n = A->nrows;
+  const int64_t *rp = A->h_rp.data();
+  const int32_t *ci = A->h_ci.data();
+  std::vector<int32_t> level(n, 0);
+  int32_t maxlev = -1;
+  if (!upper) {
+    for (int64_t i = 0; i < n; ++i) {
+      int32_t l = 0;
+      for (int64_t k = rp[i]; k < diag[i]; ++k) l = std::max(l, level[ci[k]] + 1);
+      level[i] = l;
+      maxlev = std::max(maxlev, l);
+    }
+  } else {
+    for (int64_t i = n - 1; i >= 0; --i) {
+      int32_t l = 0;
+      for (int64_t k = diag[i] + 1; k < rp[i + 1]; ++k) l = std::max(l, level[ci[k]] + 1);
+      level[i] = l;
+      maxlev = std::max(maxlev, l);
+    }
+  }
+  const int64_t nlev = (int64_t)maxlev + 1;
+  S.nlev = nlev;
+  std::vector<int64_t> lptr(nlev + 1, 0);
+  for (int64_t i = 0; i < n; ++i) lptr[level[i] + 1]++;
+  for (int64_t l = 0; l < nlev; ++l) lptr[l + 1] += lptr[l];
+  std::vector<int32_t> rows(n);
+  {
+    std::vector<int64_t> pos(lptr.begin(), lptr.end() - 1);
+    for (int64_t i = 0; i < n; ++i) rows[pos[level[i]]++] = (int32_t)i; // ascending row inside a level
+  }
+  S.desc.resize(nlev);
+  int64_t ent = 0;
+  for (int64_t l = 0; l < nlev; ++l) {
+    const int64_t m = lptr[l + 1] - lptr[l];
+    int w = 0;
+    for (int64_t r = lptr[l]; r < lptr[l + 1]; ++r) {
+      const int64_t i = rows[r];
+      const int cnt = upper ? (int)(rp[i + 1] - diag[i] - 1) : (int)(diag[i] - rp[i]);
+      w = std::max(w, cnt);
+    }
+    S.desc[l] = LevelDesc{(int32_t)m, (int32_t)w, lptr[l], ent};
+    ent += m * (int64_t)w;
+  }
+  S.ell_entries = ent;
+  std::vector<int32_t> cols((size_t)std::max<int64_t>(ent, 1));
+  std::vector<double> vals((size_t)std::max<int64_t>(ent, 1));
+  std::vector<double> dinv;
+  if (upper) dinv.resize(n);
+  for (int64_t l = 0; l < nlev; ++l) {
+    const LevelDesc &D = S.desc[l];
+    for (int64_t r = 0; r < D.m; ++r) {
+      const int64_t i = rows[D.row_off + r];
+      const int64_t k0 = upper ? diag[i] + 1 : rp[i];
+      const int64_t k1 = upper ? rp[i + 1] : diag[i];
+      int k = 0;
+      for (int64_t p = k0; p < k1; ++p, ++k) {
+        cols[D.ent_off + (int64_t)k * D.m + r] = ci[p];
+        vals[D.ent_off + (int64_t)k * D.m + r] = lu[p];
+      }
+      for (; k < D.w; ++k) { // padding: a dependency that is already resolved, value 0
+        cols[D.ent_off + (int64_t)k * D.m + r] = ci[k0];
+        vals[D.ent_off + (int64_t)k * D.m + r] = 0.0;
+      }
+      if (upper) dinv[D.row_off + r] = lu[diag[i]];
+    }
+  }
+  // launch plan: runs of small levels share one single-workgroup launch
+  int l = 0;
+  while (l < nlev) {
+    if (S.desc[l].m <= SMALL_LEVEL_ROWS) {
+      int c = 0;
+      while (l + c < nlev && c < SMALL_LEVELS_PER_LAUNCH && S.desc[l + c].m <= SMALL_LEVEL_ROWS) ++c;
+      S.plan.push_back({l, c, true});
+      l += c;
+    } else {
+      S.plan.push_back({l, 1, false});
+      l += 1;
+    }
+  }
+  DDMCHECK(upload(ctx, rows.data(), n, &S.rows));
+  DDMCHECK(upload(ctx, cols.data(), ent, &S.cols));
+  DDMCHECK(upload(ctx, vals.data(), ent, &S.vals));
+  if (upper) DDMCHECK(upload(ctx, dinv.data(), n, &S.dinv));
+  DDMCHECK(upload(ctx, S.desc.data(), nlev, &S.d_desc));
+  return DDM_OK;
+}
+
+static void free_schedule(TriSchedule &S)
+{
+  (void)hipFree(S.rows);
+  (void)hipFree(S.cols);
+  (void)hipFree(S.vals);
+  (void)hipFree(S.dinv);
+  (void)hipFree(S.d_desc);
+}
+
+extern "C" int ddm_ilu0_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, ddm_ilu0 **out)
+{
+  if (!ctx || !A || !out || nblocks < 1 || !block_ptr) return fail(ctx, DDM_EINVAL, "ddm_ilu0_create: bad arguments");
+  if (A->nrows != A->ncols) return fail(ctx, DDM_EINVAL, "ILU(0) needs a square matrix");
+  if (block_ptr[0] != 0 || block_ptr[nblocks] != A->nrows) return fail(ctx, DDM_EINVAL, "block_ptr does not cover the matrix");
+  ddm_ilu0 *F = new ddm_ilu0;
+  F->n = A->nrows;
+  F->nnz = A->nnz;
+  F->h_lu = A->h_va;
+  std::vector<int64_t> diag(A->nrows);
+  std::vector<int> rcs(nblocks, 0);
+  {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int nthreads = (int)std::min<int64_t>(nblocks, hw);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t)
+      th.emplace_back([&, t]() {
+        for (int64_t b = t; b < nblocks; b += nthreads)
+          rcs[b] = ilu0_factor_block(A->h_rp.data(), A->h_ci.data(), F->h_lu.data(), diag.data(), block_ptr[b], block_ptr[b + 1]);
+      });
+    for (auto &t : th) t.join();
+  }
+  for (int64_t b = 0; b < nblocks; ++b)
+    if (rcs[b]) {
+      const int rc = rcs[b];
+      delete F;
+      if (rc == -2) return fail(ctx, DDM_EINVAL, "ILU(0): block %lld has entries outside its diagonal block", (long long)b);
+      if (rc == -3) return fail(ctx, DDM_EINVAL, "ILU(0): rows must have sorted column indices");
+      return fail(ctx, DDM_ENUMERIC, "ILU(0): missing or zero pivot in block %lld", (long long)b);
+    }
+  int rc = build_schedule(ctx, A, F->h_lu, diag, false, F->L);
+  if (!rc) rc = build_schedule(ctx, A, F->h_lu, diag, true, F->U);
+  if (rc) {
+    ddm_ilu0_destroy(F);
+    return rc;
+  }
+  *out = F;
+  return DDM_OK;
+}
+extern "C" void ddm_ilu0_destroy(ddm_ilu0 *F)
+{
+  if (!F) return;
+  if (F->graph) (void)hipGraphExecDestroy(F->graph);
+  free_schedule(F->L);
+  free_schedule(F->U);
+  delete F;
+}
+extern "C" int64_t ddm_ilu0_num_levels(const ddm_ilu0 *F, int upper) { return upper ? F->U.nlev : F->L.nlev; }
+extern "C" int ddm_ilu0_get_factors_host(ddm_ctx *ctx, const ddm_ilu0 *F, double *lu_host)
+{
+  if (!F || !lu_host) return fail(ctx, DDM_EINVAL, "bad arguments");
+  std::memcpy(lu_host, F->h_lu.data(), sizeof(double) * (size_t)F->nnz);
+  return DDM_OK;
+}
+
+static int enqueue_tri(ddm_ctx *ctx, const TriSchedule &S, bool upper, const double *d, double *x)
+{
+  for (const auto &p : S.plan) {
+    if (p.small) {
+      if (upper)
+        hipLaunchKernelGGL(k_trsv_small_levels<true>, dim3(1), dim3(TRSV_SMALL_WG), 0, ctx->stream, p.count, S.d_desc + p.first,
+                           S.rows, S.cols, S.vals, S.dinv, d, x);
+      else
+        hipLaunchKernelGGL(k_trsv_small_levels<false>, dim3(1), dim3(TRSV_SMALL_WG), 0, ctx->stream, p.count, S.d_desc + p.first,
+                           S.rows, S.cols, S.vals, S.dinv, d, x);
+    } else {
+      const LevelDesc &D = S.desc[p.first];
+      const int grid = (D.m + WG - 1) / WG;
+      if (upper)
+        hipLaunchKernelGGL(k_trsv_upper_level, dim3(grid), dim3(WG), 0, ctx->stream, D.m, D.w, S.rows + D.row_off, S.cols + D.ent_off,
+                           S.vals + D.ent_off, S.dinv + D.row_off, x);
+      else
+        hipLaunchKernelGGL(k_trsv_lower_level, dim3(grid), dim3(WG), 0, ctx->stream, D.m, D.w, S.rows + D.row_off, S.cols + D.ent_off,
+                           S.vals + D.ent_off, d, x);
+    }
+  }
+  HIPCHECK(ctx, hipGetLastError());
+  return DDM_OK;
+}
+
+extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x)
+{
+  if (!F || !d || !x || d == x) return fail(ctx, DDM_EINVAL, "ddm_ilu0_solve: bad arguments (d and x must not alias)");
+  if (F->graph && F->g_d == d && F->g_x == x) {
+    HIPCHECK(ctx, hipGraphLaunch(F->graph, ctx->stream));
+    return DDM_OK;
+  }
+  // (re)capture the ~2*nlev launches into a graph bound to this (d, x) pair
+  if (F->graph) {
+    (void)hipGraphExecDestroy(F->graph);
+    F->graph = nullptr;
+  }
+  hipGraph_t g = nullptr;
+  HIPCHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  int rc = enqueue_tri(ctx, F->L, false, d, x);
+  if (!rc) rc = enqueue_tri(ctx, F->U, true, d, x);
+  hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(ctx, DDM_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+  e = hipGraphInstantiate(&F->graph, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) {
+    F->graph = nullptr;
+    return fail(ctx, DDM_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+  }
+  F->g_d = d;
+  F->g_x = x;
+  HIPCHECK(ctx, hipGraphLaunch(F->graph, ctx->stream));
+  return DDM_OK;
+}
+
+// ---- halo --------------------------------------------------------------------------------------
+struct ddm_halo {
+  int tag = 0, mode = 0;
+  int64_t nsend = 0, nrecv = 0, ndst = 0, self_off_send = 0, self_off_recv = 0, self_count = 0;
+  int64_t *send_idx = nullptr, *dst_idx = nullptr, *dst_ptr = nullptr, *src_pos = nullptr;
+  double *sendbuf = nullptr, *recvbuf = nullptr;
+  bool remote = false; // any traffic to/from other ranks
+};
+
+extern "C" int ddm_halo_create(ddm_ctx *ctx, int tag, int mode, int64_t nsend, const int64_t *send_idx,
+                               const int64_t *send_counts, const int64_t *recv_counts, int64_t ndst, const int64_t *dst_idx,
+                               const int64_t *dst_ptr, const int64_t *src_pos, ddm_halo **out)
+{
+  if (!ctx || !out || (mode != 0 && mode != 1)) return fail(ctx, DDM_EINVAL, "ddm_halo_create: bad arguments");
+  ddm_halo *H = new ddm_halo;
+  H->tag = tag;
+  H->mode = mode;
+  H->nsend = nsend;
+  H->ndst = ndst;
+  int64_t ssum = 0, rsum = 0;
+  for (int r = 0; r < ctx->nranks; ++r) {
+    if (r == ctx->rank) {
+      H->self_off_send = ssum;
+      H->self_off_recv = rsum;
+      H->self_count = send_counts[r];
+      if (send_counts[r] != recv_counts[r]) {
+        delete H;
+        return fail(ctx, DDM_EINVAL, "halo: self send/recv counts differ");
+      }
+    } else if (send_counts[r] || recv_counts[r])
+      H->remote = true;
+    ssum += send_counts[r];
+    rsum += recv_counts[r];
+  }
+  if (ssum != nsend) {
+    delete H;
+    return fail(ctx, DDM_EINVAL, "halo: send_counts do not sum to nsend");
+  }
+  H->nrecv = rsum;
+  const int64_t nsrc = ndst > 0 ? dst_ptr[ndst] : 0;
+  for (int64_t k = 0; k < nsrc; ++k)
+    if (src_pos[k] < 0 || src_pos[k] >= rsum) {
+      delete H;
+      return fail(ctx, DDM_EINVAL, "halo: src_pos out of range");
+    }
+  int rc = upload(ctx, send_idx, nsend, &H->send_idx);
+  if (!rc) rc = upload(ctx, dst_idx, ndst, &H->dst_idx);
+  if (!rc) rc = upload(ctx, dst_ptr, ndst + 1, &H->dst_ptr);
+  if (!rc) rc = upload(ctx, src_pos, nsrc, &H->src_pos);
+  if (!rc && hipMalloc((void **)&H->sendbuf, sizeof(double) * (size_t)std::max<int64_t>(nsend, 1)) != hipSuccess) rc = DDM_EHIP;
+  if (!rc && hipMalloc((void **)&H->recvbuf, sizeof(double) * (size_t)std::max<int64_t>(rsum, 1)) != hipSuccess) rc = DDM_EHIP;
+  if (rc) {
+    ddm_halo_destroy(H);
+    return fail(ctx, rc, "halo: device allocation failed");
+  }
+  *out = H;
+  return DDM_OK;
+}
+extern "C" void ddm_halo_destroy(ddm_halo *H)
+{
+  if (!H) return;
+  (void)hipFree(H->send_idx);
+  (void)hipFree(H->dst_idx);
+  (void)hipFree(H->dst_ptr);
+  (void)hipFree(H->src_pos);
+  (void)hipFree(H->sendbuf);
+  (void)hipFree(H->recvbuf);
+  delete H;
+}
+extern "C" double *ddm_halo_sendbuf(ddm_halo *H) { return H->sendbuf; }
+extern "C" double *ddm_halo_recvbuf(ddm_halo *H) { return H->recvbuf; }
+
+extern "C" int ddm_halo_exchange(ddm_ctx *ctx, ddm_halo *H, double *v)
+{
+  if (!H) return DDM_OK;
+  if (H->nsend == 0 && H->ndst == 0 && !H->remote) return DDM_OK;
+  if (H->nsend > 0) hipLaunchKernelGGL(k_pack, dim3(grid_for(H->nsend)), dim3(WG), 0, ctx->stream, H->nsend, H->send_idx, v, H->sendbuf);
+  const double *rbuf = H->recvbuf;
+  if (ctx->nranks > 1) {
+    if (ctx->a2a(ctx->user, H->tag, H->sendbuf, H->recvbuf) != 0) return fail(ctx, DDM_ECOMM, "alltoall callback failed (tag %d)", H->tag);
+  } else {
+    rbuf = H->sendbuf; // single rank: the self segment is the whole buffer
+  }
+  if (H->ndst > 0) {
+    if (H->mode == 1)
+      hipLaunchKernelGGL(k_unpack<true>, dim3(grid_for(H->ndst)), dim3(WG), 0, ctx->stream, H->ndst, H->dst_idx, H->dst_ptr, H->src_pos, rbuf, v);
+    else
+      hipLaunchKernelGGL(k_unpack<false>, dim3(grid_for(H->ndst)), dim3(WG), 0, ctx->stream, H->ndst, H->dst_idx, H->dst_ptr, H->src_pos, rbuf, v);
+  }
+  HIPCHECK(ctx, hipGetLastError());
+  return DDM_OK;
+}
+
+// ---- reductions --------------------------------------------------------------------------------
+// result (device scalar) = sum over ranks of sum_i [mask_i] x_i y_i
+static int dot_device(ddm_ctx *ctx, int64_t n, const uint8_t *mask, const double *x, const double *y, double *result_dev)
+{
+  const int nb = grid_for(n, WG * 4, RED_MAX_BLOCKS);
+  if (mask)
+    hipLaunchKernelGGL(k_dot_partial<true>, dim3(nb), dim3(WG), 0, ctx->stream, n, mask, x, y, ctx->partial);
+  else
+    hipLaunchKernelGGL(k_dot_partial<false>, dim3(nb), dim3(WG), 0, ctx->stream, n, mask, x, y, ctx->partial);
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(WG), 0, ctx->stream, nb, ctx->partial, result_dev);
+  HIPCHECK(ctx, hipGetLastError());
+  if (ctx->nranks > 1)
+    if (ctx->allreduce(ctx->user, result_dev, 1) != 0) return fail(ctx, DDM_ECOMM, "allreduce callback failed");
+  return DDM_OK;
+}
+
+// ---- NonOverlappingOperator --------------------------------------------------------------------
+struct ddm_op {
+  const ddm_csr *A = nullptr;
+  ddm_halo *halo = nullptr;
+  uint8_t *owner = nullptr;
+  int64_t n = 0;
+  double *tmp = nullptr;
+};
+extern "C" int ddm_op_create(ddm_ctx *ctx, const ddm_csr *A, ddm_halo *novlp_add, const uint8_t *owner_mask_host, ddm_op **out)
+{
+  if (!ctx || !A || !out || !owner_mask_host) return fail(ctx, DDM_EINVAL, "ddm_op_create: bad arguments");
+  if (A->nrows != A->ncols) return fail(ctx, DDM_EINVAL, "operator matrix must be square");
+  if (novlp_add && novlp_add->mode != 1) return fail(ctx, DDM_EINVAL, "operator halo must be an 'add' halo");
+  ddm_op *op = new ddm_op;
+  op->A = A;
+  op->halo = novlp_add;
+  op->n = A->nrows;
+  int rc = upload(ctx, owner_mask_host, op->n, &op->owner);
+  if (!rc && hipMalloc((void **)&op->tmp, sizeof(double) * (size_t)std::max<int64_t>(op->n, 1)) != hipSuccess) rc = DDM_EHIP;
+  if (rc) {
+    ddm_op_destroy(op);
+    return fail(ctx, rc, "ddm_op_create: allocation failed");
+  }
+  *out = op;
+  return DDM_OK;
+}
+extern "C" void ddm_op_destroy(ddm_op *op)
+{
+  if (!op) return;
+  (void)hipFree(op->owner);
+  (void)hipFree(op->tmp);
+  delete op;
+}
+extern "C" int ddm_op_apply(ddm_ctx *ctx, ddm_op *op, const double *x, double *y)
+{
+  ScopedTimer t(ctx, "Operator/apply");
+  DDMCHECK(ddm_csr_mv(ctx, op->A, x, y));           // A->mv(x, y)
+  return ddm_halo_exchange(ctx, op->halo, y);       // comm->addOwnerCopyToOwnerCopy(y, y)
+}
+extern "C" int ddm_op_applyscaleadd(ddm_ctx *ctx, ddm_op *op, double alpha, const double *x, double *y)
+{
+  ScopedTimer t(ctx, "Operator/applyscaleadd");
+  // y1 = y; y = 0; usmv; halo; y += y1   (only alpha*A*x is communicated, y is already consistent)
+  DDMCHECK(ddm_csr_mv(ctx, op->A, x, op->tmp));
+  DDMCHECK(ddm_halo_exchange(ctx, op->halo, op->tmp));
+  hipLaunchKernelGGL(k_axpy, dim3(grid_for(op->n)), dim3(WG), 0, ctx->stream, op->n, alpha, op->tmp, y);
+  HIPCHECK(ctx, hipGetLastError());
+  return DDM_OK;
+}
+extern "C" int ddm_dot(ddm_ctx *ctx, ddm_op *op, const double *x, const double *y, double *result_host)
+{
+  DDMCHECK(dot_device(ctx, op->n, op->owner, x, y, ctx->scal + 8));
+  return ddm_memcpy_d2h(ctx, result_host, ctx->scal + 8, sizeof(double));
+}
+extern "C" int ddm_norm(ddm_ctx *ctx, ddm_op *op, const double *x, double *result_host)
+{
+  DDMCHECK(ddm_dot(ctx, op, x, x, result_host));
+  *result_host = std::sqrt(*result_host);
+  return DDM_OK;
+}
+
+// ---- SchwarzPreconditioner ---------------------------------------------------------------------
+struct ddm_schwarz {
+  int64_t n = 0, n_novlp = 0;
+  int type = 1;
+  ddm_ilu0 *solver = nullptr;
+  int32_t *ext_map = nullptr;
+  double *pou = nullptr;
+  double *d_ovlp = nullptr, *x_ovlp = nullptr;
+  ddm_halo *copy = nullptr, *add = nullptr;
+};
+extern "C" int ddm_schwarz_create(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t nblocks, const int64_t *block_ptr, int64_t n_novlp,
+                                  const int32_t *ext_map_host, const double *pou_host, int type, ddm_halo *ovlp_copy,
+                                  ddm_halo *ovlp_add, ddm_schwarz **out)
+{
+  if (!ctx || !A_dir || !out || !ext_map_host) return fail(ctx, DDM_EINVAL, "ddm_schwarz_create: bad arguments");
+  if (type != 0 && type != 1) return fail(ctx, DDM_ENOTIMPL, "Unknown Schwarz type %d", type); // schwarz.hh:83
+  if (ovlp_copy && ovlp_copy->mode != 0) return fail(ctx, DDM_EINVAL, "ovlp_copy must be a 'copy' halo");
+  if (ovlp_add && ovlp_add->mode != 1) return fail(ctx, DDM_EINVAL, "ovlp_add must be an 'add' halo");
+  const int64_t n = A_dir->nrows;
+  for (int64_t i = 0; i < n; ++i)
+    if (ext_map_host[i] >= n_novlp) return fail(ctx, DDM_EINVAL, "ext_map entry out of range"); // size checks, schwarz.hh:186-193
+  ddm_schwarz *S = new ddm_schwarz;
+  S->n = n;
+  S->n_novlp = n_novlp;
+  S->type = type;
+  S->copy = ovlp_copy;
+  S->add = ovlp_add;
+  int rc = ddm_ilu0_create(ctx, A_dir, nblocks, block_ptr, &S->solver); // factorisation happens in the ctor (:92)
+  if (!rc) rc = upload(ctx, ext_map_host, n, &S->ext_map);
+  if (!rc && pou_host) rc = upload(ctx, pou_host, n, &S->pou);
+  if (!rc && hipMalloc((void **)&S->d_ovlp, sizeof(double) * (size_t)std::max<int64_t>(n, 1)) != hipSuccess) rc = fail(ctx, DDM_EHIP, "alloc");
+  if (!rc && hipMalloc((void **)&S->x_ovlp, sizeof(double) * (size_t)std::max<int64_t>(n, 1)) != hipSuccess) rc = fail(ctx, DDM_EHIP, "alloc");
+  if (rc) {
+    ddm_schwarz_destroy(S);
+    return rc;
+  }
+  *out = S;
+  return DDM_OK;
+}
+extern "C" void ddm_schwarz_destroy(ddm_schwarz *S)
+{
+  if (!S) return;
+  ddm_ilu0_destroy(S->solver);
+  (void)hipFree(S->ext_map);
+  (void)hipFree(S->pou);
+  (void)hipFree(S->d_ovlp);
+  (void)hipFree(S->x_ovlp);
+  delete S;
+}
+// x (= or +=) R~^T [D] A_dir^-1 R~ d
+static int schwarz_apply_impl(ddm_ctx *ctx, ddm_schwarz *S, double *x, const double *d, bool acc)
+{
+  {
+    ScopedTimer t(ctx, "Schwarz/get defect");
+    hipLaunchKernelGGL(k_extend, dim3(grid_for(S->n)), dim3(WG), 0, ctx->stream, S->n, S->ext_map, d, S->d_ovlp); // :121-122
+    DDMCHECK(ddm_halo_exchange(ctx, S->copy, S->d_ovlp));                                                          // :125
+  }
+  {
+    ScopedTimer t(ctx, "Schwarz/local solve");
+    DDMCHECK(ddm_ilu0_solve(ctx, S->solver, S->d_ovlp, S->x_ovlp)); // :131-133
+  }
+  {
+    ScopedTimer t(ctx, "Schwarz/add solution");
+    if (S->type == 1 && S->pou)
+      hipLaunchKernelGGL(k_scale, dim3(grid_for(S->n)), dim3(WG), 0, ctx->stream, S->n, S->pou, S->x_ovlp); // :139-141
+    DDMCHECK(ddm_halo_exchange(ctx, S->add, S->x_ovlp));                                                     // :138/:142
+    if (acc)
+      hipLaunchKernelGGL((k_restrict<true, false>), dim3(grid_for(S->n)), dim3(WG), 0, ctx->stream, S->n, S->ext_map, S->x_ovlp, (const double *)nullptr, x);
+    else
+      hipLaunchKernelGGL((k_restrict<false, false>), dim3(grid_for(S->n)), dim3(WG), 0, ctx->stream, S->n, S->ext_map, S->x_ovlp, (const double *)nullptr, x); // :146
+    HIPCHECK(ctx, hipGetLastError());
+  }
+  return DDM_OK;
+}
+extern "C" int ddm_schwarz_apply(ddm_ctx *ctx, ddm_schwarz *S, double *x, const double *d)
+{
+  ScopedTimer t(ctx, "Schwarz/apply");
+  return schwarz_apply_impl(ctx, S, x, d, false);
+}
+
+// ---- GalerkinPreconditioner --------------------------------------------------------------------
+struct ddm_galerkin {
+  int64_t n = 0, n_novlp = 0, nsub = 0, kmax = 0, K = 0, ld = 0;
+  int32_t *ext_map = nullptr;
+  double *basis = nullptr;       // kmax x ld
+  int64_t *coarse_index = nullptr;
+  double *a0inv = nullptr;
+  RowChunk *chunks = nullptr;
+  int32_t *sub_chunk_ptr = nullptr;
+  int nchunk = 0;
+  double *partial = nullptr, *d0 = nullptr, *x0 = nullptr;
+  double *d_ovlp = nullptr, *x_ovlp = nullptr;
+  ddm_halo *copy = nullptr, *add = nullptr;
+};
+static constexpr int64_t COARSE_CHUNK_ROWS = 8192;
+
+extern "C" int ddm_galerkin_create(ddm_ctx *ctx, int64_t n, int64_t n_novlp, const int32_t *ext_map_host, int64_t nsub,
+                                   const int64_t *sub_ptr, int64_t kmax, const double *basis_host, const int64_t *coarse_index,
+                                   int64_t K, const double *a0inv_host, ddm_halo *ovlp_copy, ddm_halo *ovlp_add,
+                                   ddm_galerkin **out)
+{
+  if (!ctx || !out || !ext_map_host || !sub_ptr || !basis_host || !coarse_index || !a0inv_host)
+    return fail(ctx, DDM_EINVAL, "ddm_galerkin_create: bad arguments");
+  if (kmax < 1) return fail(ctx, DDM_EINVAL, "Must at least pass one template vector"); // galerkin_preconditioner.hh:129
+  if (kmax > 64) return fail(ctx, DDM_ENOTIMPL, "more than 64 basis vectors per subdomain are not supported");
+  if (sub_ptr[0] != 0 || sub_ptr[nsub] != n) return fail(ctx, DDM_EINVAL, "Template vectors must match size of matrix"); // :131
+  for (int64_t t = 0; t < nsub * kmax; ++t)
+    if (coarse_index[t] >= K) return fail(ctx, DDM_EINVAL, "coarse_index out of range");
+  ddm_galerkin *G = new ddm_galerkin;
+  G->n = n;
+  G->n_novlp = n_novlp;
+  G->nsub = nsub;
+  G->kmax = kmax;
+  G->K = K;
+  G->ld = (n + 63) / 64 * 64;
+  G->copy = ovlp_copy;
+  G->add = ovlp_add;
+  std::vector<RowChunk> chunks;
+  std::vector<int32_t> scp(nsub + 1, 0);
+  for (int64_t s = 0; s < nsub; ++s) {
+    for (int64_t r = sub_ptr[s]; r < sub_ptr[s + 1]; r += COARSE_CHUNK_ROWS)
+      chunks.push_back(RowChunk{r, std::min(r + COARSE_CHUNK_ROWS, sub_ptr[s + 1]), (int32_t)s, 0});
+    scp[s + 1] = (int32_t)chunks.size();
+  }
+  G->nchunk = (int)chunks.size();
+  int rc = upload(ctx, ext_map_host, n, &G->ext_map);
+  if (!rc) rc = upload(ctx, coarse_index, nsub * kmax, &G->coarse_index);
+  if (!rc) rc = upload(ctx, a0inv_host, K * K, &G->a0inv);
+  if (!rc) rc = upload(ctx, chunks.data(), (int64_t)chunks.size(), &G->chunks);
+  if (!rc) rc = upload(ctx, scp.data(), nsub + 1, &G->sub_chunk_ptr);
+  auto dalloc = [&](double **p, int64_t cnt) {
+    if (!rc && hipMalloc((void **)p, sizeof(double) * (size_t)std::max<int64_t>(cnt, 1)) != hipSuccess) rc = fail(ctx, DDM_EHIP, "galerkin: allocation failed");
+  };
+  dalloc(&G->basis, kmax * G->ld);
+  dalloc(&G->partial, (int64_t)G->nchunk * kmax);
+  dalloc(&G->d0, K);
+  dalloc(&G->x0, K);
+  dalloc(&G->d_ovlp, n);
+  dalloc(&G->x_ovlp, n);
+  if (!rc && hipMemset(G->basis, 0, sizeof(double) * (size_t)(kmax * G->ld)) != hipSuccess) rc = DDM_EHIP;
+  if (!rc && hipMemcpy2D(G->basis, sizeof(double) * (size_t)G->ld, basis_host, sizeof(double) * (size_t)n, sizeof(double) * (size_t)n,
+                         (size_t)kmax, hipMemcpyHostToDevice) != hipSuccess)
+    rc = fail(ctx, DDM_EHIP, "galerkin: basis upload failed");
+  if (rc) {
+    ddm_galerkin_destroy(G);
+    return rc;
+  }
+  *out = G;
+  return DDM_OK;
+}
+extern "C" void ddm_galerkin_destroy(ddm_galerkin *G)
+{
+  if (!G) return;
+  (void)hipFree(G->ext_map);
+  (void)hipFree(G->basis);
+  (void)hipFree(G->coarse_index);
+  (void)hipFree(G->a0inv);
+  (void)hipFree(G->chunks);
+  (void)hipFree(G->sub_chunk_ptr);
+  (void)hipFree(G->partial);
+  (void)hipFree(G->d0);
+  (void)hipFree(G->x0);
+  (void)hipFree(G->d_ovlp);
+  (void)hipFree(G->x_ovlp);
+  delete G;
+}
+static int galerkin_apply_impl(ddm_ctx *ctx, ddm_galerkin *G, double *x, const double *d, bool acc)
+{
+  hipLaunchKernelGGL(k_extend, dim3(grid_for(G->n)), dim3(WG), 0, ctx->stream, G->n, G->ext_map, d, G->d_ovlp); // :159
+  DDMCHECK(ddm_halo_exchange(ctx, G->copy, G->d_ovlp));                                                         // :162
+  hipLaunchKernelGGL(k_coarse_restrict_partial, dim3(G->nchunk), dim3(WG), 0, ctx->stream, (int)G->kmax, G->ld, G->basis, G->d_ovlp,
+                     G->chunks, G->partial); // :165-167
+  hipLaunchKernelGGL(k_coarse_restrict_final, dim3(1), dim3(WG), 0, ctx->stream, (int)G->nsub, (int)G->kmax, G->sub_chunk_ptr, G->partial,
+                     G->coarse_index, G->K, G->d0);
+  HIPCHECK(ctx, hipGetLastError());
+  if (ctx->nranks > 1) // replaces MPI_Gatherv (:170-171): every rank obtains the full coarse defect
+    if (ctx->allreduce(ctx->user, G->d0, G->K) != 0) return fail(ctx, DDM_ECOMM, "allreduce callback failed (coarse defect)");
+  hipLaunchKernelGGL(k_dense_mv, dim3((unsigned)((G->K + 3) / 4)), dim3(WG), 0, ctx->stream, G->K, G->a0inv, G->d0, G->x0); // :174-179 (replicated)
+  hipLaunchKernelGGL(k_coarse_prolong, dim3(G->nchunk), dim3(WG), 0, ctx->stream, (int)G->kmax, G->ld, G->basis, G->x0, G->coarse_index,
+                     G->chunks, G->x_ovlp);       // :186-188
+  DDMCHECK(ddm_halo_exchange(ctx, G->add, G->x_ovlp)); // :190
+  if (acc)
+    hipLaunchKernelGGL((k_restrict<true, false>), dim3(grid_for(G->n)), dim3(WG), 0, ctx->stream, G->n, G->ext_map, G->x_ovlp, (const double *)nullptr, x);
+  else
+    hipLaunchKernelGGL((k_restrict<false, false>), dim3(grid_for(G->n)), dim3(WG), 0, ctx->stream, G->n, G->ext_map, G->x_ovlp, (const double *)nullptr, x); // :193
+  HIPCHECK(ctx, hipGetLastError());
+  return DDM_OK;
+}
+extern "C" int ddm_galerkin_apply(ddm_ctx *ctx, ddm_galerkin *G, double *x, const double *d)
+{
+  ScopedTimer t(ctx, "GalerkinPrec/apply");
+  return galerkin_apply_impl(ctx, G, x, d, false);
+}
+
+extern "C" int ddm_galerkin_products(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t nleft, const double *left, int64_t nright,
+                                     const double *right, int64_t row0, int64_t row1, double *out_host)
+{
+  // out[j*nleft + i] = <left_i, A_dir right_j> over rows [row0,row1)   (column-major nleft x nright,
+  // the slab layout of galerkin_preconditioner.hh:294 / helpers.hh:252)
+  if (!A_dir || !left || !right || !out_host || nleft < 1 || nleft > 64 || nright < 1 || row0 < 0 || row1 > A_dir->nrows || row0 > row1)
+    return fail(ctx, DDM_EINVAL, "ddm_galerkin_products: bad arguments");
+  const int64_t n = A_dir->nrows;
+  double *y = nullptr, *partial = nullptr, *outd = nullptr;
+  RowChunk *chunks = nullptr;
+  std::vector<RowChunk> hc;
+  for (int64_t r = row0; r < row1; r += COARSE_CHUNK_ROWS) hc.push_back(RowChunk{r, std::min(r + COARSE_CHUNK_ROWS, row1), 0, 0});
+  const int nchunk = (int)hc.size();
+  HIPCHECK(ctx, hipMalloc((void **)&y, sizeof(double) * (size_t)n));
+  HIPCHECK(ctx, hipMalloc((void **)&partial, sizeof(double) * (size_t)std::max<int64_t>((int64_t)nchunk * nleft, 1)));
+  HIPCHECK(ctx, hipMalloc((void **)&outd, sizeof(double) * (size_t)(nleft * nright)));
+  int rc = upload(ctx, hc.data(), (int64_t)hc.size(), &chunks);
+  std::vector<int32_t> scp = {0, nchunk};
+  std::vector<int64_t> cidx(nleft);
+  int32_t *d_scp = nullptr;
+  int64_t *d_cidx = nullptr;
+  if (!rc) rc = upload(ctx, scp.data(), 2, &d_scp);
+  for (int64_t j = 0; j < nright && !rc; ++j) {
+    rc = ddm_csr_mv(ctx, A_dir, right + j * n, y);
+    if (rc) break;
+    for (int64_t i = 0; i < nleft; ++i) cidx[i] = i;
+    if (!d_cidx) rc = upload(ctx, cidx.data(), nleft, &d_cidx);
+    if (rc) break;
+    if (nchunk > 0)
+      hipLaunchKernelGGL(k_coarse_restrict_partial, dim3(nchunk), dim3(WG), 0, ctx->stream, (int)nleft, n, left, y, chunks, partial);
+    hipLaunchKernelGGL(k_coarse_restrict_final, dim3(1), dim3(WG), 0, ctx->stream, 1, (int)nleft, d_scp, partial, d_cidx, nleft, outd + j * nleft);
+  }
+  if (!rc) rc = ddm_memcpy_d2h(ctx, out_host, outd, sizeof(double) * (size_t)(nleft * nright));
+  (void)hipFree(y);
+  (void)hipFree(partial);
+  (void)hipFree(outd);
+  (void)hipFree(chunks);
+  (void)hipFree(d_scp);
+  (void)hipFree(d_cidx);
+  return rc;
+}
+
+// ---- CombinedPreconditioner --------------------------------------------------------------------
+struct ddm_combined {
+  int mode = 0;
+  ddm_op *op = nullptr;
+  ddm_schwarz *schwarz = nullptr;
+  ddm_galerkin *galerkin = nullptr;
+  double *dnext = nullptr;
+  int64_t n = 0;
+};
+extern "C" int ddm_combined_create(ddm_ctx *ctx, int mode, ddm_op *op, ddm_schwarz *schwarz, ddm_galerkin *galerkin, ddm_combined **out)
+{
+  if (!ctx || !out || !schwarz) return fail(ctx, DDM_EINVAL, "ERROR: No preconditioners added yet"); // combined_preconditioner.hh:77
+  if (mode != 0 && mode != 1) return fail(ctx, DDM_ENOTIMPL, "Unknown apply mode in CombinedPreconditioner, use either additive or multiplicative"); // :68
+  if (mode == 1 && galerkin && !op) return fail(ctx, DDM_EINVAL, "ERROR: ApplyMode is multiplicative but operator A is not provided. Set with `set_op`"); // :146
+  ddm_combined *C = new ddm_combined;
+  C->mode = mode;
+  C->op = op;
+  C->schwarz = schwarz;
+  C->galerkin = galerkin;
+  C->n = schwarz->n_novlp;
+  if (hipMalloc((void **)&C->dnext, sizeof(double) * (size_t)std::max<int64_t>(C->n, 1)) != hipSuccess) {
+    delete C;
+    return fail(ctx, DDM_EHIP, "combined: allocation failed");
+  }
+  *out = C;
+  return DDM_OK;
+}
+extern "C" void ddm_combined_destroy(ddm_combined *C)
+{
+  if (!C) return;
+  (void)hipFree(C->dnext);
+  delete C;
+}
+extern "C" int ddm_combined_apply(ddm_ctx *ctx, ddm_combined *C, double *x, const double *d)
+{
+  ScopedTimer t(ctx, "CombinedPreconditioner/apply");
+  // x = 0; precs[0]->apply(x, d)  (:133-134)  -- the restrict kernel overwrites every entry of x
+  DDMCHECK(schwarz_apply_impl(ctx, C->schwarz, x, d, false));
+  if (!C->galerkin) return DDM_OK;
+  if (C->mode == 0) { // additive: xnext = P1 d; x += xnext (:136-142) -- fused into the restrict of the coarse level
+    return galerkin_apply_impl(ctx, C->galerkin, x, d, true);
+  }
+  // multiplicative: dnext = d - A x; x += P1 dnext (:149-158)
+  HIPCHECK(ctx, hipMemcpyAsync(C->dnext, d, sizeof(double) * (size_t)C->n, hipMemcpyDeviceToDevice, ctx->stream));
+  DDMCHECK(ddm_op_applyscaleadd(ctx, C->op, -1.0, x, C->dnext));
+  return galerkin_apply_impl(ctx, C->galerkin, x, C->dnext, true);
+}
+
+// ---- CG ----------------------------------------------------------------------------------------
+extern "C" int ddm_cg_solve(ddm_ctx *ctx, ddm_op *op, ddm_combined *prec, double *x, double *b, double reduction, int maxit,
+                            int fixed_iterations, double *hist_host, ddm_solve_result *res)
+{
+  if (!ctx || !op || !prec || !x || !b || !res) return fail(ctx, DDM_EINVAL, "ddm_cg_solve: bad arguments");
+  const int64_t n = op->n;
+  double *p = nullptr, *q = nullptr;
+  HIPCHECK(ctx, hipMalloc((void **)&p, sizeof(double) * (size_t)std::max<int64_t>(n, 1)));
+  HIPCHECK(ctx, hipMalloc((void **)&q, sizeof(double) * (size_t)std::max<int64_t>(n, 1)));
+  double *scal = ctx->scal;
+  int rc = DDM_OK;
+  auto done = [&](int r) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(p);
+    (void)hipFree(q);
+    return r;
+  };
+  const int G = grid_for(n);
+  // prec.pre(x,b); b -= A x
+  rc = ddm_op_applyscaleadd(ctx, op, -1.0, x, b);
+  if (rc) return done(rc);
+  double bb = 0.0;
+  rc = dot_device(ctx, n, op->owner, b, b, scal + 5);
+  if (!rc) rc = ddm_memcpy_d2h(ctx, &bb, scal + 5, sizeof(double));
+  if (rc) return done(rc);
+  const double def0 = std::sqrt(bb);
+  res->def0 = def0;
+  res->iterations = 0;
+  res->converged = 0;
+  res->reduction = 1.0;
+  res->elapsed_s = 0.0;
+  if (hist_host) hist_host[0] = def0;
+  if (!(def0 == def0)) return done(fail(ctx, DDM_ENUMERIC, "initial defect is NaN"));
+  if (def0 < 1e-30) {
+    res->converged = 1;
+    return done(DDM_OK);
+  }
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  const auto t0 = std::chrono::steady_clock::now();
+  // p = 0; prec.apply(p, b); rholast = <p, b>
+  rc = ddm_combined_apply(ctx, prec, p, b);
+  if (!rc) rc = dot_device(ctx, n, op->owner, p, b, scal + 0);
+  if (rc) return done(rc);
+  const int iters = fixed_iterations > 0 ? fixed_iterations : maxit;
+  double deff = def0;
+  for (int i = 1; i <= iters; ++i) {
+    rc = ddm_op_apply(ctx, op, p, q);                       // q = A p
+    if (!rc) rc = dot_device(ctx, n, op->owner, p, q, scal + 1); // alpha = <p, q>
+    if (rc) break;
+    hipLaunchKernelGGL(k_cg_lambda, dim3(1), dim3(1), 0, ctx->stream, scal);                 // lambda = rholast / alpha
+    hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(WG), 0, ctx->stream, n, scal, p, q, x, b); // x += lambda p; b -= lambda q
+    rc = dot_device(ctx, n, op->owner, b, b, scal + 5);                                      // def = ||b||
+    if (rc) break;
+    res->iterations = i;
+    if (fixed_iterations <= 0 || hist_host) {
+      rc = ddm_memcpy_d2h(ctx, &bb, scal + 5, sizeof(double));
+      if (rc) break;
+      deff = std::sqrt(bb);
+      if (hist_host) hist_host[i] = deff;
+      if (!(deff == deff)) {
+        rc = fail(ctx, DDM_ENUMERIC, "defect is NaN in iteration %d", i);
+        break;
+      }
+      if (fixed_iterations <= 0 && (deff < def0 * reduction || deff < 1e-30)) {
+        res->converged = 1;
+        break;
+      }
+    }
+    if (i == iters) break;
+    rc = ddm_combined_apply(ctx, prec, q, b);                 // q = 0; q = M^-1 b
+    if (!rc) rc = dot_device(ctx, n, op->owner, q, b, scal + 3); // rho = <q, b>
+    if (rc) break;
+    hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(1), 0, ctx->stream, scal);              // beta = rho / rholast; rholast = rho
+    hipLaunchKernelGGL(k_cg_direction, dim3(G), dim3(WG), 0, ctx->stream, n, scal, q, p); // p = beta p + q
+  }
+  if (!rc && hipGetLastError() != hipSuccess) rc = fail(ctx, DDM_EHIP, "kernel launch failed in CG");
+  (void)hipStreamSynchronize(ctx->stream);
+  const auto t1 = std::chrono::steady_clock::now();
+  res->elapsed_s = std::chrono::duration<double>(t1 - t0).count();
+  if (!rc && fixed_iterations > 0 && !hist_host) {
+    rc = ddm_memcpy_d2h(ctx, &bb, scal + 5, sizeof(double));
+    deff = std::sqrt(bb);
+  }
+  res->reduction = deff / def0;
+  return done(rc);
+}

@@ -1,0 +1,315 @@
+// Device kernels of the two-level Schwarz hot path (gfx950 / CDNA4, wave64).
+// All kernels are HBM-bandwidth or dependency-latency bound FP64 streaming kernels; none is
+// GEMM-shaped, so no MFMA here (DESIGN.md section "Kernels").  Launch wrappers are at the
+// bottom; every wrapper enqueues on the given stream and never synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ddm {
+
+constexpr int WG = 256;          // 4 waves of 64
+constexpr int SPMV_NNZ = 2048;   // non-zeros staged in LDS per workgroup (16 KiB of products)
+constexpr int RED_MAX_BLOCKS = 1024;
+
+// bijective XCD-aware remap (cdna_hip_programming.md T1): consecutive work items of one XCD
+// become contiguous, so each XCD's L2 sees one contiguous slab of the matrix / x vector.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg)
+{
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// block-wide sum in a fixed order; result valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double *lds4)
+{
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) lds4[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) r = (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+  __syncthreads();
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 / K11: CSR SpMV, "CSR-stream": a workgroup owns a block of consecutive rows holding at most
+// SPMV_NNZ non-zeros; values / column indices are read fully coalesced, the products are staged
+// in LDS and each row is then summed sequentially in column order (deterministic).
+// reference: BCRSMatrix::mv / usmv at nonoverlapping_operator.hh:37,47; spectra.hh:100-105.
+template <bool ACC>
+__global__ __launch_bounds__(WG) void k_spmv_stream(const int64_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                     const double *__restrict__ va, const int32_t *__restrict__ blk_row,
+                                                     int nblk, const double *__restrict__ x, double *__restrict__ y,
+                                                     double alpha)
+{
+  __shared__ double prod[SPMV_NNZ];
+  __shared__ double red[4];
+  const int b = xcd_remap(blockIdx.x, nblk);
+  const int r0 = blk_row[b], r1 = blk_row[b + 1];
+  const int64_t z0 = rp[r0], z1 = rp[r1];
+  const int64_t nz = z1 - z0;
+  if (nz > SPMV_NNZ) { // a single long row: strided partial sums + block reduction
+    double s = 0.0;
+    for (int64_t k = z0 + threadIdx.x; k < z1; k += WG) s += va[k] * x[ci[k]];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) y[r0] = ACC ? y[r0] + alpha * s : s;
+    return;
+  }
+#pragma unroll
+  for (int u = 0; u < SPMV_NNZ / WG; ++u) {
+    const int k = threadIdx.x + u * WG;
+    if (k < nz) prod[k] = va[z0 + k] * x[ci[z0 + k]];
+  }
+  __syncthreads();
+  const int r = r0 + threadIdx.x;
+  if (r < r1) {
+    const int k0 = (int)(rp[r] - z0), k1 = (int)(rp[r + 1] - z0);
+    double s = 0.0;
+    for (int k = k0; k < k1; ++k) s += prod[k];
+    y[r] = ACC ? y[r] + alpha * s : s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: level-scheduled sparse triangular solves with the ILU(0) factors (schwarz.hh:133).
+// Rows of one level are independent; their entries are stored level-by-level in sliced-ELL
+// (column-major inside the level) so that a thread-per-row kernel reads them coalesced and sums
+// them in the same column order as the sequential back-solve.
+__global__ __launch_bounds__(WG) void k_trsv_lower_level(int m, int w, const int32_t *__restrict__ rows,
+                                                          const int32_t *__restrict__ cols, const double *__restrict__ vals,
+                                                          const double *__restrict__ d, double *__restrict__ x)
+{
+  const int r = blockIdx.x * WG + threadIdx.x;
+  if (r >= m) return;
+  const int row = rows[r];
+  double s = d[row];
+  for (int k = 0; k < w; ++k) s -= vals[(int64_t)k * m + r] * x[cols[(int64_t)k * m + r]];
+  x[row] = s;
+}
+
+__global__ __launch_bounds__(WG) void k_trsv_upper_level(int m, int w, const int32_t *__restrict__ rows,
+                                                          const int32_t *__restrict__ cols, const double *__restrict__ vals,
+                                                          const double *__restrict__ dinv, double *__restrict__ x)
+{
+  const int r = blockIdx.x * WG + threadIdx.x;
+  if (r >= m) return;
+  const int row = rows[r];
+  double s = x[row];
+  for (int k = 0; k < w; ++k) s -= vals[(int64_t)k * m + r] * x[cols[(int64_t)k * m + r]];
+  x[row] = s * dinv[r];
+}
+
+// Several consecutive small levels (each <= WG*TRSV_SMALL_ROWS rows) in ONE workgroup: the levels
+// are separated by workgroup barriers instead of kernel boundaries.  desc[l] = {m, w, row_off,
+// ent_off}.  All data of these levels is produced and consumed by this workgroup only.
+struct LevelDesc {
+  int32_t m, w;
+  int64_t row_off, ent_off;
+};
+constexpr int TRSV_SMALL_WG = 1024;
+
+template <bool UPPER>
+__global__ __launch_bounds__(TRSV_SMALL_WG) void k_trsv_small_levels(int nlev, const LevelDesc *__restrict__ desc,
+                                                                      const int32_t *__restrict__ rows,
+                                                                      const int32_t *__restrict__ cols,
+                                                                      const double *__restrict__ vals,
+                                                                      const double *__restrict__ dinv,
+                                                                      const double *__restrict__ d, double *x)
+{
+  for (int l = 0; l < nlev; ++l) {
+    const LevelDesc L = desc[l];
+    for (int r = threadIdx.x; r < L.m; r += TRSV_SMALL_WG) {
+      const int row = rows[L.row_off + r];
+      double s = UPPER ? x[row] : d[row];
+      const int32_t *c = cols + L.ent_off;
+      const double *v = vals + L.ent_off;
+      for (int k = 0; k < L.w; ++k) s -= v[(int64_t)k * L.m + r] * x[c[(int64_t)k * L.m + r]];
+      x[row] = UPPER ? s * dinv[L.row_off + r] : s;
+    }
+    __syncthreads(); // workgroup-scope release/acquire of the x entries just written
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2 extend (schwarz.hh:121-122), K5 restrict (schwarz.hh:146), K4 POU scaling (schwarz.hh:141)
+__global__ void k_extend(int64_t n, const int32_t *__restrict__ ext_map, const double *__restrict__ d, double *__restrict__ dov)
+{
+  for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG) {
+    const int32_t m = ext_map[i];
+    dov[i] = m >= 0 ? d[m] : 0.0;
+  }
+}
+// x[m] = (ACC ? x[m] : 0) + w[i]*xov[i] for the rows that have a non-overlapping image
+template <bool ACC, bool SCALE>
+__global__ void k_restrict(int64_t n, const int32_t *__restrict__ ext_map, const double *__restrict__ xov,
+                           const double *__restrict__ w, double *__restrict__ x)
+{
+  for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG) {
+    const int32_t m = ext_map[i];
+    if (m >= 0) {
+      const double v = SCALE ? xov[i] * w[i] : xov[i];
+      x[m] = ACC ? x[m] + v : v;
+    }
+  }
+}
+__global__ void k_scale(int64_t n, const double *__restrict__ w, double *__restrict__ x)
+{
+  for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG) x[i] *= w[i];
+}
+__global__ void k_fill(int64_t n, double v, double *__restrict__ x)
+{
+  for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG) x[i] = v;
+}
+// y = a*x + y  (a from host) ; z = x + y
+__global__ void k_axpy(int64_t n, double a, const double *__restrict__ x, double *__restrict__ y)
+{
+  for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG) y[i] += a * x[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// halo exchange: pack (gather) and deterministic unpack (copy / add), SURVEY.md 2.3 C1-C4
+__global__ void k_pack(int64_t n, const int64_t *__restrict__ idx, const double *__restrict__ v, double *__restrict__ buf)
+{
+  for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG) buf[i] = v[idx[i]];
+}
+template <bool ADD>
+__global__ void k_unpack(int64_t ndst, const int64_t *__restrict__ dst_idx, const int64_t *__restrict__ dst_ptr,
+                         const int64_t *__restrict__ src_pos, const double *__restrict__ buf, double *__restrict__ v)
+{
+  for (int64_t t = blockIdx.x * (int64_t)WG + threadIdx.x; t < ndst; t += (int64_t)gridDim.x * WG) {
+    const int64_t i = dst_idx[t];
+    double s = ADD ? v[i] : 0.0;
+    for (int64_t k = dst_ptr[t]; k < dst_ptr[t + 1]; ++k) s = ADD ? s + buf[src_pos[k]] : buf[src_pos[k]];
+    v[i] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K20 / a3: owner-masked dot products (nonoverlapping_operator.hh:76-83), two-stage and
+// deterministic: partial[b] per workgroup, then one workgroup sums the partials in index order.
+template <bool MASKED>
+__global__ __launch_bounds__(WG) void k_dot_partial(int64_t n, const uint8_t *__restrict__ mask, const double *__restrict__ x,
+                                                     const double *__restrict__ y, double *__restrict__ partial)
+{
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG)
+    if (!MASKED || mask[i]) s += x[i] * y[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(WG) void k_reduce_final(int nb, const double *__restrict__ partial, double *__restrict__ out)
+{
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += WG) s += partial[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[0] = s;
+}
+
+// CG scalar recurrences on the device (dune-istl CGSolver), one thread.
+// scal: [0]=rholast [1]=alpha=<p,q> [2]=lambda [3]=rho [4]=beta [5]=<b,b>
+__global__ void k_cg_lambda(double *scal) { scal[2] = scal[0] / scal[1]; }
+__global__ void k_cg_beta(double *scal)
+{
+  scal[4] = scal[3] / scal[0];
+  scal[0] = scal[3];
+}
+// x += lambda p ; b -= lambda q
+__global__ void k_cg_update(int64_t n, const double *__restrict__ scal, const double *__restrict__ p,
+                            const double *__restrict__ q, double *__restrict__ x, double *__restrict__ b)
+{
+  const double lam = scal[2];
+  for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG) {
+    x[i] += lam * p[i];
+    b[i] -= lam * q[i];
+  }
+}
+// p = beta p + q
+__global__ void k_cg_direction(int64_t n, const double *__restrict__ scal, const double *__restrict__ q, double *__restrict__ p)
+{
+  const double beta = scal[4];
+  for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG) p[i] = beta * p[i] + q[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6 coarse restriction d0[(s,j)] = <r_j^s, d_ovlp^s>  (galerkin_preconditioner.hh:165-167):
+// a tall-skinny GEMV.  Work item = (chunk of rows inside one subdomain); wave w of the
+// workgroup handles vectors w, w+4, ...; lanes stride the rows (coalesced).
+struct RowChunk {
+  int64_t r0, r1;
+  int32_t sub, pad;
+};
+__global__ __launch_bounds__(WG) void k_coarse_restrict_partial(int kmax, int64_t ld, const double *__restrict__ basis,
+                                                                 const double *__restrict__ d, const RowChunk *__restrict__ chunks,
+                                                                 double *__restrict__ partial /* [nchunk][kmax] */)
+{
+  const RowChunk c = chunks[blockIdx.x];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int j = w; j < kmax; j += 4) {
+    const double *bj = basis + (int64_t)j * ld;
+    double s = 0.0;
+    for (int64_t r = c.r0 + lane; r < c.r1; r += 64) s += bj[r] * d[r];
+    s = wave_sum(s);
+    if (lane == 0) partial[(int64_t)blockIdx.x * kmax + j] = s;
+  }
+}
+// one workgroup: sums the chunk partials of each (subdomain, vector) in chunk order and scatters
+// them to the global coarse vector (zero elsewhere, so that an all-reduce assembles d0)
+__global__ __launch_bounds__(WG) void k_coarse_restrict_final(int nsub, int kmax, const int32_t *__restrict__ sub_chunk_ptr,
+                                                               const double *__restrict__ partial,
+                                                               const int64_t *__restrict__ coarse_index, int64_t K,
+                                                               double *__restrict__ d0)
+{
+  for (int64_t i = threadIdx.x; i < K; i += WG) d0[i] = 0.0;
+  __syncthreads();
+  for (int t = threadIdx.x; t < nsub * kmax; t += WG) {
+    const int s = t / kmax, j = t % kmax;
+    const int64_t gi = coarse_index[t];
+    if (gi < 0) continue;
+    double acc = 0.0;
+    for (int c = sub_chunk_ptr[s]; c < sub_chunk_ptr[s + 1]; ++c) acc += partial[(int64_t)c * kmax + j];
+    d0[gi] = acc;
+  }
+}
+// K8: x0 = A0^-1 d0 with the replicated explicit inverse (K x K, row-major); one wave per row
+__global__ __launch_bounds__(WG) void k_dense_mv(int64_t K, const double *__restrict__ M, const double *__restrict__ v,
+                                                  double *__restrict__ out)
+{
+  const int lane = threadIdx.x & 63;
+  const int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= K) return;
+  double s = 0.0;
+  for (int64_t c = lane; c < K; c += 64) s += M[row * K + c] * v[c];
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s;
+}
+// K7 prolongation x_ovlp = sum_j c_j r_j  (galerkin_preconditioner.hh:186-188)
+__global__ __launch_bounds__(WG) void k_coarse_prolong(int kmax, int64_t ld, const double *__restrict__ basis,
+                                                        const double *__restrict__ x0, const int64_t *__restrict__ coarse_index,
+                                                        const RowChunk *__restrict__ chunks, double *__restrict__ xov)
+{
+  __shared__ double cj[64];
+  const RowChunk c = chunks[blockIdx.x];
+  if (threadIdx.x < kmax) {
+    const int64_t gi = coarse_index[(int64_t)c.sub * kmax + threadIdx.x];
+    cj[threadIdx.x] = gi >= 0 ? x0[gi] : 0.0;
+  }
+  __syncthreads();
+  for (int64_t r = c.r0 + threadIdx.x; r < c.r1; r += WG) {
+    double s = 0.0;
+    for (int j = 0; j < kmax; ++j) s += cj[j] * basis[(int64_t)j * ld + r];
+    xov[r] = s;
+  }
+}
+
+} // namespace ddm

@@ -1,0 +1,231 @@
+"""High-level driver mirroring the call order of examples/poisson.cc:198-321 on one rank:
+
+    A_dir, pou, interfaces  ->  SchwarzPreconditioner  ->  coarse basis (POU / GenEO / given)
+    -> zero_at_dirichlet -> GalerkinPreconditioner (R A R^T assembled on the device)
+    -> NonOverlappingOperator -> CombinedPreconditioner -> CG.
+
+torch is used for device memory, the stream and torch.distributed (RCCL over xGMI); all compute
+goes through the C ABI of libddm_hip.so.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import (CombinedPreconditioner, Context, CsrMatrix, GalerkinPreconditioner, Halo, NonOverlappingOperator,
+               SchwarzPreconditioner, cg_solve, galerkin_products)
+from .problem import Decomposition, RankLocal
+
+
+class _DevView:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+class TorchComm:
+    """Inter-rank exchange over torch.distributed.  backend 'nccl' (= RCCL over xGMI) moves device
+    buffers directly; with 'gloo' (CPU rehearsal of the N>1 path) buffers are staged through the host."""
+
+    def __init__(self):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank, self.nranks = dist.get_rank(), dist.get_world_size()
+        self.backend = dist.get_backend()
+        self.halos = {}
+        self._views = {}
+
+    def view(self, ptr, n):
+        key = (int(ptr), int(n))
+        if key not in self._views:
+            self._views[key] = self.torch.as_tensor(_DevView(ptr, n), device="cuda")
+        return self._views[key]
+
+    def register(self, halo: Halo):
+        self.halos[halo.tag] = halo
+
+    def alltoall(self, tag, sptr, rptr):
+        h = self.halos[tag]
+        ns, nr = sum(h.send_counts), sum(h.recv_counts)
+        send = self.view(sptr, max(ns, 1))
+        recv = self.view(rptr, max(nr, 1))
+        staged = self.backend != "nccl"
+        s_host = send.cpu() if staged else send
+        r_host = self.torch.empty(max(nr, 1), dtype=self.torch.float64) if staged else recv
+        ops = []
+        so = ro = 0
+        for r in range(self.nranks):
+            sc, rc = h.send_counts[r], h.recv_counts[r]
+            if r == self.rank:
+                if sc:
+                    r_host[ro:ro + rc].copy_(s_host[so:so + sc])
+            else:
+                if sc:
+                    ops.append(self.dist.P2POp(self.dist.isend, s_host[so:so + sc], r))
+                if rc:
+                    ops.append(self.dist.P2POp(self.dist.irecv, r_host[ro:ro + rc], r))
+            so += sc
+            ro += rc
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+        if staged:
+            recv[:max(nr, 1)].copy_(r_host)
+        return 0
+
+    def allreduce(self, ptr, n):
+        t = self.view(ptr, n)
+        if self.backend == "nccl":
+            self.dist.all_reduce(t)
+        else:
+            h = t.cpu()
+            self.dist.all_reduce(h)
+            t.copy_(h)
+        return 0
+
+
+def pou_basis(rl: RankLocal):
+    """POUCoarseSpace (coarse_spaces.hh:1175-1231): 1 * pou / ||pou||_2 per subdomain, then
+    zero_at_dirichlet (examples/poisson.cc:235-238,282).  Returns {sub id: (1, n_s) array}."""
+    out = {}
+    for sd in rl.subs:
+        v = np.ones(sd.n) * sd.pou
+        v = v * (1.0 / np.sqrt(float(np.dot(v, v))))
+        v[sd.dirichlet_ovlp > 0] = 0.0
+        out[sd.id] = v[None, :]
+    return out
+
+
+class TwoLevelSchwarz:
+    def __init__(self, dec: Decomposition, rank=0, nranks=1, device=0, comm: TorchComm | None = None,
+                 schwarz_type="standard", mode="additive", coarse="pou", use_pou_in_schwarz=True):
+        import torch
+        self.torch = torch
+        torch.cuda.set_device(device)
+        self.dev = torch.device("cuda", device)
+        self.dec = dec
+        self.comm = comm
+        self.ctx = Context(device, torch.cuda.current_stream().cuda_stream)
+        if nranks > 1:
+            assert comm is not None
+            self.ctx.set_comm(rank, nranks, comm.alltoall, comm.allreduce)
+        rl = self.rl = RankLocal(dec, rank, nranks)
+        ctx = self.ctx
+        self.A = CsrMatrix(ctx, rl.A)
+        self.A_dir = CsrMatrix(ctx, rl.A_dir)
+        self.h_novlp = Halo(ctx, 1, Halo.ADD, rl.plan_novlp_add)
+        self.h_copy = Halo(ctx, 2, Halo.COPY, rl.plan_ovlp_copy)
+        self.h_add = Halo(ctx, 3, Halo.ADD, rl.plan_ovlp_add)
+        if comm is not None:
+            for h in (self.h_novlp, self.h_copy, self.h_add):
+                comm.register(h)
+        self.op = NonOverlappingOperator(ctx, self.A, self.h_novlp, rl.owner_novlp)
+        self.schwarz = SchwarzPreconditioner(ctx, self.A_dir, rl.block_ptr, rl.n_o, rl.ext_map,
+                                             rl.pou if use_pou_in_schwarz else None, schwarz_type, self.h_copy, self.h_add)
+        self.galerkin = None
+        self.a0 = None
+        if coarse is not None and coarse != "none":
+            basis = pou_basis(rl) if isinstance(coarse, str) and coarse == "pou" else coarse
+            self.set_coarse_basis(basis)
+        self.prec = CombinedPreconditioner(ctx, mode, self.op, self.schwarz, self.galerkin)
+
+    # -- device vectors
+    def zeros(self, n):
+        return self.torch.zeros(int(n), dtype=self.torch.float64, device=self.dev)
+
+    def to_device(self, a):
+        return self.torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(self.dev)
+
+    # -- coarse level -------------------------------------------------------------------------
+    def set_coarse_basis(self, basis_by_sub):
+        """basis_by_sub: {local sub id: (k_s, n_s) array}; builds R A R^T and the Galerkin level."""
+        rl, dec, torch = self.rl, self.dec, self.torch
+        P = dec.nsub
+        k_local = {s: int(basis_by_sub[s].shape[0]) for s in rl.local}
+        k_all = self._allgather_small(k_local, P)              # MPI_Allgather of num_t (galerkin_preconditioner.hh:248)
+        kmax = max(k_all)
+        offset = np.concatenate([[0], np.cumsum(k_all)[:-1]]).astype(np.int64)   # offset_per_rank (:256)
+        K = int(sum(k_all))
+        basis = np.zeros((kmax, rl.n))
+        coarse_index = np.full((len(rl.local), kmax), -1, dtype=np.int64)
+        for li, s in enumerate(rl.local):
+            basis[:k_all[s], rl.off[s]:rl.off[s] + dec.subs[s].n] = basis_by_sub[s]
+            coarse_index[li, :k_all[s]] = offset[s] + np.arange(k_all[s])
+        self.k_all, self.coarse_offset, self.K = k_all, offset, K
+        A0 = self._build_coarse_matrix(basis, k_all, offset, K)
+        self.a0 = A0
+        a0inv = np.linalg.inv(A0)
+        self.galerkin = GalerkinPreconditioner(self.ctx, rl.n, rl.n_o, rl.ext_map, rl.block_ptr, basis, coarse_index.reshape(-1),
+                                               a0inv, self.h_copy, self.h_add)
+
+    def _allgather_small(self, local: dict, P):
+        if self.comm is None:
+            return [local[s] for s in range(P)]
+        objs = [None] * self.comm.nranks
+        self.comm.dist.all_gather_object(objs, local)
+        merged = {}
+        for o in objs:
+            merged.update(o)
+        return [merged[s] for s in range(P)]
+
+    def _build_coarse_matrix(self, basis, k_all, offset, K):
+        """GalerkinPreconditioner::build_solver (galerkin_preconditioner.hh:219-349) on the device:
+        local x local blocks from Y = A_dir R^T, local x neighbour blocks from the neighbours' vectors
+        restricted to the shared indices (CopyGatherScatterWithRank, :66-103), one neighbour slot
+        at a time for all local subdomains at once (A_dir is block diagonal)."""
+        rl, dec, torch, ctx = self.rl, self.dec, self.torch, self.ctx
+        kmax = basis.shape[0]
+        R = self.to_device(basis)                                   # (kmax, n)
+        A0 = np.zeros((K, K))
+        for s in rl.local:                                           # :292-295
+            blk = galerkin_products(ctx, self.A_dir, R, R, rl.off[s], rl.off[s] + dec.subs[s].n)   # [i, j] = <r_i, A r_j>
+            ks = k_all[s]
+            A0[offset[s]:offset[s] + ks, offset[s]:offset[s] + ks] = blk[:ks, :ks]
+        nbrs = {s: sorted({a for (a, b) in dec.ovlp_all if b == s}) for s in rl.local}
+        nslots = max([len(v) for v in nbrs.values()] + [0])
+        if self.comm is not None:
+            nslots = max(self._allgather_small({s: len(nbrs[s]) for s in rl.local}, dec.nsub) + [0])
+        from .problem import halo_plan
+        offs = {s: rl.off.get(s, 0) for s in range(dec.nsub)}
+        for t in range(nslots):                                      # :298-309, 321-327
+            pairs_t = {(a, b): v for (a, b), v in dec.ovlp_all.items()
+                       if self._slot_of(dec, a, b) == t}
+            plan = halo_plan(pairs_t, rl.local, rl.sub2rank, offs, rl.rank, rl.nranks)
+            halo = Halo(ctx, 100 + t, Halo.COPY, plan)
+            if self.comm is not None:
+                self.comm.register(halo)
+            mask = torch.zeros(rl.n, dtype=torch.float64, device=self.dev)
+            if len(plan["dst_idx"]):
+                mask[torch.as_tensor(plan["dst_idx"], device=self.dev)] = 1.0
+            V = R.clone()
+            for j in range(kmax):
+                halo.exchange(V[j])
+            V *= mask[None, :]
+            for s in rl.local:
+                if t >= len(nbrs[s]):
+                    continue
+                src = nbrs[s][t]
+                blk = galerkin_products(ctx, self.A_dir, R, V, rl.off[s], rl.off[s] + dec.subs[s].n)
+                A0[offset[s]:offset[s] + k_all[s], offset[src]:offset[src] + k_all[src]] = blk[:k_all[s], :k_all[src]]
+            self.ctx.sync()
+        if self.comm is not None:                                    # gatherMatrixFromRowsFlat (helpers.hh:204-339), replicated
+            t_ = torch.as_tensor(A0)
+            if self.comm.backend == "nccl":
+                t_ = t_.to(self.dev)
+            self.comm.dist.all_reduce(t_)
+            A0 = t_.cpu().numpy()
+        return A0
+
+    @staticmethod
+    def _slot_of(dec, src, dst):
+        cache = dec.meta.setdefault("_nbr_slots", {})
+        if dst not in cache:
+            cache[dst] = {a: i for i, a in enumerate(sorted({a for (a, b) in dec.ovlp_all if b == dst}))}
+        return cache[dst][src]
+
+    # -- solve -------------------------------------------------------------------------------
+    def solve(self, reduction=1e-10, maxit=1000, fixed_iterations=0, history=True, x0=None, b=None):
+        """v = 0; solver->apply(v, b, res)  (examples/poisson.cc:318-319).  Returns (res, hist, x)."""
+        x = self.zeros(self.rl.n_o) if x0 is None else self.to_device(x0)
+        bd = self.to_device(self.rl.b if b is None else b)
+        res, hist = cg_solve(self.ctx, self.op, self.prec, x, bd, reduction, maxit, fixed_iterations, history)
+        return res, hist, x

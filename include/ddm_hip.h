@@ -1,0 +1,181 @@
+/* ddm_hip.h -- C ABI of the MI355X-native two-level Schwarz + GenEO hot path.
+ *
+ * This is the drop-in boundary: a DUNE-side adaptor (header-only classes with the reference's
+ * names, see dune-ddm_amd/dune/ddm/ and INTEGRATION.md) flattens its BCRSMatrix / BlockVector /
+ * Interface objects once and then only calls the entry points below.  Plain pointers and sizes,
+ * no C++ or torch types.  Citations are file:line in nilsfriess/dune-ddm (the reference).
+ *
+ * Conventions
+ *   - All arithmetic FP64; column indices int32; row pointers / sizes int64.
+ *   - "rank-local" vectors are the concatenation of the rank's subdomains (one subdomain per rank
+ *     in the reference; several per GPU are allowed here so that the 8-subdomain problem also
+ *     runs on 1, 2 or 4 GPUs).  n_o = non-overlapping size, n = overlapping size.
+ *   - Vector arguments are DEVICE pointers unless the function name ends in _host.
+ *   - Every call returns 0 on success or a negative DDM_E* code; ddm_last_error() gives the text
+ *     (the adaptor turns it into DUNE_THROW, cf. dune/ddm/schwarz.hh:83,91,190,193).
+ *   - All work is enqueued on the context's HIP stream; calls are asynchronous unless stated.
+ *   - There is NO CPU fallback: without a HIP device every compute entry point fails.
+ */
+#ifndef DDM_HIP_H
+#define DDM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDM_OK 0
+#define DDM_EINVAL (-1)   /* bad argument / size mismatch (Dune::Exception, InvalidStateException) */
+#define DDM_EHIP (-2)     /* HIP runtime error */
+#define DDM_ENOTIMPL (-3) /* Dune::NotImplemented */
+#define DDM_ENUMERIC (-4) /* zero pivot, singular coarse matrix, eigensolver failure */
+#define DDM_ECOMM (-5)    /* exchange callback failed (MPI_Abort in the reference) */
+
+typedef struct ddm_ctx ddm_ctx;
+typedef struct ddm_csr ddm_csr;
+typedef struct ddm_ilu0 ddm_ilu0;
+typedef struct ddm_halo ddm_halo;
+typedef struct ddm_op ddm_op;
+typedef struct ddm_schwarz ddm_schwarz;
+typedef struct ddm_galerkin ddm_galerkin;
+typedef struct ddm_combined ddm_combined;
+
+/* ---- context ---------------------------------------------------------------------------- */
+/* One context per process/GPU.  stream == NULL: the library creates its own stream. */
+int ddm_ctx_create(int device, void *hip_stream, ddm_ctx **out);
+void ddm_ctx_destroy(ddm_ctx *ctx);
+const char *ddm_last_error(const ddm_ctx *ctx);
+int ddm_ctx_sync(ddm_ctx *ctx); /* hipStreamSynchronize */
+void *ddm_ctx_stream(ddm_ctx *ctx);
+
+/* Inter-rank exchange is delegated to the host program (MPI in a DUNE build, torch.distributed
+ * over RCCL in bench.py).  Both callbacks are invoked with the data already produced on the
+ * context's stream; they must enqueue on (or synchronise with) that stream.
+ *   alltoall: send/recv buffers are device pointers with the per-peer layout fixed at
+ *             ddm_halo_create time; `tag` is the halo's id.
+ *   allreduce_sum: in-place sum over all ranks of n doubles at a device pointer.
+ * With no callbacks installed the context is single-rank (all subdomains local). */
+typedef int (*ddm_alltoall_fn)(void *user, int tag, const double *sendbuf, double *recvbuf);
+typedef int (*ddm_allreduce_fn)(void *user, double *buf, int64_t n);
+int ddm_ctx_set_comm(ddm_ctx *ctx, int rank, int nranks, ddm_alltoall_fn a2a, ddm_allreduce_fn allreduce, void *user);
+
+/* raw device memory helpers for callers that do not bring their own allocator */
+int ddm_malloc(ddm_ctx *ctx, int64_t bytes, void **dptr);
+int ddm_free(ddm_ctx *ctx, void *dptr);
+int ddm_memcpy_h2d(ddm_ctx *ctx, void *dst, const void *src, int64_t bytes); /* synchronous */
+int ddm_memcpy_d2h(ddm_ctx *ctx, void *dst, const void *src, int64_t bytes); /* synchronous */
+
+/* ---- CSR matrix (flattened Dune::BCRSMatrix<FieldMatrix<double,1,1>>; cf. the in-tree
+ *      precedent dune/ddm/strumpack.hh:36-62) ---------------------------------------------- */
+int ddm_csr_create(ddm_ctx *ctx, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *col,
+                   const double *val, ddm_csr **out); /* host arrays are copied */
+void ddm_csr_destroy(ddm_csr *A);
+int64_t ddm_csr_rows(const ddm_csr *A);
+int64_t ddm_csr_nnz(const ddm_csr *A);
+/* y = A x  (BCRSMatrix::mv, dune/ddm/nonoverlapping_operator.hh:37) */
+int ddm_csr_mv(ddm_ctx *ctx, const ddm_csr *A, const double *x, double *y);
+/* y += alpha A x  (BCRSMatrix::usmv, nonoverlapping_operator.hh:47) */
+int ddm_csr_usmv(ddm_ctx *ctx, const ddm_csr *A, double alpha, const double *x, double *y);
+
+/* ---- local subdomain solver: ILU(0), natural row order ------------------------------------
+ * The InverseOperator behind schwarz.hh:57,92,133 for [subdomain_solver] type=loopsolver maxit=1,
+ * preconditioner type=ilu n=0.  block_ptr[0..nblocks] = row ranges of the independent diagonal
+ * blocks (subdomains) of A; pass nblocks=1, block_ptr={0,n} for one subdomain. */
+int ddm_ilu0_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, ddm_ilu0 **out);
+void ddm_ilu0_destroy(ddm_ilu0 *F);
+/* x = (LU)^-1 d ; d and x must not alias */
+int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x);
+int64_t ddm_ilu0_num_levels(const ddm_ilu0 *F, int upper);
+/* factor values in the pattern of A (inverse pivots on the diagonal), for parity tests */
+int ddm_ilu0_get_factors_host(ddm_ctx *ctx, const ddm_ilu0 *F, double *lu_host);
+
+/* ---- halo exchange plan: one per DUNE interface -------------------------------------------
+ * (copyOwnerToAll: schwarz.hh:125, galerkin_preconditioner.hh:162;
+ *  addOwnerCopyToOwnerCopy: nonoverlapping_operator.hh:38,48, schwarz.hh:138,142;
+ *  addOwnerCopyToAll: galerkin_preconditioner.hh:190.)
+ * send side : sendbuf[k] = v[send_idx[k]], k < nsend, grouped by destination rank
+ *             (send_counts[nranks]); the segment for this rank itself is delivered locally.
+ * recv side : recvbuf is the concatenation of the peers' segments (recv_counts[nranks]).
+ *             For entry t < ndst:  v[dst_idx[t]] (=|+=) sum_{k=dst_ptr[t]}^{dst_ptr[t+1]-1} recvbuf[src_pos[k]]
+ *             contributions are added in list order (the adaptor lists them by ascending source
+ *             rank, which is the order DUNE's BufferedCommunicator scatters them).
+ * mode      : 0 = copy (overwrite), 1 = add. */
+int ddm_halo_create(ddm_ctx *ctx, int tag, int mode, int64_t nsend, const int64_t *send_idx,
+                    const int64_t *send_counts, const int64_t *recv_counts, int64_t ndst, const int64_t *dst_idx,
+                    const int64_t *dst_ptr, const int64_t *src_pos, ddm_halo **out);
+void ddm_halo_destroy(ddm_halo *H);
+int ddm_halo_exchange(ddm_ctx *ctx, ddm_halo *H, double *v); /* pack -> (callback) -> unpack, in place */
+/* Buffers the alltoall callback is handed (device pointers; stable for the halo's lifetime). */
+double *ddm_halo_sendbuf(ddm_halo *H);
+double *ddm_halo_recvbuf(ddm_halo *H);
+
+/* ---- NonOverlappingOperator + NonOverlappingScalarProduct (nonoverlapping_operator.hh) ---- */
+int ddm_op_create(ddm_ctx *ctx, const ddm_csr *A, ddm_halo *novlp_add, const uint8_t *owner_mask_host, ddm_op **out);
+void ddm_op_destroy(ddm_op *op);
+int ddm_op_apply(ddm_ctx *ctx, ddm_op *op, const double *x, double *y);                       /* :34-39 */
+int ddm_op_applyscaleadd(ddm_ctx *ctx, ddm_op *op, double alpha, const double *x, double *y); /* :41-50 */
+int ddm_dot(ddm_ctx *ctx, ddm_op *op, const double *x, const double *y, double *result_host); /* :76-81, synchronous */
+int ddm_norm(ddm_ctx *ctx, ddm_op *op, const double *x, double *result_host);                 /* :83, synchronous */
+
+/* ---- SchwarzPreconditioner (schwarz.hh:54-220) --------------------------------------------
+ * type: 0 = standard, 1 = restricted (schwarz.hh:80-83).  pou may be NULL (schwarz.hh:140).
+ * ext_map[n]  : index into the non-overlapping vector or -1  ("extend": schwarz.hh:121-122)
+ * A_dir is only read during creation (factorisation). */
+int ddm_schwarz_create(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t nblocks, const int64_t *block_ptr, int64_t n_novlp,
+                       const int32_t *ext_map_host, const double *pou_host, int type, ddm_halo *ovlp_copy,
+                       ddm_halo *ovlp_add, ddm_schwarz **out);
+void ddm_schwarz_destroy(ddm_schwarz *S);
+int ddm_schwarz_apply(ddm_ctx *ctx, ddm_schwarz *S, double *x, const double *d); /* :115-149 */
+
+/* ---- GalerkinPreconditioner (galerkin_preconditioner.hh:40-363) ---------------------------
+ * basis_host: kmax x n row-major (vector j contiguous), zero rows where a subdomain has fewer
+ * vectors; sub_ptr[nsub+1]: overlapping row ranges of the rank's subdomains; coarse_index[nsub*kmax]:
+ * global coarse row of (subdomain, vector) or -1; K = total coarse dimension;
+ * a0inv_host: K x K row-major inverse of the coarse matrix R A R^T (every rank solves the
+ * replicated coarse problem instead of the rank-0 gather/solve/scatter of :170-183).
+ * Shares the ext_map / halos of the Schwarz object. */
+int ddm_galerkin_create(ddm_ctx *ctx, int64_t n, int64_t n_novlp, const int32_t *ext_map_host, int64_t nsub,
+                        const int64_t *sub_ptr, int64_t kmax, const double *basis_host, const int64_t *coarse_index,
+                        int64_t K, const double *a0inv_host, ddm_halo *ovlp_copy, ddm_halo *ovlp_add,
+                        ddm_galerkin **out);
+void ddm_galerkin_destroy(ddm_galerkin *G);
+int ddm_galerkin_apply(ddm_ctx *ctx, ddm_galerkin *G, double *x, const double *d); /* :151-194 */
+/* Local slab of the Galerkin product (build_solver, :219-349; layout helpers.hh:252):
+ * Y = A_dir * V for nvec device vectors V (nvec x n row-major) then out[i*nvec_r + j] = <R_i, Y_j>
+ * restricted to the subdomain row range [row0,row1).  Used by the host to assemble R A R^T. */
+int ddm_galerkin_products(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t nleft, const double *left, int64_t nright,
+                          const double *right, int64_t row0, int64_t row1, double *out_host);
+
+/* ---- CombinedPreconditioner (combined_preconditioner.hh:39-180) --------------------------- */
+/* mode 0 = additive, 1 = multiplicative (:56-69).  galerkin may be NULL (one-level). */
+int ddm_combined_create(ddm_ctx *ctx, int mode, ddm_op *op, ddm_schwarz *schwarz, ddm_galerkin *galerkin,
+                        ddm_combined **out);
+void ddm_combined_destroy(ddm_combined *C);
+int ddm_combined_apply(ddm_ctx *ctx, ddm_combined *C, double *x, const double *d); /* :127-163 */
+
+/* ---- outer Krylov loop: dune-istl CGSolver::apply as driven by examples/poisson.cc:311-319 -- */
+typedef struct {
+  int32_t iterations;
+  int32_t converged;
+  double def0;        /* initial defect norm */
+  double reduction;   /* achieved ||r_k|| / ||r_0|| */
+  double elapsed_s;   /* wall time of the loop (host clock, stream synchronised) */
+} ddm_solve_result;
+/* x: initial guess / solution; b: right-hand side, overwritten by the defect (as in dune-istl).
+ * hist_host (may be NULL): maxit+1 doubles receiving ||r_0||, ||r_1||, ...
+ * fixed_iterations > 0: run exactly that many iterations without testing convergence (bench). */
+int ddm_cg_solve(ddm_ctx *ctx, ddm_op *op, ddm_combined *prec, double *x, double *b, double reduction, int maxit,
+                 int fixed_iterations, double *hist_host, ddm_solve_result *res);
+
+/* ---- instrumentation ---------------------------------------------------------------------
+ * Named event timers mirroring the reference's Logger events ("Schwarz/local solve", ...,
+ * dune/ddm/schwarz.hh:178-181).  Times are HIP-event milliseconds accumulated on the stream. */
+int ddm_timing_enable(ddm_ctx *ctx, int on);
+int ddm_timing_get(ddm_ctx *ctx, const char *name, double *total_ms, int64_t *count);
+int ddm_timing_reset(ddm_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDM_HIP_H */
