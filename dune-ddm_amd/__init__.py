@@ -161,6 +161,22 @@ class Context:
             self.h = None
 
 
+def torch_context(device=0):
+    """Context bound to torch's current stream on ``device``.  If that is the legacy default stream
+    (which can neither be captured into a HIP graph nor ordered against a non-blocking stream) a
+    side stream is created and made current, so torch allocations / copies and the library's
+    kernels are ordered on one stream."""
+    import torch
+    torch.cuda.set_device(device)
+    s = torch.cuda.current_stream()
+    if s.cuda_stream == 0:
+        s = torch.cuda.Stream(device=device)
+        torch.cuda.set_stream(s)
+    ctx = Context(device, s.cuda_stream)
+    ctx._torch_stream = s
+    return ctx
+
+
 def _ptr(t):
     """device pointer of a torch tensor / raw int"""
     return ctypes.c_void_p(t if isinstance(t, int) else t.data_ptr())

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import (CombinedPreconditioner, Context, CsrMatrix, GalerkinPreconditioner, Halo, NonOverlappingOperator,
+from . import (CombinedPreconditioner, Context, torch_context, CsrMatrix, GalerkinPreconditioner, Halo, NonOverlappingOperator,
                SchwarzPreconditioner, cg_solve, galerkin_products)
 from .problem import Decomposition, RankLocal
 
@@ -104,7 +104,7 @@ class TwoLevelSchwarz:
         self.dev = torch.device("cuda", device)
         self.dec = dec
         self.comm = comm
-        self.ctx = Context(device, torch.cuda.current_stream().cuda_stream)
+        self.ctx = torch_context(device)
         if nranks > 1:
             assert comm is not None
             self.ctx.set_comm(rank, nranks, comm.alltoall, comm.allreduce)

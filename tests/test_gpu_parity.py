@@ -7,7 +7,8 @@ import scipy.sparse as sp
 pytestmark = pytest.mark.gpu
 
 RTOL_VEC = 1e-12      # one kernel application (different summation order only)
-RTOL_HIST = 1e-8      # per-iteration ||r_k|| relative difference
+RTOL_HIST = 1e-8      # per-iteration ||r_k||: |gpu - oracle| <= RTOL_HIST*||r_k|| + ATOL_HIST*||r_0||
+ATOL_HIST = 1e-14     # (rounding differences are amplified by CG once ||r_k|| approaches 1e-10 ||r_0||)
 
 
 @pytest.fixture(scope="module")
@@ -38,7 +39,7 @@ def _random_csr(rng, n, density=0.01, long_row=None):
 def test_csr_mv_usmv_random_and_edge_cases(ddm, torch_cuda):
     from oracle import apply_oracle as ao
     torch = torch_cuda
-    ctx = ddm.Context(0, torch.cuda.current_stream().cuda_stream)
+    ctx = ddm.torch_context(0)
     rng = np.random.default_rng(42)
     cases = [_random_csr(rng, 5000, 0.004), _random_csr(rng, 3000, 0.002, long_row=17),   # a row longer than the LDS tile
              sp.csr_matrix((700, 700)),                                                    # empty matrix (ragged: all rows empty)
@@ -67,7 +68,7 @@ def test_ilu0_factor_and_solve(ddm, torch_cuda):
     from dune_ddm_amd import synth
     from oracle import apply_oracle as ao
     torch = torch_cuda
-    ctx = ddm.Context(0, torch.cuda.current_stream().cuda_stream)
+    ctx = ddm.torch_context(0)
     grid = synth.StructuredPoisson((14, 12, 11), (1, 1, 1), synth.islands_kappa((13, 11, 10), 1e4, 4, 2))
     M = grid.subdomain(0).A
     A = ddm.CsrMatrix(ctx, M)
@@ -143,7 +144,8 @@ def test_operator_dot_and_preconditioner_applies(ddm, torch_cuda):
     dict(N=(17, 17, 17), P=(2, 2, 2), overlap=2, coarse="pou", stype="standard", mode="additive"),
     dict(N=(21, 13, 9), P=(3, 2, 1), overlap=1, coarse="none", stype="standard", mode="additive"),
     dict(N=(40, 33), P=(2, 2), overlap=2, coarse="none", stype="standard", mode="additive"),       # BASELINE config 1 (2-D, one-level)
-    dict(N=(15, 15, 15), P=(2, 2, 2), overlap=2, coarse="pou", stype="standard", mode="multiplicative"),
+    # multiplicative combination is not symmetric: CG need not converge, compare 25 iterations of the recurrences
+    dict(N=(15, 15, 15), P=(2, 2, 2), overlap=2, coarse="pou", stype="standard", mode="multiplicative", maxit=25),
     dict(N=(20, 20, 20), P=(1, 1, 1), overlap=1, coarse="none", stype="standard", mode="additive"),  # BASELINE config 2 shape: ILU(0)-CG
 ])
 def test_cg_history_matches_oracle(ddm, torch_cuda, cfg):
@@ -152,14 +154,15 @@ def test_cg_history_matches_oracle(ddm, torch_cuda, cfg):
     from tests.oracle_bridge import oracle_solve
     dec = _build(ddm, cfg["N"], cfg["P"], overlap=cfg["overlap"])
     tl = TwoLevelSchwarz(dec, coarse=cfg["coarse"], schwarz_type=cfg["stype"], mode=cfg["mode"])
-    res, hist, x = tl.solve(reduction=1e-10, maxit=300)
-    it, conv, hist_o, xo = oracle_solve(dec, reduction=1e-10, maxit=300, coarse=cfg["coarse"], schwarz_type=cfg["stype"], mode=cfg["mode"])
-    assert conv and res.converged
-    assert res.iterations == it
+    maxit = cfg.get("maxit", 300)
+    res, hist, x = tl.solve(reduction=1e-10, maxit=maxit)
+    it, conv, hist_o, xo = oracle_solve(dec, reduction=1e-10, maxit=maxit, coarse=cfg["coarse"], schwarz_type=cfg["stype"], mode=cfg["mode"])
+    assert res.iterations == it and bool(res.converged) == conv
     hist_o = np.array(hist_o)
-    assert np.max(np.abs(hist - hist_o) / hist_o) < RTOL_HIST
-    assert _relerr(x.cpu().numpy(), np.concatenate(xo)) < 1e-8
-    assert res.reduction <= 1e-10
+    assert (np.abs(hist - hist_o) <= RTOL_HIST * hist_o + ATOL_HIST * hist_o[0]).all()
+    if "maxit" not in cfg:
+        assert conv and res.reduction <= 1e-10
+        assert _relerr(x.cpu().numpy(), np.concatenate(xo)) < 1e-8
     tl.ctx.close()
 
 
@@ -170,7 +173,7 @@ def test_halo_exchange_bit_exact(ddm, torch_cuda):
     torch = torch_cuda
     dec = _build(ddm, (12, 11, 10), (2, 2, 2), overlap=2)
     rl = RankLocal(dec)
-    ctx = ddm.Context(0, torch.cuda.current_stream().cuda_stream)
+    ctx = ddm.torch_context(0)
     rng = np.random.default_rng(3)
     ocomm = ao.Comm(dec.nsub, dec.ovlp_owner, dec.ovlp_all, [sd.owner_ovlp for sd in dec.subs])
     for mode, plan, fn in ((ddm.Halo.COPY, rl.plan_ovlp_copy, ocomm.copyOwnerToAll), (ddm.Halo.ADD, rl.plan_ovlp_add, ocomm.addOwnerCopyToAll)):
