@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- preconditioned CG iterations/s of the two-level additive Schwarz + coarse-space path.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on; it fits one GPU):
+3-D Q1 Poisson on 216^3 = 10 077 696 DoF, 2x2x2 = 8 overlapping subdomains (overlap 2, distance
+partition of unity), ILU(0) subdomain solves, coarse space of 8 x k vectors, additive combination, CG.
+The 8 subdomains are distributed 8/N per GPU, so the SAME problem (same iteration count) runs at
+N = 1, 2, 4, 8  ->  strong scaling.  A "step" is one CG iteration (operator apply with halo sum,
+preconditioner apply, 2 dots + 1 norm, vector updates).  Inputs are resident in HBM before the
+timed region; setup (assembly, ILU(0), coarse basis, R A R^T) is reported separately.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+
+
+def log(rank, *a):
+    if rank == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--grid", type=int, default=216, help="nodes per axis (216 -> 10M DoF)")
+    ap.add_argument("--overlap", type=int, default=2)
+    ap.add_argument("--coarse", default="auto", choices=["auto", "geneo", "pou", "none"])
+    ap.add_argument("--nev", type=int, default=20)
+    ap.add_argument("--no-solve", action="store_true", help="skip the full solve to 1e-10 (iteration count / residual check)")
+    ap.add_argument("--cpu-iters", type=int, default=8, help="CG iterations of the CPU oracle timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=8)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+
+    import numpy as np
+    import torch
+    import __graft_entry__ as ge
+    pkg = ge.import_package()
+    pkg.load_library()                      # fails loudly if the HIP extension is missing
+    assert torch.cuda.is_available(), "bench.py needs a HIP device: the hot path has no CPU fallback"
+    from dune_ddm_amd import CgIteration, synth
+    from dune_ddm_amd.problem import build_structured
+    from dune_ddm_amd.solver import TorchComm, TwoLevelSchwarz
+
+    torch.cuda.set_device(local_rank)
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=os.environ.get("DDM_BACKEND", "nccl"), device_id=torch.device("cuda", local_rank))
+        comm = TorchComm()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # ---- setup (host): what DUNE/PDELab + dune-ddm's L3 hand to the hot path -------------------
+    t_setup0 = time.perf_counter()
+    G = args.grid
+    grid = synth.StructuredPoisson((G, G, G), (2, 2, 2))
+    coarse = args.coarse
+    if coarse == "auto":
+        coarse = "geneo" if hasattr(pkg, "GENEO_AVAILABLE") and pkg.GENEO_AVAILABLE else "pou"
+    dec = build_structured(grid, overlap=args.overlap, pou_type="distance", shrink=0, neumann=(coarse == "geneo"))
+    t_host = time.perf_counter() - t_setup0
+    log(rank, f"host setup (assembly, overlap extension, POU): {t_host:.1f} s")
+    t1 = time.perf_counter()
+    if coarse == "geneo":
+        from dune_ddm_amd.geneo import geneo_basis
+        tl = TwoLevelSchwarz(dec, rank, world, local_rank, comm, schwarz_type="standard", mode="additive", coarse="none")
+        basis = geneo_basis(tl, nev=args.nev)
+        tl.set_coarse_basis(basis)
+        tl.rebuild_combined("additive")
+    else:
+        tl = TwoLevelSchwarz(dec, rank, world, local_rank, comm, schwarz_type="standard", mode="additive", coarse=coarse)
+    tl.ctx.sync()
+    t_dev = time.perf_counter() - t1
+    log(rank, f"device setup (upload, ILU(0), level schedule, coarse space '{coarse}', R A R^T): {t_dev:.1f} s; "
+              f"ILU levels L/U = {tl.schwarz_levels()}")
+
+    # ---- full solve: iteration count and final residual (validity of the configuration) --------
+    solve_info = None
+    if not args.no_solve:
+        res, hist, x = tl.solve(reduction=1e-10, maxit=1000, history=True)
+        solve_info = {"iterations": int(res.iterations), "converged": bool(res.converged), "reduction": float(res.reduction),
+                      "solve_s": float(res.elapsed_s)}
+        log(rank, f"full solve: {res.iterations} iterations, ||r||/||r0|| = {res.reduction:.3e}, {res.elapsed_s:.3f} s")
+        del x
+
+    # ---- timed region: exactly K CG iterations ---------------------------------------------------
+    x = tl.zeros(tl.rl.n_o)
+    b = tl.to_device(tl.rl.b)
+    cg = CgIteration(tl.ctx, tl.op, tl.prec, x, b)
+    cg.steps(args.warmup)
+    tl.ctx.timing(True)
+    tl.ctx.timing_reset()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cg.steps(args.steps)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tl.ctx.timing(False)
+    deff = cg.defect()
+    local_ms, local_cnt = tl.ctx.timer("Schwarz/local solve")
+    timers = {name: tl.ctx.timer(name) for name in ("Operator/apply", "Schwarz/get defect", "Schwarz/local solve",
+                                                    "Schwarz/add solution", "GalerkinPrec/apply", "CombinedPreconditioner/apply")}
+    cg.end()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert np.isfinite(deff), "defect became non-finite inside the timed region"
+
+    its_per_s = args.steps / elapsed
+    ndof = grid.nglobal
+    # ---- roofline of the dominant kernel: the level-scheduled ILU(0) triangular solve -----------
+    # unit = one local solve x = (LU)^-1 d over the rank's subdomains (one HIP-graph launch of the
+    # level kernels); algorithmic bytes = 12 B per stored factor entry (f64 value + int32 column)
+    # + 40 B per row (d read, x written, x read + written by the backward sweep, inverse pivot).
+    z, n = tl.A_dir.nnz, tl.rl.n
+    alg_bytes = 12.0 * z + 40.0 * n
+    roofline = None
+    if local_cnt > 0:
+        avg_ms = local_ms / local_cnt
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "ilu0_trsv (k_trsv_lower_level / k_trsv_upper_level / k_trsv_small_levels)",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
+                    "launches_timed": int(local_cnt)}
+    # whole-iteration algorithmic traffic: 12(z_o+z) + 16 k n + 56 n + 170 n_o
+    k = 0 if tl.galerkin is None else max(tl.k_all)
+    it_bytes = 12.0 * (tl.A.nnz + z) + 16.0 * k * n + 56.0 * n + 170.0 * tl.rl.n_o
+    iteration = {"algorithmic_bytes": it_bytes, "achieved_GBs": it_bytes / (elapsed / args.steps) / 1e9,
+                 "frac_of_hbm_peak": it_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                 "phase_ms_per_iteration": {nm: (v[0] / max(v[1], 1)) for nm, v in timers.items()}}
+
+    # ---- CPU baseline: the oracle (port of the reference's CPU path) on the host cores ----------
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_iters > 0:
+        from oracle import apply_oracle as ao
+        from tests.oracle_bridge import oracle_time_iterations
+        threads = max(1, min(args.cpu_threads, os.cpu_count() or 1, dec.nsub))
+        ao.set_threads(threads)
+        basis_o = "pou" if coarse == "pou" else ("none" if coarse == "none" else tl.host_basis())
+        t_cpu, it_cpu = oracle_time_iterations(dec, args.cpu_iters, coarse=basis_o, schwarz_type="standard", mode="additive")
+        ao.set_threads(1)
+        cpu = {"value": it_cpu / t_cpu, "unit": "iterations/s", "cores": threads, "kind": "port",
+               "sample": f"{it_cpu} CG iterations of the same {G}^3 / 8-subdomain problem (setup excluded), one host thread per subdomain"}
+        log(rank, f"cpu_baseline: {it_cpu} iterations in {t_cpu:.1f} s on {threads} threads")
+
+    if rank == 0:
+        out = {
+            "metric": "preconditioned CG iterations/sec (two-level additive Schwarz), 3D Poisson 10M DoF",
+            "value": its_per_s, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"3D Q1 Poisson {G}^3 = {ndof} DoF, 8 overlapping subdomains (2x2x2, overlap {args.overlap}), "
+                                   f"ILU(0) subdomain solves, coarse space '{coarse}' (K = {0 if tl.galerkin is None else tl.K}), additive, CG",
+                       "subdomains_per_gpu": 8 // world, "parallelism": f"dd{world}"},
+            "dof_iters_per_sec": ndof * its_per_s,
+            "solve": solve_info,
+            "setup_s": {"host": t_host, "device": t_dev},
+            "roofline": roofline, "iteration_traffic": iteration, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

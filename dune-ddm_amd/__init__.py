@@ -76,6 +76,7 @@ SYMBOLS = {
     "ddm_schwarz_create": (_I32, [_P, _P, _I64, _P, _I64, _P, _P, _I32, _P, _P, _PP]),
     "ddm_schwarz_destroy": (None, [_P]),
     "ddm_schwarz_apply": (_I32, [_P, _P, _P, _P]),
+    "ddm_schwarz_num_levels": (_I64, [_P, _I32]),
     "ddm_galerkin_create": (_I32, [_P, _I64, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _P, _PP]),
     "ddm_galerkin_destroy": (None, [_P]),
     "ddm_galerkin_apply": (_I32, [_P, _P, _P, _P]),
@@ -84,6 +85,11 @@ SYMBOLS = {
     "ddm_combined_destroy": (None, [_P]),
     "ddm_combined_apply": (_I32, [_P, _P, _P, _P]),
     "ddm_cg_solve": (_I32, [_P, _P, _P, _P, _P, _D, _I32, _I32, _P, ctypes.POINTER(SolveResult)]),
+    "ddm_cg_begin": (_I32, [_P, _P, _P, _P, _P, _PP]),
+    "ddm_cg_steps": (_I32, [_P, _P, _I32]),
+    "ddm_cg_defect": (_I32, [_P, _P, ctypes.POINTER(ctypes.c_double)]),
+    "ddm_cg_def0": (_D, [_P]),
+    "ddm_cg_end": (None, [_P, _P]),
     "ddm_timing_enable": (_I32, [_P, _I32]),
     "ddm_timing_get": (_I32, [_P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
     "ddm_timing_reset": (_I32, [_P]),
@@ -316,6 +322,9 @@ class SchwarzPreconditioner:
     def apply(self, x, d):
         self.ctx.check(self.ctx.lib.ddm_schwarz_apply(self.ctx.h, self.h, _ptr(x), _ptr(d)))
 
+    def num_levels(self):
+        return (int(self.ctx.lib.ddm_schwarz_num_levels(self.h, 0)), int(self.ctx.lib.ddm_schwarz_num_levels(self.h, 1)))
+
 
 class GalerkinPreconditioner:
     """dune/ddm/galerkin_preconditioner.hh:40-363 (apply path; the coarse matrix is assembled by
@@ -377,3 +386,28 @@ def cg_solve(ctx: Context, op: NonOverlappingOperator, prec: CombinedPreconditio
     ctx.check(ctx.lib.ddm_cg_solve(ctx.h, op.h, prec.h, _ptr(x), _ptr(b), float(reduction), int(maxit), int(fixed_iterations),
                                    _hp(hist), ctypes.byref(res)))
     return res, (hist[:res.iterations + 1] if history else None)
+
+
+class CgIteration:
+    """ddm_cg_begin / steps / defect / end: the CG loop in pieces (exact-K timing in bench.py)."""
+
+    def __init__(self, ctx: Context, op: NonOverlappingOperator, prec: CombinedPreconditioner, x, b):
+        self.ctx = ctx
+        h = ctypes.c_void_p()
+        ctx.check(ctx.lib.ddm_cg_begin(ctx.h, op.h, prec.h, _ptr(x), _ptr(b), ctypes.byref(h)))
+        self.h = h
+        self._keep = (op, prec, x, b)
+        self.def0 = ctx.lib.ddm_cg_def0(h)
+
+    def steps(self, k):
+        self.ctx.check(self.ctx.lib.ddm_cg_steps(self.ctx.h, self.h, int(k)))
+
+    def defect(self):
+        d = ctypes.c_double()
+        self.ctx.check(self.ctx.lib.ddm_cg_defect(self.ctx.h, self.h, ctypes.byref(d)))
+        return d.value
+
+    def end(self):
+        if self.h:
+            self.ctx.lib.ddm_cg_end(self.ctx.h, self.h)
+            self.h = None

@@ -20,6 +20,8 @@ using namespace ddm;
 struct TimerEntry {
   double ms = 0.0;
   int64_t count = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; // recorded, not yet resolved (no sync in the hot loop)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;    // recycled event pairs
 };
 
 struct ddm_ctx {
@@ -80,25 +82,47 @@ static int upload(ddm_ctx *ctx, const T *host, int64_t n, T **dev)
   return DDM_OK;
 }
 
+// HIP-event timer on the context's stream.  Nothing synchronises while timing is on: the event
+// pairs are resolved (hipEventElapsedTime) when the totals are read, after the stream has drained.
 struct ScopedTimer {
   ddm_ctx *ctx;
-  const char *name;
-  ScopedTimer(ddm_ctx *c, const char *n) : ctx(c), name(n)
+  TimerEntry *t = nullptr;
+  std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+  ScopedTimer(ddm_ctx *c, const char *n) : ctx(c)
   {
-    if (ctx->timing) (void)hipEventRecord(ctx->ev0, ctx->stream);
+    if (!ctx->timing) return;
+    t = &ctx->timers[n];
+    if (!t->pool.empty()) {
+      ev = t->pool.back();
+      t->pool.pop_back();
+    } else {
+      (void)hipEventCreate(&ev.first);
+      (void)hipEventCreate(&ev.second);
+    }
+    (void)hipEventRecord(ev.first, ctx->stream);
   }
   ~ScopedTimer()
   {
-    if (!ctx->timing) return;
-    (void)hipEventRecord(ctx->ev1, ctx->stream);
-    (void)hipEventSynchronize(ctx->ev1);
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
-    auto &t = ctx->timers[name];
-    t.ms += ms;
-    t.count += 1;
+    if (!t) return;
+    (void)hipEventRecord(ev.second, ctx->stream);
+    t->pending.push_back(ev);
   }
 };
+static void resolve_timers(ddm_ctx *ctx)
+{
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &kv : ctx->timers) {
+    for (auto &ev : kv.second.pending) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+        kv.second.ms += ms;
+        kv.second.count += 1;
+      }
+      kv.second.pool.push_back(ev);
+    }
+    kv.second.pending.clear();
+  }
+}
 
 // ---- context ---------------------------------------------------------------------------------
 extern "C" int ddm_ctx_create(int device, void *hip_stream, ddm_ctx **out)
@@ -191,6 +215,7 @@ extern "C" int ddm_timing_enable(ddm_ctx *ctx, int on)
 }
 extern "C" int ddm_timing_get(ddm_ctx *ctx, const char *name, double *total_ms, int64_t *count)
 {
+  resolve_timers(ctx);
   auto it = ctx->timers.find(name);
   if (it == ctx->timers.end()) {
     if (total_ms) *total_ms = 0.0;
@@ -203,7 +228,11 @@ extern "C" int ddm_timing_get(ddm_ctx *ctx, const char *name, double *total_ms, 
 }
 extern "C" int ddm_timing_reset(ddm_ctx *ctx)
 {
-  ctx->timers.clear();
+  resolve_timers(ctx);
+  for (auto &kv : ctx->timers) {
+    kv.second.ms = 0.0;
+    kv.second.count = 0;
+  }
   return DDM_OK;
 }
 
@@ -788,6 +817,7 @@ extern "C" void ddm_schwarz_destroy(ddm_schwarz *S)
   (void)hipFree(S->x_ovlp);
   delete S;
 }
+extern "C" int64_t ddm_schwarz_num_levels(const ddm_schwarz *S, int upper) { return ddm_ilu0_num_levels(S->solver, upper); }
 // x (= or +=) R~^T [D] A_dir^-1 R~ d
 static int schwarz_apply_impl(ddm_ctx *ctx, ddm_schwarz *S, double *x, const double *d, bool acc)
 {
@@ -907,6 +937,7 @@ extern "C" void ddm_galerkin_destroy(ddm_galerkin *G)
 }
 static int galerkin_apply_impl(ddm_ctx *ctx, ddm_galerkin *G, double *x, const double *d, bool acc)
 {
+  ScopedTimer t(ctx, "GalerkinPrec/apply");
   hipLaunchKernelGGL(k_extend, dim3(grid_for(G->n)), dim3(WG), 0, ctx->stream, G->n, G->ext_map, d, G->d_ovlp); // :159
   DDMCHECK(ddm_halo_exchange(ctx, G->copy, G->d_ovlp));                                                         // :162
   hipLaunchKernelGGL(k_coarse_restrict_partial, dim3(G->nchunk), dim3(WG), 0, ctx->stream, (int)G->kmax, G->ld, G->basis, G->d_ovlp,
@@ -929,7 +960,6 @@ static int galerkin_apply_impl(ddm_ctx *ctx, ddm_galerkin *G, double *x, const d
 }
 extern "C" int ddm_galerkin_apply(ddm_ctx *ctx, ddm_galerkin *G, double *x, const double *d)
 {
-  ScopedTimer t(ctx, "GalerkinPrec/apply");
   return galerkin_apply_impl(ctx, G, x, d, false);
 }
 
@@ -1024,63 +1054,125 @@ extern "C" int ddm_combined_apply(ddm_ctx *ctx, ddm_combined *C, double *x, cons
 }
 
 // ---- CG ----------------------------------------------------------------------------------------
+// dune-istl CGSolver::apply, split so that a caller can time an exact number of
+// iterations: begin = "b -= A x; def0 = ||b||", one step = "prec.apply; rho; [beta; p = beta p + q];
+// q = A p; alpha; lambda; x += lambda p; b -= lambda q; def = ||b||".
+struct ddm_cg {
+  ddm_op *op = nullptr;
+  ddm_combined *prec = nullptr;
+  double *x = nullptr, *b = nullptr, *p = nullptr, *q = nullptr;
+  int64_t n = 0;
+  int it = 0;
+  double def0 = 0.0;
+};
+extern "C" int ddm_cg_begin(ddm_ctx *ctx, ddm_op *op, ddm_combined *prec, double *x, double *b, ddm_cg **out)
+{
+  if (!ctx || !op || !prec || !x || !b || !out) return fail(ctx, DDM_EINVAL, "ddm_cg_begin: bad arguments");
+  ddm_cg *S = new ddm_cg;
+  S->op = op;
+  S->prec = prec;
+  S->x = x;
+  S->b = b;
+  S->n = op->n;
+  if (hipMalloc((void **)&S->p, sizeof(double) * (size_t)std::max<int64_t>(S->n, 1)) != hipSuccess ||
+      hipMalloc((void **)&S->q, sizeof(double) * (size_t)std::max<int64_t>(S->n, 1)) != hipSuccess) {
+    (void)hipFree(S->p);
+    delete S;
+    return fail(ctx, DDM_EHIP, "ddm_cg_begin: allocation failed");
+  }
+  int rc = ddm_op_applyscaleadd(ctx, op, -1.0, x, b); // prec.pre(x,b); b -= A x
+  double bb = 0.0;
+  if (!rc) rc = dot_device(ctx, S->n, op->owner, b, b, ctx->scal + 5);
+  if (!rc) rc = ddm_memcpy_d2h(ctx, &bb, ctx->scal + 5, sizeof(double));
+  if (rc) {
+    (void)hipFree(S->p);
+    (void)hipFree(S->q);
+    delete S;
+    return rc;
+  }
+  S->def0 = std::sqrt(bb);
+  *out = S;
+  return DDM_OK;
+}
+extern "C" void ddm_cg_end(ddm_ctx *ctx, ddm_cg *S)
+{
+  if (!S) return;
+  if (ctx) (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(S->p);
+  (void)hipFree(S->q);
+  delete S;
+}
+extern "C" double ddm_cg_def0(const ddm_cg *S) { return S->def0; }
+// Enqueues k iterations without synchronising; the squared defect of the last one is left in
+// device scalar 5 (read it with ddm_cg_defect).
+extern "C" int ddm_cg_steps(ddm_ctx *ctx, ddm_cg *S, int k)
+{
+  double *scal = ctx->scal;
+  const int G = grid_for(S->n);
+  for (int i = 0; i < k; ++i) {
+    const bool first = S->it == 0;
+    DDMCHECK(ddm_combined_apply(ctx, S->prec, first ? S->p : S->q, S->b));                 // q = M^-1 b  (p on the first step)
+    DDMCHECK(dot_device(ctx, S->n, S->op->owner, first ? S->p : S->q, S->b, scal + (first ? 0 : 3))); // rho = <q, b>
+    if (!first) {
+      hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(1), 0, ctx->stream, scal);                 // beta = rho / rholast; rholast = rho
+      hipLaunchKernelGGL(k_cg_direction, dim3(G), dim3(WG), 0, ctx->stream, S->n, scal, S->q, S->p); // p = beta p + q
+    }
+    DDMCHECK(ddm_op_apply(ctx, S->op, S->p, S->q));                                          // q = A p
+    DDMCHECK(dot_device(ctx, S->n, S->op->owner, S->p, S->q, scal + 1));                     // alpha = <p, q>
+    hipLaunchKernelGGL(k_cg_lambda, dim3(1), dim3(1), 0, ctx->stream, scal);                 // lambda = rholast / alpha
+    hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(WG), 0, ctx->stream, S->n, scal, S->p, S->q, S->x, S->b); // x += lambda p; b -= lambda q
+    DDMCHECK(dot_device(ctx, S->n, S->op->owner, S->b, S->b, scal + 5));                     // def^2 = <b, b>
+    S->it += 1;
+  }
+  HIPCHECK(ctx, hipGetLastError());
+  return DDM_OK;
+}
+extern "C" int ddm_cg_defect(ddm_ctx *ctx, ddm_cg *S, double *def_host) // synchronous
+{
+  double bb = 0.0;
+  DDMCHECK(ddm_memcpy_d2h(ctx, &bb, ctx->scal + 5, sizeof(double)));
+  *def_host = std::sqrt(bb);
+  (void)S;
+  return DDM_OK;
+}
+
 extern "C" int ddm_cg_solve(ddm_ctx *ctx, ddm_op *op, ddm_combined *prec, double *x, double *b, double reduction, int maxit,
                             int fixed_iterations, double *hist_host, ddm_solve_result *res)
 {
-  if (!ctx || !op || !prec || !x || !b || !res) return fail(ctx, DDM_EINVAL, "ddm_cg_solve: bad arguments");
-  const int64_t n = op->n;
-  double *p = nullptr, *q = nullptr;
-  HIPCHECK(ctx, hipMalloc((void **)&p, sizeof(double) * (size_t)std::max<int64_t>(n, 1)));
-  HIPCHECK(ctx, hipMalloc((void **)&q, sizeof(double) * (size_t)std::max<int64_t>(n, 1)));
-  double *scal = ctx->scal;
-  int rc = DDM_OK;
-  auto done = [&](int r) {
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(p);
-    (void)hipFree(q);
-    return r;
-  };
-  const int G = grid_for(n);
-  // prec.pre(x,b); b -= A x
-  rc = ddm_op_applyscaleadd(ctx, op, -1.0, x, b);
-  if (rc) return done(rc);
-  double bb = 0.0;
-  rc = dot_device(ctx, n, op->owner, b, b, scal + 5);
-  if (!rc) rc = ddm_memcpy_d2h(ctx, &bb, scal + 5, sizeof(double));
-  if (rc) return done(rc);
-  const double def0 = std::sqrt(bb);
+  if (!res) return fail(ctx, DDM_EINVAL, "ddm_cg_solve: bad arguments");
+  ddm_cg *S = nullptr;
+  DDMCHECK(ddm_cg_begin(ctx, op, prec, x, b, &S));
+  const double def0 = S->def0;
   res->def0 = def0;
   res->iterations = 0;
   res->converged = 0;
   res->reduction = 1.0;
   res->elapsed_s = 0.0;
   if (hist_host) hist_host[0] = def0;
-  if (!(def0 == def0)) return done(fail(ctx, DDM_ENUMERIC, "initial defect is NaN"));
+  if (!(def0 == def0)) {
+    ddm_cg_end(ctx, S);
+    return fail(ctx, DDM_ENUMERIC, "initial defect is NaN");
+  }
   if (def0 < 1e-30) {
     res->converged = 1;
-    return done(DDM_OK);
+    ddm_cg_end(ctx, S);
+    return DDM_OK;
   }
-  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  (void)hipStreamSynchronize(ctx->stream);
   const auto t0 = std::chrono::steady_clock::now();
-  // p = 0; prec.apply(p, b); rholast = <p, b>
-  rc = ddm_combined_apply(ctx, prec, p, b);
-  if (!rc) rc = dot_device(ctx, n, op->owner, p, b, scal + 0);
-  if (rc) return done(rc);
-  const int iters = fixed_iterations > 0 ? fixed_iterations : maxit;
+  int rc = DDM_OK;
   double deff = def0;
-  for (int i = 1; i <= iters; ++i) {
-    rc = ddm_op_apply(ctx, op, p, q);                       // q = A p
-    if (!rc) rc = dot_device(ctx, n, op->owner, p, q, scal + 1); // alpha = <p, q>
-    if (rc) break;
-    hipLaunchKernelGGL(k_cg_lambda, dim3(1), dim3(1), 0, ctx->stream, scal);                 // lambda = rholast / alpha
-    hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(WG), 0, ctx->stream, n, scal, p, q, x, b); // x += lambda p; b -= lambda q
-    rc = dot_device(ctx, n, op->owner, b, b, scal + 5);                                      // def = ||b||
-    if (rc) break;
-    res->iterations = i;
-    if (fixed_iterations <= 0 || hist_host) {
-      rc = ddm_memcpy_d2h(ctx, &bb, scal + 5, sizeof(double));
+  if (fixed_iterations > 0 && !hist_host) {
+    rc = ddm_cg_steps(ctx, S, fixed_iterations);
+    if (!rc) rc = ddm_cg_defect(ctx, S, &deff);
+    res->iterations = fixed_iterations;
+  } else {
+    const int iters = fixed_iterations > 0 ? fixed_iterations : maxit;
+    for (int i = 1; i <= iters && !rc; ++i) {
+      rc = ddm_cg_steps(ctx, S, 1);
+      if (!rc) rc = ddm_cg_defect(ctx, S, &deff); // the Krylov loop tests the defect every iteration
       if (rc) break;
-      deff = std::sqrt(bb);
+      res->iterations = i;
       if (hist_host) hist_host[i] = deff;
       if (!(deff == deff)) {
         rc = fail(ctx, DDM_ENUMERIC, "defect is NaN in iteration %d", i);
@@ -1091,21 +1183,10 @@ extern "C" int ddm_cg_solve(ddm_ctx *ctx, ddm_op *op, ddm_combined *prec, double
         break;
       }
     }
-    if (i == iters) break;
-    rc = ddm_combined_apply(ctx, prec, q, b);                 // q = 0; q = M^-1 b
-    if (!rc) rc = dot_device(ctx, n, op->owner, q, b, scal + 3); // rho = <q, b>
-    if (rc) break;
-    hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(1), 0, ctx->stream, scal);              // beta = rho / rholast; rholast = rho
-    hipLaunchKernelGGL(k_cg_direction, dim3(G), dim3(WG), 0, ctx->stream, n, scal, q, p); // p = beta p + q
   }
-  if (!rc && hipGetLastError() != hipSuccess) rc = fail(ctx, DDM_EHIP, "kernel launch failed in CG");
   (void)hipStreamSynchronize(ctx->stream);
-  const auto t1 = std::chrono::steady_clock::now();
-  res->elapsed_s = std::chrono::duration<double>(t1 - t0).count();
-  if (!rc && fixed_iterations > 0 && !hist_host) {
-    rc = ddm_memcpy_d2h(ctx, &bb, scal + 5, sizeof(double));
-    deff = std::sqrt(bb);
-  }
+  res->elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   res->reduction = deff / def0;
-  return done(rc);
+  ddm_cg_end(ctx, S);
+  return rc;
 }

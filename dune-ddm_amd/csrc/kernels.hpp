@@ -84,28 +84,49 @@ __global__ __launch_bounds__(WG) void k_spmv_stream(const int64_t *__restrict__ 
 // Rows of one level are independent; their entries are stored level-by-level in sliced-ELL
 // (column-major inside the level) so that a thread-per-row kernel reads them coalesced and sums
 // them in the same column order as the sequential back-solve.
+// One row of a level: all column indices / values of the row are loaded first, then all x
+// gathers are issued together (memory-level parallelism: two dependent round trips per level
+// instead of two per entry), then the products are subtracted in column order.
+constexpr int TRSV_UNROLL = 16;
+template <class IDX>
+__device__ __forceinline__ double trsv_row_sum(double s, int w, IDX m, IDX r, const int32_t *__restrict__ cols,
+                                               const double *__restrict__ vals, const double *x)
+{
+  for (int k0 = 0; k0 < w; k0 += TRSV_UNROLL) {
+    int32_t c[TRSV_UNROLL];
+    double v[TRSV_UNROLL], xv[TRSV_UNROLL];
+#pragma unroll
+    for (int u = 0; u < TRSV_UNROLL; ++u) {
+      const bool ok = k0 + u < w;
+      c[u] = ok ? cols[(IDX)(k0 + u) * m + r] : -1;
+      v[u] = ok ? vals[(IDX)(k0 + u) * m + r] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < TRSV_UNROLL; ++u) xv[u] = c[u] >= 0 ? x[c[u]] : 0.0;
+#pragma unroll
+    for (int u = 0; u < TRSV_UNROLL; ++u) s -= v[u] * xv[u];
+  }
+  return s;
+}
+
 __global__ __launch_bounds__(WG) void k_trsv_lower_level(int m, int w, const int32_t *__restrict__ rows,
                                                           const int32_t *__restrict__ cols, const double *__restrict__ vals,
-                                                          const double *__restrict__ d, double *__restrict__ x)
+                                                          const double *__restrict__ d, double *x)
 {
   const int r = blockIdx.x * WG + threadIdx.x;
   if (r >= m) return;
   const int row = rows[r];
-  double s = d[row];
-  for (int k = 0; k < w; ++k) s -= vals[(int64_t)k * m + r] * x[cols[(int64_t)k * m + r]];
-  x[row] = s;
+  x[row] = trsv_row_sum<int64_t>(d[row], w, m, r, cols, vals, x);
 }
 
 __global__ __launch_bounds__(WG) void k_trsv_upper_level(int m, int w, const int32_t *__restrict__ rows,
                                                           const int32_t *__restrict__ cols, const double *__restrict__ vals,
-                                                          const double *__restrict__ dinv, double *__restrict__ x)
+                                                          const double *__restrict__ dinv, double *x)
 {
   const int r = blockIdx.x * WG + threadIdx.x;
   if (r >= m) return;
   const int row = rows[r];
-  double s = x[row];
-  for (int k = 0; k < w; ++k) s -= vals[(int64_t)k * m + r] * x[cols[(int64_t)k * m + r]];
-  x[row] = s * dinv[r];
+  x[row] = trsv_row_sum<int64_t>(x[row], w, m, r, cols, vals, x) * dinv[r];
 }
 
 // Several consecutive small levels (each <= WG*TRSV_SMALL_ROWS rows) in ONE workgroup: the levels
@@ -129,10 +150,7 @@ __global__ __launch_bounds__(TRSV_SMALL_WG) void k_trsv_small_levels(int nlev, c
     const LevelDesc L = desc[l];
     for (int r = threadIdx.x; r < L.m; r += TRSV_SMALL_WG) {
       const int row = rows[L.row_off + r];
-      double s = UPPER ? x[row] : d[row];
-      const int32_t *c = cols + L.ent_off;
-      const double *v = vals + L.ent_off;
-      for (int k = 0; k < L.w; ++k) s -= v[(int64_t)k * L.m + r] * x[c[(int64_t)k * L.m + r]];
+      const double s = trsv_row_sum<int>(UPPER ? x[row] : d[row], L.w, L.m, r, cols + L.ent_off, vals + L.ent_off, x);
       x[row] = UPPER ? s * dinv[L.row_off + r] : s;
     }
     __syncthreads(); // workgroup-scope release/acquire of the x entries just written

@@ -128,6 +128,16 @@ class TwoLevelSchwarz:
             self.set_coarse_basis(basis)
         self.prec = CombinedPreconditioner(ctx, mode, self.op, self.schwarz, self.galerkin)
 
+    def schwarz_levels(self):
+        return self.schwarz.num_levels()
+
+    def rebuild_combined(self, mode="additive"):
+        self.prec = CombinedPreconditioner(self.ctx, mode, self.op, self.schwarz, self.galerkin)
+
+    def host_basis(self):
+        """coarse basis as {sub id: [vectors]} for every subdomain (single-rank runs; checker input)"""
+        return {s: [v.copy() for v in self.basis_by_sub[s]] for s in self.rl.local}
+
     # -- device vectors
     def zeros(self, n):
         return self.torch.zeros(int(n), dtype=self.torch.float64, device=self.dev)
@@ -140,6 +150,7 @@ class TwoLevelSchwarz:
         """basis_by_sub: {local sub id: (k_s, n_s) array}; builds R A R^T and the Galerkin level."""
         rl, dec, torch = self.rl, self.dec, self.torch
         P = dec.nsub
+        self.basis_by_sub = {s: np.asarray(basis_by_sub[s], dtype=np.float64) for s in rl.local}
         k_local = {s: int(basis_by_sub[s].shape[0]) for s in rl.local}
         k_all = self._allgather_small(k_local, P)              # MPI_Allgather of num_t (galerkin_preconditioner.hh:248)
         kmax = max(k_all)

@@ -127,6 +127,7 @@ int ddm_schwarz_create(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t nblocks, cons
                        ddm_halo *ovlp_add, ddm_schwarz **out);
 void ddm_schwarz_destroy(ddm_schwarz *S);
 int ddm_schwarz_apply(ddm_ctx *ctx, ddm_schwarz *S, double *x, const double *d); /* :115-149 */
+int64_t ddm_schwarz_num_levels(const ddm_schwarz *S, int upper); /* dependency levels of the local L / U solve */
 
 /* ---- GalerkinPreconditioner (galerkin_preconditioner.hh:40-363) ---------------------------
  * basis_host: kmax x n row-major (vector j contiguous), zero rows where a subdomain has fewer
@@ -167,6 +168,16 @@ typedef struct {
  * fixed_iterations > 0: run exactly that many iterations without testing convergence (bench). */
 int ddm_cg_solve(ddm_ctx *ctx, ddm_op *op, ddm_combined *prec, double *x, double *b, double reduction, int maxit,
                  int fixed_iterations, double *hist_host, ddm_solve_result *res);
+
+/* The same loop in pieces, so that a caller can bracket an exact number of iterations
+ * (bench.py): begin = "b -= A x; def0 = ||b||" (synchronous); steps = k iterations enqueued
+ * without host synchronisation; defect = ||b|| of the last enqueued iteration (synchronous). */
+typedef struct ddm_cg ddm_cg;
+int ddm_cg_begin(ddm_ctx *ctx, ddm_op *op, ddm_combined *prec, double *x, double *b, ddm_cg **out);
+int ddm_cg_steps(ddm_ctx *ctx, ddm_cg *cg, int k);
+int ddm_cg_defect(ddm_ctx *ctx, ddm_cg *cg, double *def_host);
+double ddm_cg_def0(const ddm_cg *cg);
+void ddm_cg_end(ddm_ctx *ctx, ddm_cg *cg);
 
 /* ---- instrumentation ---------------------------------------------------------------------
  * Named event timers mirroring the reference's Logger events ("Schwarz/local solve", ...,

@@ -61,6 +61,32 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+# One host thread per simulated rank (the reference runs one MPI rank per subdomain); the C
+# kernels release the GIL.  THREADS = 1 keeps everything sequential (default, used by the tests).
+THREADS = 1
+_POOL = None
+
+
+def set_threads(n):
+    global THREADS, _POOL
+    THREADS = max(1, int(n))
+    if _POOL is not None:
+        _POOL.shutdown()
+        _POOL = None
+    if THREADS > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(THREADS)
+
+
+def pfor(fn, n):
+    """for r in range(n): fn(r) -- ranks are independent between communication calls"""
+    if THREADS > 1 and n > 1:
+        list(_POOL.map(fn, range(n)))
+    else:
+        for r in range(n):
+            fn(r)
+
+
 class Csr:
     """Flattened scalar BCRSMatrix (int64 row pointers, int32 columns, f64 values)."""
 
@@ -156,8 +182,7 @@ class NonOverlappingOperator:
         self.A, self.comm = A, comm
 
     def apply(self, x, y):                                   # :34-39
-        for r, A in enumerate(self.A):
-            A.mv(x[r], y[r])
+        pfor(lambda r: self.A[r].mv(x[r], y[r]), len(self.A))
         self.comm.addOwnerCopyToOwnerCopy(y)
 
     def applyscaleadd(self, alpha, x, y):                    # :41-50
@@ -190,7 +215,11 @@ class SchwarzPreconditioner:
         if type not in ("restricted", "standard"):
             raise NotImplementedError("Unknown Schwarz type '" + type + "'")   # :83
         self.A, self.comm, self.pou, self.type = Aovlp, comm, pou, type
-        self.solver = [solver_factory(A) for A in Aovlp]                       # :92
+        self.solver = [None] * len(Aovlp)
+
+        def factor(r):
+            self.solver[r] = solver_factory(Aovlp[r])                          # :92
+        pfor(factor, len(Aovlp))
         for r, A in enumerate(Aovlp):                                          # :186-193
             if len(comm.owner[r]) != A.n:
                 raise RuntimeError("Remote indices size does not match overlapping matrix size")
@@ -204,9 +233,10 @@ class SchwarzPreconditioner:
             self.d_ovlp[r][:] = 0.0                            # :121
             self.d_ovlp[r][:len(d[r])] = d[r]                  # :122
         self.comm.copyOwnerToAll(self.d_ovlp)                 # :125
-        for r in range(len(d)):
+        def local_solve(r):
             self.x_ovlp[r][:] = 0.0                            # :132
             self.solver[r].apply(self.x_ovlp[r], self.d_ovlp[r])   # :133
+        pfor(local_solve, len(d))
         if self.type == "restricted" and self.pou is not None:     # :139-141
             for r in range(len(d)):
                 lib().orc_scale(len(self.pou[r]), _p(self.pou[r]), _p(self.x_ovlp[r]))
@@ -304,14 +334,18 @@ class GalerkinPreconditioner:
             self.d_ovlp[r][:len(d[r])] = d[r]                  # :159 (no zero fill: the tail is overwritten by the copy below)
         self.comm.copyOwnerToAll(self.d_ovlp)                 # :162
         d0 = np.zeros(self.total_num_t)
-        for r in range(P):                                     # :165-171
+
+        def restrict(r):                                       # :165-171
             for k in range(self.num_t[r]):
                 d0[self.offset_per_rank[r] + k] = lib().orc_dot(len(self.d_ovlp[r]), _p(self.restr_vecs[r][k]), _p(self.d_ovlp[r]))
+        pfor(restrict, P)
         x0 = self.solver.solve(d0)                             # :174-179
-        for r in range(P):                                     # :186-188
+
+        def prolong(r):                                        # :186-188
             self.x_ovlp[r][:] = 0.0
             for k in range(self.num_t[r]):
                 lib().orc_axpy(len(self.x_ovlp[r]), float(x0[self.offset_per_rank[r] + k]), _p(self.restr_vecs[r][k]), _p(self.x_ovlp[r]))
+        pfor(prolong, P)
         self.comm.addOwnerCopyToAll(self.x_ovlp)              # :190
         for r in range(P):
             x[r][:] = self.x_ovlp[r][:len(x[r])]               # :193
