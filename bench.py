@@ -85,7 +85,9 @@ def main():
     if coarse == "geneo":
         from dune_ddm_amd.geneo import geneo_basis
         tl = TwoLevelSchwarz(dec, rank, world, local_rank, comm, schwarz_type="standard", mode="additive", coarse="none")
-        basis = geneo_basis(tl, nev=args.nev)
+        basis = geneo_basis(tl, nev=args.nev, verbose=(rank == 0 and os.environ.get("DDM_VERBOSE") == "1"))
+        log(rank, f"GenEO: {tl.geneo_info['iterations']} block iterations, converged={tl.geneo_info['converged']}, "
+                  f"lambda range of subdomain {tl.rl.local[0]}: {tl.geneo_info['eigenvalues'][tl.rl.local[0]][[0, -1]]}")
         tl.set_coarse_basis(basis)
         tl.rebuild_combined("additive")
     else:

@@ -19,6 +19,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libddm_hip.so")
 
+GENEO_AVAILABLE = True   # dune-ddm_amd/geneo.py: device GenEO coarse-basis builder
+
 DDM_OK, DDM_EINVAL, DDM_EHIP, DDM_ENOTIMPL, DDM_ENUMERIC, DDM_ECOMM = 0, -1, -2, -3, -4, -5
 
 
@@ -57,6 +59,8 @@ SYMBOLS = {
     "ddm_csr_nnz": (_I64, [_P]),
     "ddm_csr_mv": (_I32, [_P, _P, _P, _P]),
     "ddm_csr_usmv": (_I32, [_P, _P, _D, _P, _P]),
+    "ddm_csr_mm": (_I32, [_P, _P, _I32, _P, _P]),
+    "ddm_ilu0_solve_multi": (_I32, [_P, _P, _I32, _P, _P]),
     "ddm_ilu0_create": (_I32, [_P, _P, _I64, _P, _PP]),
     "ddm_ilu0_destroy": (None, [_P]),
     "ddm_ilu0_solve": (_I32, [_P, _P, _P, _P]),
@@ -210,6 +214,11 @@ class CsrMatrix:
     def usmv(self, alpha, x, y):
         self.ctx.check(self.ctx.lib.ddm_csr_usmv(self.ctx.h, self.h, float(alpha), _ptr(x), _ptr(y)))
 
+    def mm(self, X, Y):
+        """Y = A X for row-major (n, nrhs) device tensors"""
+        assert X.shape == Y.shape and X.is_contiguous() and Y.is_contiguous() and X.shape[0] == self.shape[1]
+        self.ctx.check(self.ctx.lib.ddm_csr_mm(self.ctx.h, self.h, int(X.shape[1]), _ptr(X), _ptr(Y)))
+
     def __del__(self):
         try:
             if self.h and self.ctx.h:
@@ -228,6 +237,11 @@ class Ilu0:
 
     def solve(self, d, x):
         self.ctx.check(self.ctx.lib.ddm_ilu0_solve(self.ctx.h, self.h, _ptr(d), _ptr(x)))
+
+    def solve_multi(self, D, X):
+        """X = (LU)^-1 D for row-major (n, nrhs) device tensors"""
+        assert D.shape == X.shape and D.is_contiguous() and X.is_contiguous()
+        self.ctx.check(self.ctx.lib.ddm_ilu0_solve_multi(self.ctx.h, self.h, int(D.shape[1]), _ptr(D), _ptr(X)))
 
     def num_levels(self, upper=False):
         return int(self.ctx.lib.ddm_ilu0_num_levels(self.h, int(upper)))

@@ -324,6 +324,18 @@ extern "C" int ddm_csr_usmv(ddm_ctx *ctx, const ddm_csr *A, double alpha, const 
   return csr_mv_impl(ctx, A, alpha, x, y, true);
 }
 
+// Y = A X, row-major n x nrhs block vectors (MatOp::perform_op on a block; spectra.hh:100-105)
+extern "C" int ddm_csr_mm(ddm_ctx *ctx, const ddm_csr *A, int nrhs, const double *X, double *Y)
+{
+  if (!A || !X || !Y || X == Y || nrhs < 1) return fail(ctx, DDM_EINVAL, "ddm_csr_mm: bad arguments");
+  const int64_t threads = A->nrows * (int64_t)nrhs;
+  if (threads == 0) return DDM_OK;
+  hipLaunchKernelGGL(k_spmm_rowmajor, dim3((unsigned)((threads + WG - 1) / WG)), dim3(WG), 0, ctx->stream, A->nrows, nrhs, A->rp, A->ci,
+                     A->va, X, Y);
+  HIPCHECK(ctx, hipGetLastError());
+  return DDM_OK;
+}
+
 // ---- ILU(0) -----------------------------------------------------------------------------------
 // Host factorisation: dune-istl blockILU0Decomposition semantics (IKJ in the pattern, multipliers
 // in L, inverse pivots on the diagonal), natural row order; independent diagonal blocks
@@ -595,6 +607,30 @@ extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double
   F->g_d = d;
   F->g_x = x;
   HIPCHECK(ctx, hipGraphLaunch(F->graph, ctx->stream));
+  return DDM_OK;
+}
+
+// Multi-RHS solve X = (LU)^-1 D for row-major n x nrhs block vectors (GenEO setup path; eager
+// launches, one per level -- the per-level work is nrhs times larger, so launch overhead matters less).
+extern "C" int ddm_ilu0_solve_multi(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double *D, double *X)
+{
+  if (!F || !D || !X || D == X || nrhs < 1) return fail(ctx, DDM_EINVAL, "ddm_ilu0_solve_multi: bad arguments");
+  for (int pass = 0; pass < 2; ++pass) {
+    const TriSchedule &S = pass ? F->U : F->L;
+    for (int64_t l = 0; l < S.nlev; ++l) {
+      const LevelDesc &L = S.desc[l];
+      const int64_t threads = (int64_t)L.m * nrhs;
+      const unsigned grid = (unsigned)((threads + WG - 1) / WG);
+      if (grid == 0) continue;
+      if (pass)
+        hipLaunchKernelGGL(k_trsv_level_multi<true>, dim3(grid), dim3(WG), 0, ctx->stream, L.m, L.w, nrhs, S.rows + L.row_off,
+                           S.cols + L.ent_off, S.vals + L.ent_off, S.dinv + L.row_off, D, X);
+      else
+        hipLaunchKernelGGL(k_trsv_level_multi<false>, dim3(grid), dim3(WG), 0, ctx->stream, L.m, L.w, nrhs, S.rows + L.row_off,
+                           S.cols + L.ent_off, S.vals + L.ent_off, (const double *)nullptr, D, X);
+    }
+  }
+  HIPCHECK(ctx, hipGetLastError());
   return DDM_OK;
 }
 

@@ -129,6 +129,74 @@ __global__ __launch_bounds__(WG) void k_trsv_upper_level(int m, int w, const int
   x[row] = trsv_row_sum<int64_t>(x[row], w, m, r, cols, vals, x) * dinv[r];
 }
 
+// Multi-right-hand-side variants (GenEO setup: block eigensolver; cf. the reference's own
+// multi-RHS triangular solve, eigensolvers/umfpack.hh:131-197).  Block vectors are row-major
+// n x nrhs, a thread owns one (row, rhs) pair; the nrhs lanes of a row read the same factor
+// entries (broadcast) and gather nrhs consecutive doubles of x (coalesced).
+template <class IDX>
+__device__ __forceinline__ double trsv_row_sum_multi(double s, int w, IDX m, IDX r, int nrhs, int j,
+                                                     const int32_t *__restrict__ cols, const double *__restrict__ vals,
+                                                     const double *x)
+{
+  for (int k0 = 0; k0 < w; k0 += TRSV_UNROLL) {
+    int32_t c[TRSV_UNROLL];
+    double v[TRSV_UNROLL], xv[TRSV_UNROLL];
+#pragma unroll
+    for (int u = 0; u < TRSV_UNROLL; ++u) {
+      const bool ok = k0 + u < w;
+      c[u] = ok ? cols[(IDX)(k0 + u) * m + r] : -1;
+      v[u] = ok ? vals[(IDX)(k0 + u) * m + r] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < TRSV_UNROLL; ++u) xv[u] = c[u] >= 0 ? x[(int64_t)c[u] * nrhs + j] : 0.0;
+#pragma unroll
+    for (int u = 0; u < TRSV_UNROLL; ++u) s -= v[u] * xv[u];
+  }
+  return s;
+}
+
+template <bool UPPER>
+__global__ __launch_bounds__(WG) void k_trsv_level_multi(int m, int w, int nrhs, const int32_t *__restrict__ rows,
+                                                          const int32_t *__restrict__ cols, const double *__restrict__ vals,
+                                                          const double *__restrict__ dinv, const double *__restrict__ d, double *x)
+{
+  const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x;
+  const int r = (int)(t / nrhs);
+  if (r >= m) return;
+  const int j = (int)(t - (int64_t)r * nrhs);
+  const int64_t o = (int64_t)rows[r] * nrhs + j;
+  const double s = trsv_row_sum_multi<int64_t>(UPPER ? x[o] : d[o], w, m, r, nrhs, j, cols, vals, x);
+  x[o] = UPPER ? s * dinv[r] : s;
+}
+
+// Y = A X for row-major block vectors (n x nrhs): one thread per (row, rhs)
+__global__ __launch_bounds__(WG) void k_spmm_rowmajor(int64_t n, int nrhs, const int64_t *__restrict__ rp,
+                                                       const int32_t *__restrict__ ci, const double *__restrict__ va,
+                                                       const double *__restrict__ x, double *__restrict__ y)
+{
+  const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x;
+  const int64_t row = t / nrhs;
+  if (row >= n) return;
+  const int j = (int)(t - row * nrhs);
+  const int64_t k0 = rp[row], k1 = rp[row + 1];
+  double s = 0.0;
+  for (int64_t kb = k0; kb < k1; kb += 8) {
+    int32_t c[8];
+    double v[8], xv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool ok = kb + u < k1;
+      c[u] = ok ? ci[kb + u] : -1;
+      v[u] = ok ? va[kb + u] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xv[u] = c[u] >= 0 ? x[(int64_t)c[u] * nrhs + j] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u] * xv[u];
+  }
+  y[row * nrhs + j] = s;
+}
+
 // Several consecutive small levels (each <= WG*TRSV_SMALL_ROWS rows) in ONE workgroup: the levels
 // are separated by workgroup barriers instead of kernel boundaries.  desc[l] = {m, w, row_off,
 // ent_off}.  All data of these levels is produced and consumed by this workgroup only.

@@ -78,6 +78,10 @@ int ddm_csr_mv(ddm_ctx *ctx, const ddm_csr *A, const double *x, double *y);
 /* y += alpha A x  (BCRSMatrix::usmv, nonoverlapping_operator.hh:47) */
 int ddm_csr_usmv(ddm_ctx *ctx, const ddm_csr *A, double alpha, const double *x, double *y);
 
+/* Y = A X for row-major n x nrhs block vectors (the B*x / A*x products of the GenEO eigensolver,
+ * eigensolvers/spectra.hh:100-105, on a block of vectors) */
+int ddm_csr_mm(ddm_ctx *ctx, const ddm_csr *A, int nrhs, const double *X, double *Y);
+
 /* ---- local subdomain solver: ILU(0), natural row order ------------------------------------
  * The InverseOperator behind schwarz.hh:57,92,133 for [subdomain_solver] type=loopsolver maxit=1,
  * preconditioner type=ilu n=0.  block_ptr[0..nblocks] = row ranges of the independent diagonal
@@ -86,6 +90,9 @@ int ddm_ilu0_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64
 void ddm_ilu0_destroy(ddm_ilu0 *F);
 /* x = (LU)^-1 d ; d and x must not alias */
 int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x);
+/* X = (LU)^-1 D for row-major n x nrhs block vectors (cf. the reference's multi-RHS triangular
+ * solve eigensolvers/umfpack.hh:131-197); D and X must not alias */
+int ddm_ilu0_solve_multi(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double *D, double *X);
 int64_t ddm_ilu0_num_levels(const ddm_ilu0 *F, int upper);
 /* factor values in the pattern of A (inverse pivots on the diagonal), for parity tests */
 int ddm_ilu0_get_factors_host(ddm_ctx *ctx, const ddm_ilu0 *F, double *lu_host);
