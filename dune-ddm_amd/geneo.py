@@ -79,8 +79,25 @@ def geneo_basis(tl, nev=20, tol=1e-5, shift=1e-3, maxit=400, extra=4, seed=0, ve
         for (a, b) in subs:
             fn(slice(a, b))
 
+    CH = 4096   # rows per split-K chunk of the tall-skinny products
+
     def gram(U, V):
-        return torch.stack([U[a:b].T @ V[a:b] for (a, b) in subs])            # (nsub, p, q)
+        """per-subdomain U^T V (p x q) for tall-skinny row-major blocks.  A plain GEMM call would put the
+        whole K = n_s reduction on a handful of workgroups; split it into CH-row chunks (batched GEMM over
+        the chunks, then a sum) so that every CU works.  TODO(next round): hand-written FP64 MFMA kernel."""
+        out = []
+        for (a, b) in subs:
+            nfull = (b - a) // CH
+            p, q = U.shape[1], V.shape[1]
+            G = torch.zeros((p, q), dtype=U.dtype, device=dev)
+            if nfull:
+                Uc = U[a:a + nfull * CH].view(nfull, CH, p)
+                Vc = V[a:a + nfull * CH].view(nfull, CH, q)
+                G += torch.bmm(Uc.transpose(1, 2), Vc).sum(dim=0)
+            if a + nfull * CH < b:
+                G += U[a + nfull * CH:b].T @ V[a + nfull * CH:b]
+            out.append(G)
+        return torch.stack(out)                                               # (nsub, p, q)
 
     def rotate(U, Ms):
         out = torch.empty((n, Ms.shape[2]), dtype=U.dtype, device=dev)
@@ -113,26 +130,63 @@ def geneo_basis(tl, nev=20, tol=1e-5, shift=1e-3, maxit=400, extra=4, seed=0, ve
         raise RuntimeError("GenEO: initial block is not A-independent")
     CX = mm(dC, X)
 
-    def rayleigh_ritz(blocks_S, blocks_AS, blocks_CS, keep):
-        """Rayleigh-Ritz of the pencil (C~, A~) on span(S) per subdomain; returns the `keep` largest mu"""
-        S = torch.cat(blocks_S, dim=1)
-        AS = torch.cat(blocks_AS, dim=1)
-        CS = torch.cat(blocks_CS, dim=1)
-        gA = gram(S, AS).cpu().numpy()
-        gC = gram(S, CS).cpu().numpy()
+    def small_gevp(gA, gC, keep):
+        """host LAPACK: the `keep` largest mu of gC y = mu gA y per subdomain (y^T gA y = 1)"""
         ws, Ys = [], []
         for i in range(gA.shape[0]):
             try:
-                w, Z = sl.eigh(0.5 * (gC[i] + gC[i].T), 0.5 * (gA[i] + gA[i].T))   # Z^T gA Z = I
+                w, Z = sl.eigh(0.5 * (gC[i] + gC[i].T), 0.5 * (gA[i] + gA[i].T))
             except (np.linalg.LinAlgError, sl.LinAlgError):
                 return None
             ws.append(w[::-1][:keep].copy())
             Ys.append(Z[:, ::-1][:, :keep].copy())
-        return torch.as_tensor(np.array(ws), device=dev), torch.as_tensor(np.array(Ys), device=dev), S, AS, CS
+        return torch.as_tensor(np.array(ws), device=dev), np.array(Ys)
+
+    def rayleigh_ritz(S, AS, CS, keep):
+        """Rayleigh-Ritz of the pencil (C~, A~) on span[S_0 S_1 ...] per subdomain.  Only the upper block
+        triangle of the Gram matrices is computed (tall-skinny products); returns mu and the coefficient
+        blocks Y_k (nsub, m, keep) so that the new vectors are sum_k S_k Y_k (no concatenation)."""
+        nb = len(S)
+        gA = np.zeros((len(subs), nb * m, nb * m))
+        gC = np.zeros_like(gA)
+        for i in range(nb):
+            for j in range(i, nb):
+                a_ij = gram(S[i], AS[j]).cpu().numpy()
+                c_ij = gram(S[i], CS[j]).cpu().numpy()
+                gA[:, i * m:(i + 1) * m, j * m:(j + 1) * m] = a_ij
+                gC[:, i * m:(i + 1) * m, j * m:(j + 1) * m] = c_ij
+                if j > i:
+                    gA[:, j * m:(j + 1) * m, i * m:(i + 1) * m] = a_ij.transpose(0, 2, 1)
+                    gC[:, j * m:(j + 1) * m, i * m:(i + 1) * m] = c_ij.transpose(0, 2, 1)
+        out = small_gevp(gA, gC, keep)
+        if out is None:
+            return None
+        w, Y = out
+        return w, [torch.as_tensor(np.ascontiguousarray(Y[:, k * m:(k + 1) * m, :]), device=dev) for k in range(nb)]
+
+    def combine(blocks, Ys, skip_first=False):
+        out = None
+        for k, (B_, Y_) in enumerate(zip(blocks, Ys)):
+            if skip_first and k == 0:
+                continue
+            t = rotate(B_, Y_)
+            out = t if out is None else out.add_(t)
+        return out
+
+    import time as _time
+    prof = {}
+
+    def tick(name, t0):
+        if verbose:
+            torch.cuda.synchronize()
+            prof[name] = prof.get(name, 0.0) + _time.perf_counter() - t0
+        return _time.perf_counter()
 
     out = rayleigh_ritz([X], [AX], [CX], m)
-    mu, Y, S, AS, CS = out
-    X, AX, CX = rotate(S, Y), rotate(AS, Y), rotate(CS, Y)
+    if out is None:
+        raise RuntimeError("GenEO: Rayleigh-Ritz on the initial block failed")
+    mu, Ys = out
+    X, AX, CX = rotate(X, Ys[0]), rotate(AX, Ys[0]), rotate(CX, Ys[0])
     P = AP = CP = None
     info = {"iterations": 0, "converged": False}
     resn = None
@@ -150,28 +204,38 @@ def geneo_basis(tl, nev=20, tol=1e-5, shift=1e-3, maxit=400, extra=4, seed=0, ve
         if worst < tol:
             info["converged"] = True
             break
+        t0 = tick("residual", _time.perf_counter()) if verbose else 0.0
         W = torch.empty_like(R)
         T.solve_multi(R, W)                                           # W = T R, all columns at once
+        t0 = tick("ilu_multi", t0)
         coef = gram(AX, W)                                            # A~-orthogonalise against X
         W = W - rotate(X, coef)
+        t0 = tick("ortho_X", t0)
         AW = mm(dA, W)
+        t0 = tick("spmm", t0)
         if not a_orthonormalise([W, AW], AW):
             break
+        t0 = tick("ortho_W", t0)
         CW = mm(dC, W)
+        t0 = tick("spmm", t0)
         blocks = ([X, W], [AX, AW], [CX, CW])
         if P is not None:
             if a_orthonormalise([P, AP, CP], AP):
                 blocks = ([X, W, P], [AX, AW, AP], [CX, CW, CP])
         out = rayleigh_ritz(*blocks, m)
         if out is None and P is not None:                             # ill-conditioned basis: drop P once
-            out = rayleigh_ritz([X, W], [AX, AW], [CX, CW], m)
+            blocks = ([X, W], [AX, AW], [CX, CW])
+            out = rayleigh_ritz(*blocks, m)
         if out is None:
             break
-        mu, Y, S, AS, CS = out
-        Yp = Y.clone()
-        Yp[:, :m, :] = 0.0                                            # P = [W P] * Y_{W,P}
-        P, AP, CP = rotate(S, Yp), rotate(AS, Yp), rotate(CS, Yp)
-        X, AX, CX = rotate(S, Y), rotate(AS, Y), rotate(CS, Y)
+        t0 = tick("rayleigh_ritz", t0)
+        mu, Ys = out
+        S, AS, CS = blocks
+        P, AP, CP = combine(S, Ys, True), combine(AS, Ys, True), combine(CS, Ys, True)      # P = [W P] Y_{W,P}
+        X, AX, CX = rotate(X, Ys[0]).add_(P), rotate(AX, Ys[0]).add_(AP), rotate(CX, Ys[0]).add_(CP)
+        t0 = tick("rotate", t0)
+    if verbose:
+        print("[geneo] phase seconds:", {k: round(v, 2) for k, v in prof.items()}, flush=True)
     lam = (1.0 / mu[:, :nev] - shift).cpu().numpy()                   # lambda = 1/mu - shift, ascending
     Xh = X[:, :nev].cpu().numpy()
     basis = {}
