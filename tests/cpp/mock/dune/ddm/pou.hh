@@ -1,0 +1,12 @@
+#pragma once
+// stand-in for the reference's dune/ddm/pou.hh: only the accessors (pou.hh:190-208)
+#include <cstddef>
+#include <vector>
+class PartitionOfUnity {
+public:
+  explicit PartitionOfUnity(std::vector<double> v) : v(std::move(v)) {}
+  std::size_t size() const { return v.size(); }
+  double operator[](std::size_t i) const { return v[i]; }
+private:
+  std::vector<double> v;
+};
