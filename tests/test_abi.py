@@ -1,0 +1,49 @@
+"""CPU checks of the C-ABI boundary: the library loads without a GPU, exports exactly the symbols declared in
+include/ddm_hip.h, fails loudly (no CPU fallback) when no HIP device is present, and the product never imports
+the oracle."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "ddm_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ddm_[a-z0-9_]+)\s*\(", txt)) - {"ddm_alltoall_fn", "ddm_allreduce_fn"})
+
+
+def test_library_exports_every_declared_symbol(ddm):
+    lib = ddm.load_library()
+    declared = _declared()
+    assert len(declared) >= 45
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/ddm_hip.h but not exported"
+        assert name in ddm.SYMBOLS, f"{name} has no ctypes prototype in the Python binding"
+    assert sorted(ddm.SYMBOLS) == declared
+
+
+def test_no_cpu_fallback_without_device(ddm):
+    import torch
+    if torch.cuda.is_available():
+        return
+    lib = ddm.load_library()
+    h = ctypes.c_void_p()
+    assert lib.ddm_ctx_create(0, None, ctypes.byref(h)) != 0 and not h.value
+    try:
+        ddm.Context(0)
+    except ddm.DdmError:
+        pass
+    else:
+        raise AssertionError("Context() must fail without a HIP device")
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "dune-ddm_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hh", ".hpp", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)
+                assert "liboracle" not in src
