@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -388,6 +389,11 @@ struct TriSchedule { // one triangular factor, level by level in sliced ELL
 
 struct ddm_ilu0 {
   int64_t n = 0, nnz = 0;
+  int mode = 1;                 // 1 = single launch with level counters (default), 2 = data-driven single launch, 0 = one launch per level
+  double *ywork = nullptr;      // forward-solve result of the data-driven kernel
+  unsigned *cnt = nullptr;      // per-level sharded arrival counters, zeroed before every solve; last word block = error flag
+  size_t cnt_bytes = 0;
+  unsigned *err = nullptr;
   std::vector<double> h_lu; // factor values in the pattern of A
   TriSchedule L, U;
   // HIP graph cache of the whole solve for one (d, x) pointer pair
@@ -531,6 +537,14 @@ extern "C" int ddm_ilu0_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, 
     }
   int rc = build_schedule(ctx, A, F->h_lu, diag, false, F->L);
   if (!rc) rc = build_schedule(ctx, A, F->h_lu, diag, true, F->U);
+  if (const char *m = std::getenv("DDM_TRSV_MODE")) F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "syncfree") ? 2 : 1);
+  if (!rc && hipMalloc((void **)&F->ywork, sizeof(double) * (size_t)std::max<int64_t>(F->n, 1)) != hipSuccess) rc = fail(ctx, DDM_EHIP, "ILU(0): allocation failed");
+  if (!rc) {
+    F->cnt_bytes = sizeof(unsigned) * (size_t)(F->L.nlev + F->U.nlev) * TRSV_P_SHARDS * TRSV_P_STRIDE;
+    if (hipMalloc((void **)&F->cnt, F->cnt_bytes + 128) != hipSuccess || hipMalloc((void **)&F->err, 128) != hipSuccess ||
+        hipMemset(F->err, 0, 128) != hipSuccess)
+      rc = fail(ctx, DDM_EHIP, "ILU(0): counter allocation failed");
+  }
   if (rc) {
     ddm_ilu0_destroy(F);
     return rc;
@@ -542,9 +556,20 @@ extern "C" void ddm_ilu0_destroy(ddm_ilu0 *F)
 {
   if (!F) return;
   if (F->graph) (void)hipGraphExecDestroy(F->graph);
+  (void)hipFree(F->cnt);
+  (void)hipFree(F->err);
+  (void)hipFree(F->ywork);
   free_schedule(F->L);
   free_schedule(F->U);
   delete F;
+}
+// 0 = ok, 1 = a wave of the persistent kernel gave up waiting (results invalid); synchronous
+extern "C" int ddm_ilu0_status(ddm_ctx *ctx, const ddm_ilu0 *F, int *status)
+{
+  unsigned e = 0;
+  DDMCHECK(ddm_memcpy_d2h(ctx, &e, F->err, sizeof(unsigned)));
+  *status = (int)e;
+  return DDM_OK;
 }
 extern "C" int64_t ddm_ilu0_num_levels(const ddm_ilu0 *F, int upper) { return upper ? F->U.nlev : F->L.nlev; }
 extern "C" int ddm_ilu0_get_factors_host(ddm_ctx *ctx, const ddm_ilu0 *F, double *lu_host)
@@ -581,6 +606,7 @@ static int enqueue_tri(ddm_ctx *ctx, const TriSchedule &S, bool upper, const dou
 
 extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x)
 {
+  if (F && F->n == 0) return DDM_OK;
   if (!F || !d || !x || d == x) return fail(ctx, DDM_EINVAL, "ddm_ilu0_solve: bad arguments (d and x must not alias)");
   if (F->graph && F->g_d == d && F->g_x == x) {
     HIPCHECK(ctx, hipGraphLaunch(F->graph, ctx->stream));
@@ -593,8 +619,21 @@ extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double
   }
   hipGraph_t g = nullptr;
   HIPCHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-  int rc = enqueue_tri(ctx, F->L, false, d, x);
-  if (!rc) rc = enqueue_tri(ctx, F->U, true, d, x);
+  int rc = DDM_OK;
+  if (F->mode == 2) {
+    // poison both result vectors (all-ones = "not computed yet"), then one data-driven launch
+    (void)hipMemsetAsync(F->ywork, 0xFF, sizeof(double) * (size_t)F->n, ctx->stream);
+    (void)hipMemsetAsync(x, 0xFF, sizeof(double) * (size_t)F->n, ctx->stream);
+    hipLaunchKernelGGL(k_trsv_syncfree, dim3(TRSV_P_GRID), dim3(64), 0, ctx->stream, (int)F->L.nlev, (int)F->U.nlev, F->L.d_desc, F->U.d_desc,
+                       F->L.rows, F->L.cols, F->L.vals, F->U.rows, F->U.cols, F->U.vals, F->U.dinv, d, F->ywork, x, F->err);
+  } else if (F->mode == 1) {
+    (void)hipMemsetAsync(F->cnt, 0, F->cnt_bytes, ctx->stream); // counters are re-initialised by every replay
+    hipLaunchKernelGGL(k_trsv_persistent, dim3(TRSV_P_GRID), dim3(64), 0, ctx->stream, (int)F->L.nlev, (int)F->U.nlev, F->L.d_desc, F->U.d_desc,
+                       F->L.rows, F->L.cols, F->L.vals, F->U.rows, F->U.cols, F->U.vals, F->U.dinv, d, x, F->cnt, F->err);
+  } else {
+    rc = enqueue_tri(ctx, F->L, false, d, x);
+    if (!rc) rc = enqueue_tri(ctx, F->U, true, d, x);
+  }
   hipError_t e = hipStreamEndCapture(ctx->stream, &g);
   if (rc) return rc;
   if (e != hipSuccess) return fail(ctx, DDM_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
@@ -1223,6 +1262,11 @@ extern "C" int ddm_cg_solve(ddm_ctx *ctx, ddm_op *op, ddm_combined *prec, double
   (void)hipStreamSynchronize(ctx->stream);
   res->elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   res->reduction = deff / def0;
+  if (!rc && prec->schwarz) {
+    int st = 0;
+    rc = ddm_ilu0_status(ctx, prec->schwarz->solver, &st);
+    if (!rc && st) rc = fail(ctx, DDM_ENUMERIC, "persistent triangular solve timed out waiting for a level (results invalid)");
+  }
   ddm_cg_end(ctx, S);
   return rc;
 }

@@ -226,6 +226,224 @@ __global__ __launch_bounds__(TRSV_SMALL_WG) void k_trsv_small_levels(int nlev, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// Persistent level-synchronous triangular solve: the whole x = (LU)^-1 d in ONE launch.
+// Grid = TRSV_P_GRID single-wave workgroups, all co-resident.  Chunk c (64 rows) of a level is
+// owned by wave c mod G; waves walk the levels in order.  Before touching a level a wave waits
+// until the previous level is complete, which it learns from per-level arrival counters
+// (TRSV_P_SHARDS shards on separate 128-B lines: arrivals spread over memory channels, one poll
+// instruction reads all shards, one per lane).  Hand-off protocol = cdna_hip_programming.md
+// Guideline 16, "row 1" form of MI355X_MICROARCH.md: every x value is stored write-through
+// (sc1), the storing wave drains its stores (s_waitcnt vmcnt(0)), ONE lane adds to the counter
+// (agent-scope atomic); consumers poll with sc1 loads and read x ONLY with sc1 loads (bypass the
+// non-coherent L1; no acquire fence needed).  Correct for any wave -> CU/XCD placement.
+// Factor entries / d are read-only in this launch and use plain loads; the entries of a wave's
+// next chunk are fetched BEFORE it starts waiting, so only the x gathers sit on the critical path.
+constexpr int TRSV_P_GRID = 256;
+constexpr int TRSV_P_SHARDS = 16;
+constexpr int TRSV_P_STRIDE = 32; // uint32 per shard = one 128-B line
+
+__device__ __forceinline__ double ld_sc1(const double *p)
+{
+  return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_sc1(double *p, double v)
+{
+  __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// returns false on timeout (err word set) -- every wave still runs to completion
+__device__ __forceinline__ bool trsv_wait_level(const unsigned *cnt_level, int nchunk_prev, int lane, unsigned *err)
+{
+  const unsigned expect = (unsigned)(nchunk_prev / TRSV_P_SHARDS) + (lane < nchunk_prev % TRSV_P_SHARDS ? 1u : 0u);
+  const bool need = lane < TRSV_P_SHARDS;
+  for (unsigned spins = 0;; ++spins) {
+    const unsigned v = need ? __hip_atomic_load(cnt_level + lane * TRSV_P_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : expect;
+    if (__all(v == expect)) break;
+    if (spins > (1u << 21)) {
+      if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // compiler-only: keep the x loads below the poll
+  return true;
+}
+
+__global__ __launch_bounds__(64) void k_trsv_persistent(int nlevL, int nlevU, const LevelDesc *__restrict__ descL,
+                                                         const LevelDesc *__restrict__ descU, const int32_t *__restrict__ rowsL,
+                                                         const int32_t *__restrict__ colsL, const double *__restrict__ valsL,
+                                                         const int32_t *__restrict__ rowsU, const int32_t *__restrict__ colsU,
+                                                         const double *__restrict__ valsU, const double *__restrict__ dinv,
+                                                         const double *__restrict__ d, double *x, unsigned *cnt, unsigned *err)
+{
+  const int g = blockIdx.x, G = gridDim.x, lane = threadIdx.x;
+  const int nlev = nlevL + nlevU;
+  int nchunk_prev = 0;
+  for (int lev = 0; lev < nlev; ++lev) {
+    const bool upper = lev >= nlevL;
+    const LevelDesc D = upper ? descU[lev - nlevL] : descL[lev];
+    const int nchunk = (D.m + 63) >> 6;
+    if (g >= nchunk) {
+      nchunk_prev = nchunk;
+      continue; // no work for this wave in this level: no waiting either
+    }
+    const int32_t *rows = (upper ? rowsU : rowsL) + D.row_off;
+    const int32_t *cols = (upper ? colsU : colsL) + D.ent_off;
+    const double *vals = (upper ? valsU : valsL) + D.ent_off;
+    int mine = 0;
+    bool waited = lev == 0;
+    for (int c = g; c < nchunk; c += G, ++mine) {
+      const int r = (c << 6) + lane;
+      const bool act = r < D.m;
+      const int rr = act ? r : D.m - 1; // idle lanes of the last chunk shadow the last row (no store): uniform control flow
+      // ---- independent of x: fetch the row id, the right-hand side and the first tile of entries
+      const int row = rows[rr];
+      int32_t cc[TRSV_UNROLL];
+      double vv[TRSV_UNROLL], xv[TRSV_UNROLL];
+#pragma unroll
+      for (int u = 0; u < TRSV_UNROLL; ++u) {
+        cc[u] = 0;
+        vv[u] = 0.0;
+        if (u < D.w) { // wave-uniform
+          cc[u] = cols[(int64_t)u * D.m + rr];
+          vv[u] = vals[(int64_t)u * D.m + rr];
+        }
+      }
+      double s = upper ? 0.0 : d[row];
+      const double di = upper ? dinv[D.row_off + rr] : 0.0;
+      // ---- now the dependencies: the previous level must be complete
+      if (!waited) {
+        trsv_wait_level(cnt + (int64_t)(lev - 1) * TRSV_P_SHARDS * TRSV_P_STRIDE, nchunk_prev, lane, err);
+        waited = true;
+      }
+#pragma unroll
+      for (int u = 0; u < TRSV_UNROLL; ++u) {
+        xv[u] = 0.0;
+        if (u < D.w) xv[u] = ld_sc1(x + cc[u]);
+      }
+      if (upper) s = ld_sc1(x + row);
+#pragma unroll
+      for (int u = 0; u < TRSV_UNROLL; ++u) s -= vv[u] * xv[u];
+      for (int k0 = TRSV_UNROLL; k0 < D.w; k0 += TRSV_UNROLL) { // rows wider than one tile (rare)
+#pragma unroll
+        for (int u = 0; u < TRSV_UNROLL; ++u) {
+          cc[u] = 0;
+          vv[u] = 0.0;
+          xv[u] = 0.0;
+          if (k0 + u < D.w) {
+            cc[u] = cols[(int64_t)(k0 + u) * D.m + rr];
+            vv[u] = vals[(int64_t)(k0 + u) * D.m + rr];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < TRSV_UNROLL; ++u)
+          if (k0 + u < D.w) xv[u] = ld_sc1(x + cc[u]);
+#pragma unroll
+        for (int u = 0; u < TRSV_UNROLL; ++u) s -= vv[u] * xv[u];
+      }
+      if (act) st_sc1(x + row, upper ? s * di : s);
+    }
+    // ---- publish: drain this wave's write-through stores, then ONE lane signals for the wave
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0)
+      __hip_atomic_fetch_add(cnt + ((int64_t)lev * TRSV_P_SHARDS + (g % TRSV_P_SHARDS)) * TRSV_P_STRIDE, (unsigned)mine, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+    nchunk_prev = nchunk;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Data-driven ("sync-free") variant of the persistent solve: no counters and no level barrier.
+// y (forward result) and x (final result) are pre-filled with an all-ones NaN pattern before
+// every solve (memset nodes in the graph); a row polls ITS OWN dependencies with sc1 loads until
+// none of them is the sentinel, computes, and publishes its value with ONE aligned 8-byte sc1
+// store -- the datum is its own flag (Guideline 16, R2: a granule written by one store is never
+// torn).  A hop on the critical path is then a single write-through store -> sc1 load, instead of
+// store + drain + counter add + counter poll + gather.  Waves own the 64-row chunks of the
+// level-sorted row list round-robin and walk them in level order, so every dependency is owned by
+// a chunk that its wave reaches without waiting on a later level: no deadlock while all
+// TRSV_P_GRID waves are resident.  A computed NaN is the canonical quiet NaN, never all-ones.
+constexpr unsigned long long TRSV_SENTINEL = ~0ull;
+
+__device__ __forceinline__ unsigned long long ld_sc1_bits(const double *p)
+{
+  return __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(64) void k_trsv_syncfree(int nlevL, int nlevU, const LevelDesc *__restrict__ descL,
+                                                       const LevelDesc *__restrict__ descU, const int32_t *__restrict__ rowsL,
+                                                       const int32_t *__restrict__ colsL, const double *__restrict__ valsL,
+                                                       const int32_t *__restrict__ rowsU, const int32_t *__restrict__ colsU,
+                                                       const double *__restrict__ valsU, const double *__restrict__ dinv,
+                                                       const double *__restrict__ d, double *y, double *x, unsigned *err)
+{
+  const int g = blockIdx.x, G = gridDim.x, lane = threadIdx.x;
+  const int nlev = nlevL + nlevU;
+  for (int lev = 0; lev < nlev; ++lev) {
+    const bool upper = lev >= nlevL;
+    const LevelDesc D = upper ? descU[lev - nlevL] : descL[lev];
+    const int nchunk = (D.m + 63) >> 6;
+    if (g >= nchunk) continue;
+    const int32_t *rows = (upper ? rowsU : rowsL) + D.row_off;
+    const int32_t *cols = (upper ? colsU : colsL) + D.ent_off;
+    const double *vals = (upper ? valsU : valsL) + D.ent_off;
+    const double *src = upper ? x : y; // where this phase's dependencies are published
+    double *dst = upper ? x : y;
+    for (int c = g; c < nchunk; c += G) {
+      const int r = (c << 6) + lane;
+      const bool act = r < D.m;
+      const int rr = act ? r : D.m - 1;
+      const int row = rows[rr];
+      double s = upper ? 0.0 : d[row];
+      const double di = upper ? dinv[D.row_off + rr] : 0.0;
+      bool have_own = !upper;
+      for (int k0 = 0; k0 < D.w || !have_own; k0 += TRSV_UNROLL) {
+        int32_t cc[TRSV_UNROLL];
+        double vv[TRSV_UNROLL];
+        unsigned long long xb[TRSV_UNROLL];
+#pragma unroll
+        for (int u = 0; u < TRSV_UNROLL; ++u) {
+          cc[u] = 0;
+          vv[u] = 0.0;
+          xb[u] = 0ull;
+          if (k0 + u < D.w) { // wave-uniform
+            cc[u] = cols[(int64_t)(k0 + u) * D.m + rr];
+            vv[u] = vals[(int64_t)(k0 + u) * D.m + rr];
+          }
+        }
+        unsigned long long own = 0ull;
+        for (unsigned spins = 0;; ++spins) {
+          bool ok = true;
+#pragma unroll
+          for (int u = 0; u < TRSV_UNROLL; ++u)
+            if (k0 + u < D.w) {
+              xb[u] = ld_sc1_bits(src + cc[u]);
+              ok &= xb[u] != TRSV_SENTINEL;
+            }
+          if (!have_own) {
+            own = ld_sc1_bits(y + row); // forward result of this row
+            ok &= own != TRSV_SENTINEL;
+          }
+          if (__all(ok)) break;
+          if (spins > (1u << 20)) {
+            if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (!have_own) {
+          s = __longlong_as_double((long long)own);
+          have_own = true;
+        }
+#pragma unroll
+        for (int u = 0; u < TRSV_UNROLL; ++u) s -= vv[u] * __longlong_as_double((long long)xb[u]);
+      }
+      if (act) st_sc1(dst + row, upper ? s * di : s);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K2 extend (schwarz.hh:121-122), K5 restrict (schwarz.hh:146), K4 POU scaling (schwarz.hh:141)
 __global__ void k_extend(int64_t n, const int32_t *__restrict__ ext_map, const double *__restrict__ d, double *__restrict__ dov)
 {

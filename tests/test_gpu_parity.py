@@ -64,7 +64,10 @@ def test_csr_mv_usmv_random_and_edge_cases(ddm, torch_cuda):
     ctx.close()
 
 
-def test_ilu0_factor_and_solve(ddm, torch_cuda):
+@pytest.mark.parametrize("trsv_mode", ["syncfree", "persistent", "levels"])
+def test_ilu0_factor_and_solve(ddm, torch_cuda, trsv_mode, monkeypatch):
+    """all triangular-solve engines: data-driven single launch (default), single launch with level counters, one launch per level"""
+    monkeypatch.setenv("DDM_TRSV_MODE", trsv_mode)
     from dune_ddm_amd import synth
     from oracle import apply_oracle as ao
     torch = torch_cuda
@@ -79,9 +82,11 @@ def test_ilu0_factor_and_solve(ddm, torch_cuda):
     d = rng.standard_normal(M.shape[0])
     xd = torch.zeros(M.shape[0], dtype=torch.float64, device="cuda")
     dd = _dev(torch, d)
-    for _ in range(2):                                     # second call replays the captured graph
+    for _ in range(3):                                     # later calls replay the captured graph (counters re-zeroed)
+        xd.fill_(float("nan"))
         F.solve(dd, xd)
     ctx.sync()
+    assert F.status() == 0
     xo = np.zeros(M.shape[0])
     ref.apply(xo, d)
     assert _relerr(xd.cpu().numpy(), xo) < RTOL_VEC
