@@ -389,8 +389,20 @@ struct TriSchedule { // one triangular factor, level by level in sliced ELL
 
 struct ddm_ilu0 {
   int64_t n = 0, nnz = 0;
-  int mode = 1;                 // 1 = single launch with level counters (default), 2 = data-driven single launch, 0 = one launch per level
+  int mode = 3;                 // 3 = XCD-local single launch (default), 1 = single launch + level counters, 2 = data-driven, 0 = launch per level
   double *ywork = nullptr;      // forward-solve result of the data-driven kernel
+  // XCD-local engine (mode 3): per-block (subdomain) level schedules, built on first use
+  std::vector<int64_t> h_diag, h_block_ptr;
+  const ddm_csr *A = nullptr;
+  bool xcd_built = false;
+  int ngroups = 0;
+  GroupDesc *xg = nullptr;
+  LevelDesc *xdesc = nullptr;
+  int64_t *xflag_off = nullptr;
+  int32_t *xrows = nullptr, *xcols = nullptr;
+  double *xvals = nullptr, *xdinv = nullptr;
+  unsigned *xflags = nullptr;
+  XcdState *xstate = nullptr;
   unsigned *cnt = nullptr;      // per-level sharded arrival counters, zeroed before every solve; last word block = error flag
   size_t cnt_bytes = 0;
   unsigned *err = nullptr;
@@ -537,7 +549,10 @@ extern "C" int ddm_ilu0_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, 
     }
   int rc = build_schedule(ctx, A, F->h_lu, diag, false, F->L);
   if (!rc) rc = build_schedule(ctx, A, F->h_lu, diag, true, F->U);
-  if (const char *m = std::getenv("DDM_TRSV_MODE")) F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "syncfree") ? 2 : 1);
+  if (const char *m = std::getenv("DDM_TRSV_MODE")) F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "syncfree") ? 2 : (!std::strcmp(m, "persistent") ? 1 : 3));
+  F->A = A;
+  F->h_diag = diag;
+  F->h_block_ptr.assign(block_ptr, block_ptr + nblocks + 1);
   if (!rc && hipMalloc((void **)&F->ywork, sizeof(double) * (size_t)std::max<int64_t>(F->n, 1)) != hipSuccess) rc = fail(ctx, DDM_EHIP, "ILU(0): allocation failed");
   if (!rc) {
     F->cnt_bytes = sizeof(unsigned) * (size_t)(F->L.nlev + F->U.nlev) * TRSV_P_SHARDS * TRSV_P_STRIDE;
@@ -559,6 +574,15 @@ extern "C" void ddm_ilu0_destroy(ddm_ilu0 *F)
   (void)hipFree(F->cnt);
   (void)hipFree(F->err);
   (void)hipFree(F->ywork);
+  (void)hipFree(F->xg);
+  (void)hipFree(F->xdesc);
+  (void)hipFree(F->xflag_off);
+  (void)hipFree(F->xrows);
+  (void)hipFree(F->xcols);
+  (void)hipFree(F->xvals);
+  (void)hipFree(F->xdinv);
+  (void)hipFree(F->xflags);
+  (void)hipFree(F->xstate);
   free_schedule(F->L);
   free_schedule(F->U);
   delete F;
@@ -576,6 +600,105 @@ extern "C" int ddm_ilu0_get_factors_host(ddm_ctx *ctx, const ddm_ilu0 *F, double
 {
   if (!F || !lu_host) return fail(ctx, DDM_EINVAL, "bad arguments");
   std::memcpy(lu_host, F->h_lu.data(), sizeof(double) * (size_t)F->nnz);
+  return DDM_OK;
+}
+
+// Per-block level schedules of the XCD-local engine: for every diagonal block its L levels then its U
+// levels, rows level-sorted, entries in sliced ELL; everything concatenated into one set of arrays.
+static int build_xcd_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
+{
+  const ddm_csr *A = F->A;
+  const int64_t *rp = A->h_rp.data();
+  const int32_t *ci = A->h_ci.data();
+  const std::vector<double> &lu = F->h_lu;
+  const std::vector<int64_t> &diag = F->h_diag;
+  const int nb = (int)F->h_block_ptr.size() - 1;
+  std::vector<GroupDesc> groups(nb);
+  std::vector<LevelDesc> desc;
+  std::vector<int64_t> flag_off(nb);
+  std::vector<int32_t> rows, cols;
+  std::vector<double> vals, dinv;
+  rows.reserve(2 * (size_t)A->nrows);
+  dinv.reserve(2 * (size_t)A->nrows);
+  cols.reserve((size_t)A->nnz);
+  vals.reserve((size_t)A->nnz);
+  std::vector<int32_t> level(A->nrows);
+  int64_t nflag = 0;
+  for (int b = 0; b < nb; ++b) {
+    const int64_t r0 = F->h_block_ptr[b], r1 = F->h_block_ptr[b + 1];
+    groups[b].lev_off = (int64_t)desc.size();
+    flag_off[b] = nflag;
+    for (int pass = 0; pass < 2; ++pass) {
+      const bool upper = pass == 1;
+      int32_t maxlev = -1;
+      if (!upper)
+        for (int64_t i = r0; i < r1; ++i) {
+          int32_t l = 0;
+          for (int64_t k = rp[i]; k < diag[i]; ++k) l = std::max(l, level[ci[k]] + 1);
+          level[i] = l;
+          maxlev = std::max(maxlev, l);
+        }
+      else
+        for (int64_t i = r1 - 1; i >= r0; --i) {
+          int32_t l = 0;
+          for (int64_t k = diag[i] + 1; k < rp[i + 1]; ++k) l = std::max(l, level[ci[k]] + 1);
+          level[i] = l;
+          maxlev = std::max(maxlev, l);
+        }
+      const int64_t nlev = (int64_t)maxlev + 1;
+      (upper ? groups[b].nlevU : groups[b].nlevL) = (int32_t)nlev;
+      std::vector<int64_t> lptr(nlev + 1, 0);
+      for (int64_t i = r0; i < r1; ++i) lptr[level[i] + 1]++;
+      for (int64_t l = 0; l < nlev; ++l) lptr[l + 1] += lptr[l];
+      const int64_t base = (int64_t)rows.size();
+      rows.resize(base + (r1 - r0));
+      dinv.resize(base + (r1 - r0), 0.0);
+      {
+        std::vector<int64_t> pos(lptr.begin(), lptr.end() - 1);
+        for (int64_t i = r0; i < r1; ++i) rows[base + pos[level[i]]++] = (int32_t)i;
+      }
+      for (int64_t l = 0; l < nlev; ++l) {
+        const int64_t m = lptr[l + 1] - lptr[l];
+        int w = 0;
+        for (int64_t r = 0; r < m; ++r) {
+          const int64_t i = rows[base + lptr[l] + r];
+          w = std::max(w, upper ? (int)(rp[i + 1] - diag[i] - 1) : (int)(diag[i] - rp[i]));
+        }
+        const int64_t ent = (int64_t)cols.size();
+        desc.push_back(LevelDesc{(int32_t)m, (int32_t)w, base + lptr[l], ent});
+        cols.resize(ent + m * (int64_t)w);
+        vals.resize(ent + m * (int64_t)w);
+        for (int64_t r = 0; r < m; ++r) {
+          const int64_t i = rows[base + lptr[l] + r];
+          const int64_t k0 = upper ? diag[i] + 1 : rp[i], k1 = upper ? rp[i + 1] : diag[i];
+          int k = 0;
+          for (int64_t p = k0; p < k1; ++p, ++k) {
+            cols[ent + (int64_t)k * m + r] = ci[p];
+            vals[ent + (int64_t)k * m + r] = lu[p];
+          }
+          for (; k < w; ++k) {
+            cols[ent + (int64_t)k * m + r] = ci[k0];
+            vals[ent + (int64_t)k * m + r] = 0.0;
+          }
+          if (upper) dinv[base + lptr[l] + r] = lu[diag[i]];
+        }
+      }
+    }
+    nflag += (int64_t)(groups[b].nlevL + groups[b].nlevU) * TRSV_X_MAXW;
+  }
+  F->ngroups = nb;
+  DDMCHECK(upload(ctx, groups.data(), (int64_t)groups.size(), &F->xg));
+  DDMCHECK(upload(ctx, desc.data(), (int64_t)desc.size(), &F->xdesc));
+  DDMCHECK(upload(ctx, flag_off.data(), (int64_t)flag_off.size(), &F->xflag_off));
+  DDMCHECK(upload(ctx, rows.data(), (int64_t)rows.size(), &F->xrows));
+  DDMCHECK(upload(ctx, cols.data(), (int64_t)cols.size(), &F->xcols));
+  DDMCHECK(upload(ctx, vals.data(), (int64_t)vals.size(), &F->xvals));
+  DDMCHECK(upload(ctx, dinv.data(), (int64_t)dinv.size(), &F->xdinv));
+  HIPCHECK(ctx, hipMalloc((void **)&F->xflags, sizeof(unsigned) * (size_t)std::max<int64_t>(nflag, 1)));
+  HIPCHECK(ctx, hipMemset(F->xflags, 0, sizeof(unsigned) * (size_t)std::max<int64_t>(nflag, 1)));
+  HIPCHECK(ctx, hipMalloc((void **)&F->xstate, sizeof(XcdState)));
+  HIPCHECK(ctx, hipMemset(F->xstate, 0, sizeof(XcdState)));
+  F->xcd_built = true;
   return DDM_OK;
 }
 
@@ -617,10 +740,15 @@ extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double
     (void)hipGraphExecDestroy(F->graph);
     F->graph = nullptr;
   }
+  if (F->mode == 3 && !F->xcd_built) DDMCHECK(build_xcd_schedule(ctx, F));
   hipGraph_t g = nullptr;
   HIPCHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
   int rc = DDM_OK;
-  if (F->mode == 2) {
+  if (F->mode == 3) {
+    hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
+    hipLaunchKernelGGL(k_trsv_xcd, dim3(TRSV_P_GRID), dim3(64), 0, ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off, F->xrows, F->xcols,
+                       F->xvals, F->xdinv, d, x, F->xflags, F->xstate, F->err);
+  } else if (F->mode == 2) {
     // poison both result vectors (all-ones = "not computed yet"), then one data-driven launch
     (void)hipMemsetAsync(F->ywork, 0xFF, sizeof(double) * (size_t)F->n, ctx->stream);
     (void)hipMemsetAsync(x, 0xFF, sizeof(double) * (size_t)F->n, ctx->stream);

@@ -444,6 +444,207 @@ __global__ __launch_bounds__(64) void k_trsv_syncfree(int nlevL, int nlevU, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// XCD-local persistent solve (default engine).  Measured on MI355X (tools/xcd_handoff_bench.hip):
+// a level hand-off between 32 waves costs 0.9 us when producers and consumers share one XCD
+// (plain stores stay in that XCD's L2, consumers read them with sc1 loads that bypass only L1)
+// against 2.0 us across XCDs (write-through) and 7-9 us for a kernel boundary or a counter barrier.
+// Each independent diagonal block (= subdomain) is therefore solved by the waves of ONE XCD:
+//   * every wave reads its XCD from HW_REG_XCC_ID and draws a ticket on that XCD; after a grid
+//     barrier it knows W = #waves on its XCD and works only on the groups owned by its XCD
+//     (group % 8 == xcc).  Same-XCD membership holds by construction, not by dispatch-order
+//     assumption; if some XCD that owns a group received no wave, all waves take the placement-
+//     independent path instead (first 64 waves, write-through stores).
+//   * chunk c (64 rows) of a level belongs to wave c mod W; a wave that finished its chunks of a
+//     level drains its stores and sets its own flag word flag[group][level][rank] = epoch;
+//     a waiter reads all W flags of the previous level with ONE sc1 load instruction.
+//   * epoch comes from a device word bumped by k_trsv_xcd_prologue, so flags never need zeroing.
+constexpr int TRSV_X_MAXW = 64;
+struct GroupDesc {
+  int32_t nlevL, nlevU;
+  int64_t lev_off; // first LevelDesc of the group (L levels, then U levels)
+};
+struct XcdState {
+  unsigned tickets[8];
+  unsigned global_ticket, arrived, epoch, pad;
+};
+__global__ void k_trsv_xcd_prologue(XcdState *st)
+{
+  if (threadIdx.x < 8) st->tickets[threadIdx.x] = 0;
+  if (threadIdx.x == 0) {
+    st->global_ticket = 0;
+    st->arrived = 0;
+    st->epoch += 1;
+  }
+}
+__device__ __forceinline__ unsigned hw_xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u; } // HW_REG_XCC_ID[3:0]
+
+// register tile = everything a chunk needs that does NOT depend on x (row id, rhs / inverse pivot,
+// the first TRSV_UNROLL factor entries of each of its 64 rows)
+struct TrsvTile {
+  int32_t row, rr, act;
+  int32_t cc[TRSV_UNROLL];
+  double vv[TRSV_UNROLL];
+  double s0, di;
+};
+__device__ __forceinline__ void trsv_load_tile(TrsvTile &T, const LevelDesc &D, bool upper, int c, int lane,
+                                               const int32_t *__restrict__ rowsA, const int32_t *__restrict__ colsA,
+                                               const double *__restrict__ valsA, const double *__restrict__ dinvA,
+                                               const double *__restrict__ d)
+{
+  const int r = (c << 6) + lane;
+  T.act = r < D.m;
+  T.rr = T.act ? r : D.m - 1; // idle lanes of the last chunk shadow the last row (no store)
+  T.row = rowsA[D.row_off + T.rr];
+  const int32_t *cols = colsA + D.ent_off;
+  const double *vals = valsA + D.ent_off;
+#pragma unroll
+  for (int u = 0; u < TRSV_UNROLL; ++u) {
+    T.cc[u] = 0;
+    T.vv[u] = 0.0;
+    if (u < D.w) { // wave-uniform
+      T.cc[u] = cols[(int64_t)u * D.m + T.rr];
+      T.vv[u] = vals[(int64_t)u * D.m + T.rr];
+    }
+  }
+  T.s0 = upper ? 0.0 : d[T.row];
+  T.di = upper ? dinvA[D.row_off + T.rr] : 0.0;
+}
+__device__ __forceinline__ void trsv_finish_tile(const TrsvTile &T, const LevelDesc &D, bool upper, bool wt,
+                                                 const int32_t *__restrict__ colsA, const double *__restrict__ valsA, double *x)
+{
+  double xv[TRSV_UNROLL];
+#pragma unroll
+  for (int u = 0; u < TRSV_UNROLL; ++u) {
+    xv[u] = 0.0;
+    if (u < D.w) xv[u] = ld_sc1(x + T.cc[u]);
+  }
+  double s = T.s0;
+  if (upper) s = ld_sc1(x + T.row);
+#pragma unroll
+  for (int u = 0; u < TRSV_UNROLL; ++u) s -= T.vv[u] * xv[u];
+  const int32_t *cols = colsA + D.ent_off;
+  const double *vals = valsA + D.ent_off;
+  for (int k0 = TRSV_UNROLL; k0 < D.w; k0 += TRSV_UNROLL) { // rows wider than one tile (rare)
+    int32_t cc[TRSV_UNROLL];
+    double vv[TRSV_UNROLL];
+#pragma unroll
+    for (int u = 0; u < TRSV_UNROLL; ++u) {
+      cc[u] = 0;
+      vv[u] = 0.0;
+      xv[u] = 0.0;
+      if (k0 + u < D.w) {
+        cc[u] = cols[(int64_t)(k0 + u) * D.m + T.rr];
+        vv[u] = vals[(int64_t)(k0 + u) * D.m + T.rr];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TRSV_UNROLL; ++u)
+      if (k0 + u < D.w) xv[u] = ld_sc1(x + cc[u]);
+#pragma unroll
+    for (int u = 0; u < TRSV_UNROLL; ++u) s -= vv[u] * xv[u];
+  }
+  const double out = upper ? s * T.di : s;
+  if (T.act) {
+    if (wt) st_sc1(x + T.row, out); // placement-independent path: write through
+    else x[T.row] = out;            // same-XCD path: the line stays in this XCD's L2
+  }
+}
+
+// One diagonal block, solved by the W waves of one XCD.  The tile of a level is requested before the
+// wave polls the previous level's flags.  (Requesting it a level earlier does not help a single wave:
+// vmcnt retires in order, so the flag poll would wait for the younger HBM loads as well -- measured
+// 16.4 ms vs 11.2 ms per solve at 216^3.)
+__device__ __forceinline__ void trsv_xcd_group(const GroupDesc Gd, const LevelDesc *__restrict__ descA, const int32_t *__restrict__ rowsA,
+                                                const int32_t *__restrict__ colsA, const double *__restrict__ valsA,
+                                                const double *__restrict__ dinvA, const double *__restrict__ d, double *x, unsigned *flags,
+                                                unsigned epoch, int rank, int W, bool wt, int lane, unsigned *err)
+{
+  const int nlev = Gd.nlevL + Gd.nlevU;
+  const LevelDesc *desc = descA + Gd.lev_off;
+  int nchunk_prev = 0;
+  for (int lev = 0; lev < nlev; ++lev) {
+    const bool upper = lev >= Gd.nlevL;
+    const LevelDesc D = desc[lev];
+    const int nchunk = (D.m + 63) >> 6;
+    if (rank >= nchunk) {
+      nchunk_prev = nchunk;
+      continue;
+    }
+    TrsvTile cur;
+    trsv_load_tile(cur, D, upper, rank, lane, rowsA, colsA, valsA, dinvA, d);
+    if (lev > 0) { // previous level complete <=> the flags of all waves that owned a chunk of it carry this epoch
+      const unsigned *fp = flags + (int64_t)(lev - 1) * TRSV_X_MAXW;
+      const int nact = nchunk_prev < W ? nchunk_prev : W;
+      for (unsigned spins = 0;; ++spins) {
+        const unsigned v = lane < nact ? __hip_atomic_load(fp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+        if (__all(v == epoch)) break;
+        if (spins > (1u << 22)) {
+          if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    trsv_finish_tile(cur, D, upper, wt, colsA, valsA, x);
+    for (int c = rank + W; c < nchunk; c += W) { // further chunks of the same level (levels wider than 64 W rows)
+      TrsvTile t2;
+      trsv_load_tile(t2, D, upper, c, lane, rowsA, colsA, valsA, dinvA, d);
+      trsv_finish_tile(t2, D, upper, wt, colsA, valsA, x);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's x stores have reached L2 (or memory)
+    if (lane == 0) {
+      unsigned *f = flags + (int64_t)lev * TRSV_X_MAXW + rank;
+      if (wt) __hip_atomic_store(f, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else *(volatile unsigned *)f = epoch;
+    }
+    nchunk_prev = nchunk;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_trsv_xcd(int ngroups, const GroupDesc *__restrict__ groups, const LevelDesc *__restrict__ desc,
+                                                  const int64_t *__restrict__ flag_off, const int32_t *__restrict__ rows,
+                                                  const int32_t *__restrict__ cols, const double *__restrict__ vals,
+                                                  const double *__restrict__ dinv, const double *__restrict__ d, double *x, unsigned *flags,
+                                                  XcdState *st, unsigned *err)
+{
+  const int lane = threadIdx.x;
+  unsigned xcc = 0, t = 0, gt = 0;
+  if (lane == 0) {
+    xcc = hw_xcc_id();
+    t = __hip_atomic_fetch_add(&st->tickets[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    gt = __hip_atomic_fetch_add(&st->global_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&st->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  xcc = __builtin_amdgcn_readfirstlane(xcc);
+  t = __builtin_amdgcn_readfirstlane(t);
+  gt = __builtin_amdgcn_readfirstlane(gt);
+  // grid barrier (all workgroups are co-resident: gridDim.x <= #CUs single-wave workgroups)
+  for (unsigned spins = 0; __hip_atomic_load(&st->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x; ++spins) {
+    if (spins > (1u << 22)) {
+      if (lane == 0) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  const unsigned epoch = __hip_atomic_load(&st->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned tk = lane < 8 ? __hip_atomic_load(&st->tickets[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+  const int owners = ngroups < 8 ? ngroups : 8;                 // XCDs 0..owners-1 own at least one group
+  const bool local_ok = __all(lane >= owners || tk > 0u);       // every owning XCD has at least one wave
+  if (local_ok) {
+    int W = (int)__shfl((int)tk, (int)xcc, 64);
+    if (W > TRSV_X_MAXW) W = TRSV_X_MAXW;
+    if ((int)t >= W) return;
+    for (int grp = (int)xcc; grp < ngroups; grp += 8)
+      trsv_xcd_group(groups[grp], desc, rows, cols, vals, dinv, d, x, flags + flag_off[grp], epoch, (int)t, W, false, lane, err);
+  } else { // placement-independent path
+    int W = (int)gridDim.x < TRSV_X_MAXW ? (int)gridDim.x : TRSV_X_MAXW;
+    if ((int)gt >= W) return;
+    for (int grp = 0; grp < ngroups; ++grp)
+      trsv_xcd_group(groups[grp], desc, rows, cols, vals, dinv, d, x, flags + flag_off[grp], epoch, (int)gt, W, true, lane, err);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K2 extend (schwarz.hh:121-122), K5 restrict (schwarz.hh:146), K4 POU scaling (schwarz.hh:141)
 __global__ void k_extend(int64_t n, const int32_t *__restrict__ ext_map, const double *__restrict__ d, double *__restrict__ dov)
 {
