@@ -64,6 +64,7 @@ SYMBOLS = {
     "ddm_ilu0_create": (_I32, [_P, _P, _I64, _P, _PP]),
     "ddm_ilu0_destroy": (None, [_P]),
     "ddm_ilu0_solve": (_I32, [_P, _P, _P, _P]),
+    "ddm_ilu0_debug_stamps": (_I32, [_P, _P, _P, _P, _P]),
     "ddm_ilu0_status": (_I32, [_P, _P, ctypes.POINTER(ctypes.c_int)]),
     "ddm_ilu0_num_levels": (_I64, [_P, _I32]),
     "ddm_ilu0_get_factors_host": (_I32, [_P, _P, _P]),
@@ -246,6 +247,11 @@ class Ilu0:
 
     def num_levels(self, upper=False):
         return int(self.ctx.lib.ddm_ilu0_num_levels(self.h, int(upper)))
+
+    def debug_stamps(self, d, x):
+        out = np.zeros(6, dtype=np.uint64)
+        self.ctx.check(self.ctx.lib.ddm_ilu0_debug_stamps(self.ctx.h, self.h, _ptr(d), _ptr(x), _hp(out)))
+        return out
 
     def status(self):
         st = ctypes.c_int()

@@ -389,7 +389,7 @@ struct TriSchedule { // one triangular factor, level by level in sliced ELL
 
 struct ddm_ilu0 {
   int64_t n = 0, nnz = 0;
-  int mode = 3;                 // 3 = XCD-local single launch (default), 1 = single launch + level counters, 2 = data-driven, 0 = launch per level
+  int mode = 4;                 // 4 = XCD-local + loader wave (default), 3 = XCD-local single wave, 1 = single launch + level counters, 2 = data-driven, 0 = launch per level
   double *ywork = nullptr;      // forward-solve result of the data-driven kernel
   // XCD-local engine (mode 3): per-block (subdomain) level schedules, built on first use
   std::vector<int64_t> h_diag, h_block_ptr;
@@ -403,6 +403,8 @@ struct ddm_ilu0 {
   double *xvals = nullptr, *xdinv = nullptr;
   unsigned *xflags = nullptr;
   XcdState *xstate = nullptr;
+  double *xdperm = nullptr;     // right-hand side permuted into level order (loader engine)
+  int64_t xnrows = 0;
   unsigned *cnt = nullptr;      // per-level sharded arrival counters, zeroed before every solve; last word block = error flag
   size_t cnt_bytes = 0;
   unsigned *err = nullptr;
@@ -549,7 +551,7 @@ extern "C" int ddm_ilu0_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, 
     }
   int rc = build_schedule(ctx, A, F->h_lu, diag, false, F->L);
   if (!rc) rc = build_schedule(ctx, A, F->h_lu, diag, true, F->U);
-  if (const char *m = std::getenv("DDM_TRSV_MODE")) F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "syncfree") ? 2 : (!std::strcmp(m, "persistent") ? 1 : 3));
+  if (const char *m = std::getenv("DDM_TRSV_MODE")) F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "syncfree") ? 2 : (!std::strcmp(m, "persistent") ? 1 : (!std::strcmp(m, "xcd") ? 3 : 4)));
   F->A = A;
   F->h_diag = diag;
   F->h_block_ptr.assign(block_ptr, block_ptr + nblocks + 1);
@@ -583,6 +585,7 @@ extern "C" void ddm_ilu0_destroy(ddm_ilu0 *F)
   (void)hipFree(F->xdinv);
   (void)hipFree(F->xflags);
   (void)hipFree(F->xstate);
+  (void)hipFree(F->xdperm);
   free_schedule(F->L);
   free_schedule(F->U);
   delete F;
@@ -698,6 +701,9 @@ static int build_xcd_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
   HIPCHECK(ctx, hipMemset(F->xflags, 0, sizeof(unsigned) * (size_t)std::max<int64_t>(nflag, 1)));
   HIPCHECK(ctx, hipMalloc((void **)&F->xstate, sizeof(XcdState)));
   HIPCHECK(ctx, hipMemset(F->xstate, 0, sizeof(XcdState)));
+  F->xnrows = (int64_t)rows.size();
+  HIPCHECK(ctx, hipMalloc((void **)&F->xdperm, sizeof(double) * (size_t)std::max<int64_t>(F->xnrows, 1)));
+  HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_xcd2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TrsvLds)));
   F->xcd_built = true;
   return DDM_OK;
 }
@@ -727,6 +733,24 @@ static int enqueue_tri(ddm_ctx *ctx, const TriSchedule &S, bool upper, const dou
   return DDM_OK;
 }
 
+// Diagnostic (not part of the product path): one solve with the loader engine and in-kernel cycle stamps of one
+// compute wave.  out[0..5] = cycles waiting for the LDS tile, for the level flags, for the x gathers, for the
+// store drain + flag; work items; total cycles (s_memtime ticks, 100 MHz constant clock on gfx9).
+extern "C" int ddm_ilu0_debug_stamps(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, unsigned long long *out_host)
+{
+  if (!F->xcd_built) DDMCHECK(build_xcd_schedule(ctx, F));
+  unsigned long long *st = nullptr;
+  HIPCHECK(ctx, hipMalloc((void **)&st, 64));
+  HIPCHECK(ctx, hipMemset(st, 0, 64));
+  hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
+  hipLaunchKernelGGL(k_permute_rhs, dim3(grid_for(F->xnrows)), dim3(WG), 0, ctx->stream, F->xnrows, F->xrows, d, F->xdperm);
+  hipLaunchKernelGGL(k_trsv_xcd2, dim3(TRSV_P_GRID), dim3(128), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off, F->xrows,
+                     F->xcols, F->xvals, F->xdinv, F->xdperm, x, F->xflags, F->xstate, F->err, st);
+  int rc = ddm_memcpy_d2h(ctx, out_host, st, 48);
+  (void)hipFree(st);
+  return rc;
+}
+
 extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x)
 {
   if (F && F->n == 0) return DDM_OK;
@@ -740,11 +764,16 @@ extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double
     (void)hipGraphExecDestroy(F->graph);
     F->graph = nullptr;
   }
-  if (F->mode == 3 && !F->xcd_built) DDMCHECK(build_xcd_schedule(ctx, F));
+  if (F->mode >= 3 && !F->xcd_built) DDMCHECK(build_xcd_schedule(ctx, F));
   hipGraph_t g = nullptr;
   HIPCHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
   int rc = DDM_OK;
-  if (F->mode == 3) {
+  if (F->mode == 4) {
+    hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
+    hipLaunchKernelGGL(k_permute_rhs, dim3(grid_for(F->xnrows)), dim3(WG), 0, ctx->stream, F->xnrows, F->xrows, d, F->xdperm);
+    hipLaunchKernelGGL(k_trsv_xcd2, dim3(TRSV_P_GRID), dim3(128), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off, F->xrows,
+                       F->xcols, F->xvals, F->xdinv, F->xdperm, x, F->xflags, F->xstate, F->err, (unsigned long long *)nullptr);
+  } else if (F->mode == 3) {
     hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
     hipLaunchKernelGGL(k_trsv_xcd, dim3(TRSV_P_GRID), dim3(64), 0, ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off, F->xrows, F->xcols,
                        F->xvals, F->xdinv, d, x, F->xflags, F->xstate, F->err);

@@ -645,6 +645,295 @@ __global__ __launch_bounds__(64) void k_trsv_xcd(int ngroups, const GroupDesc *_
 }
 
 // ---------------------------------------------------------------------------------------------
+// XCD-local solve with a dedicated LOADER wave per workgroup ("xcd2" engine).
+// vmcnt retires in order, so a wave that both streams factor entries from HBM and polls flags pays
+// the HBM latency on every level.  Here each workgroup has two waves: wave 1 streams the tiles of
+// the workgroup's chunks (row ids, permuted right-hand side / inverse pivots, 16 entries per row)
+// from HBM into an LDS ring several levels ahead; wave 0 takes a tile from LDS (lgkmcnt), polls the
+// previous level's flags, gathers x from L2, stores, drains only its own store and sets its flag.
+// The two waves synchronise through two LDS words per ring (produced / consumed counts); they never
+// meet at a barrier.  Cross-workgroup protocol and XCD grouping are those of k_trsv_xcd.
+constexpr int TRSV_L_SLOTS = 8;
+struct TrsvLdsTile {
+  int32_t row[64];
+  double s0[64];  // L: right-hand side d[row];  U: inverse pivot
+  int32_t cc[TRSV_UNROLL][64];
+  double vv[TRSV_UNROLL][64];
+};
+struct TrsvLds {
+  TrsvLdsTile tile[TRSV_L_SLOTS];
+  unsigned produced, consumed; // work items written by the loader / released by the compute wave
+};
+__global__ void k_permute_rhs(int64_t n, const int32_t *__restrict__ rows, const double *__restrict__ d, double *__restrict__ dperm)
+{
+  for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG) dperm[i] = d[rows[i]];
+}
+
+// enumerates the work items (level, chunk) of one wave in processing order
+struct TrsvWork {
+  const GroupDesc *groups;
+  const LevelDesc *desc;
+  int ngroups, gstep, grp, lev, c, rank, W;
+  __device__ bool valid() const { return grp < ngroups; }
+  __device__ void init(const GroupDesc *g, const LevelDesc *d_, int ng, int first, int step, int rank_, int W_)
+  {
+    groups = g; desc = d_; ngroups = ng; gstep = step; grp = first; lev = 0; c = rank_; rank = rank_; W = W_;
+    settle();
+  }
+  __device__ void settle()
+  { // move to the next existing (level, chunk)
+    while (grp < ngroups) {
+      const GroupDesc G = groups[grp];
+      const int nlev = G.nlevL + G.nlevU;
+      while (lev < nlev) {
+        const int nchunk = (desc[G.lev_off + lev].m + 63) >> 6;
+        if (c < nchunk) return;
+        ++lev;
+        c = rank;
+      }
+      grp += gstep;
+      lev = 0;
+      c = rank;
+    }
+  }
+  __device__ void advance()
+  {
+    c += W;
+    settle();
+  }
+};
+
+__global__ __launch_bounds__(128) void k_trsv_xcd2(int ngroups, const GroupDesc *__restrict__ groups, const LevelDesc *__restrict__ desc,
+                                                    const int64_t *__restrict__ flag_off, const int32_t *__restrict__ rowsA,
+                                                    const int32_t *__restrict__ colsA, const double *__restrict__ valsA,
+                                                    const double *__restrict__ dinvA, const double *__restrict__ dperm, double *x,
+                                                    unsigned *flags, XcdState *st, unsigned *err, unsigned long long *stamps)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  TrsvLds &S = *reinterpret_cast<TrsvLds *>(smem_raw);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) {
+    S.produced = 0;
+    S.consumed = 0;
+  }
+  // ---- placement: ticket on the own XCD, then a grid barrier (wave 0 lane 0 acts for the workgroup)
+  __shared__ unsigned sh_xcc, sh_t, sh_gt, sh_fail;
+  if (threadIdx.x == 0) {
+    const unsigned xcc = hw_xcc_id();
+    sh_xcc = xcc;
+    sh_t = __hip_atomic_fetch_add(&st->tickets[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh_gt = __hip_atomic_fetch_add(&st->global_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&st->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned fail_ = 0;
+    for (unsigned spins = 0; __hip_atomic_load(&st->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x; ++spins) {
+      if (spins > (1u << 22)) {
+        __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fail_ = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    sh_fail = fail_;
+  }
+  __syncthreads(); // the only workgroup barrier: publishes the placement to both waves
+  if (sh_fail) return;
+  const unsigned xcc = sh_xcc, t = sh_t, gt = sh_gt;
+  const unsigned epoch = __hip_atomic_load(&st->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned tk = lane < 8 ? __hip_atomic_load(&st->tickets[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+  const int owners = ngroups < 8 ? ngroups : 8;
+  const bool local_ok = __all(lane >= owners || tk > 0u);
+  int W, rank, first, step;
+  bool wt;
+  if (local_ok) {
+    W = (int)__shfl((int)tk, (int)xcc, 64);
+    if (W > TRSV_X_MAXW) W = TRSV_X_MAXW;
+    rank = (int)t; first = (int)xcc; step = 8; wt = false;
+  } else {
+    W = (int)gridDim.x < TRSV_X_MAXW ? (int)gridDim.x : TRSV_X_MAXW;
+    rank = (int)gt; first = 0; step = 1; wt = true;
+  }
+  if (rank >= W) return;
+  TrsvWork wk;
+  wk.init(groups, desc, ngroups, first, step, rank, W);
+  volatile unsigned *produced = &S.produced;
+  volatile unsigned *consumed = &S.consumed;
+
+  if (wave == 1) {
+    // =========================== loader: HBM -> LDS ring ===========================
+    // two tiles in flight: the loads of item seq+1 are issued before item seq is written to LDS
+    struct Regs {
+      int32_t rowm, w;
+      double s0;
+      int32_t cc[TRSV_UNROLL];
+      double vv[TRSV_UNROLL];
+    };
+    auto issue = [&](Regs &R, const TrsvWork &k) {
+      const GroupDesc G = groups[k.grp];
+      const LevelDesc D = desc[G.lev_off + k.lev];
+      const bool upper = k.lev >= G.nlevL;
+      const int r = (k.c << 6) + lane;
+      const int rr = r < D.m ? r : D.m - 1;
+      const int32_t row = rowsA[D.row_off + rr];
+      R.rowm = r < D.m ? row : -1 - row; // negative = shadow lane (no store)
+      R.w = D.w;
+      // warm the XCD's L2 with the line of x[row]: the compute wave's store (write-allocate) and, in the
+      // U phase, its read of the forward value would otherwise pay an HBM miss on the per-level critical path
+      (void)*(volatile const unsigned long long *)(x + row);
+      R.s0 = upper ? dinvA[D.row_off + rr] : dperm[D.row_off + rr];
+      const int32_t *cols = colsA + D.ent_off;
+      const double *vals = valsA + D.ent_off;
+#pragma unroll
+      for (int u = 0; u < TRSV_UNROLL; ++u) {
+        R.cc[u] = 0;
+        R.vv[u] = 0.0;
+        if (u < D.w) {
+          R.cc[u] = cols[(int64_t)u * D.m + rr];
+          R.vv[u] = vals[(int64_t)u * D.m + rr];
+        }
+      }
+    };
+    Regs A, B;
+    if (!wk.valid()) return;
+    issue(A, wk);
+    for (unsigned seq = 0;; ++seq) {
+      wk.advance();
+      const bool more = wk.valid();
+      if (more) issue(B, wk);
+      for (unsigned spins = 0; seq >= *consumed + TRSV_L_SLOTS; ++spins) { // free ring slot?
+        if (spins > (1u << 24)) {
+          if (lane == 0) __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      TrsvLdsTile &T = S.tile[seq % TRSV_L_SLOTS];
+      T.row[lane] = A.rowm;
+      T.s0[lane] = A.s0;
+#pragma unroll
+      for (int u = 0; u < TRSV_UNROLL; ++u)
+        if (u < A.w) {
+          T.cc[u][lane] = A.cc[u];
+          T.vv[u][lane] = A.vv[u];
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // tile is in LDS before it is announced
+      if (lane == 0) *produced = seq + 1;
+      if (!more) return;
+      A = B;
+    }
+  }
+
+  // =========================== compute wave ===========================
+  // diagnostic stamps (only when a buffer is passed; production launches pass nullptr): cycles spent by the
+  // rank-0 wave of XCD 0 waiting for its LDS tile / for the flags / for the gathers / for the store drain
+  const bool stamp = stamps != nullptr && rank == 0 && (local_ok ? xcc == 0 : true);
+  unsigned long long t_tile = 0, t_poll = 0, t_gather = 0, t_drain = 0, n_items = 0, t_begin = 0, tq = 0;
+#define DDM_STAMP(acc)                                                 \
+  if (stamp) {                                                         \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();      \
+    acc += now_ - tq;                                                  \
+    tq = now_;                                                         \
+  }
+  if (stamp) t_begin = tq = __builtin_amdgcn_s_memtime();
+  for (unsigned seq = 0; wk.valid(); ++seq) {
+    const int grp = wk.grp, lev = wk.lev;
+    const GroupDesc G = groups[grp];
+    const LevelDesc D = desc[G.lev_off + lev];
+    const bool upper = lev >= G.nlevL;
+    unsigned *gflags = flags + flag_off[grp];
+    // tile from the ring
+    for (unsigned spins = 0; *produced <= seq; ++spins) {
+      if (spins > (1u << 24)) {
+        if (lane == 0) __hip_atomic_store(err, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    const TrsvLdsTile &T = S.tile[seq % TRSV_L_SLOTS];
+    const int32_t rowm = T.row[lane];
+    const bool act = rowm >= 0;
+    const int32_t row = act ? rowm : -1 - rowm;
+    const double s0 = T.s0[lane];
+    int32_t cc[TRSV_UNROLL];
+    double vv[TRSV_UNROLL], xv[TRSV_UNROLL];
+#pragma unroll
+    for (int u = 0; u < TRSV_UNROLL; ++u) {
+      cc[u] = 0;
+      vv[u] = 0.0;
+      if (u < D.w) {
+        cc[u] = T.cc[u][lane];
+        vv[u] = T.vv[u][lane];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) *consumed = seq + 1; // slot may be refilled
+    DDM_STAMP(t_tile)
+    // previous level of this group complete?
+    const bool first_chunk_of_level = wk.c == rank;
+    if (lev > 0 && first_chunk_of_level) {
+      const unsigned *fp = gflags + (int64_t)(lev - 1) * TRSV_X_MAXW;
+      const int ncp = (desc[G.lev_off + lev - 1].m + 63) >> 6;
+      const int nact = ncp < W ? ncp : W;
+      for (unsigned spins = 0;; ++spins) {
+        const unsigned v = lane < nact ? __hip_atomic_load(fp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+        if (__all(v == epoch)) break;
+        if (spins > (1u << 22)) {
+          if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    DDM_STAMP(t_poll)
+#pragma unroll
+    for (int u = 0; u < TRSV_UNROLL; ++u) {
+      xv[u] = 0.0;
+      if (u < D.w) xv[u] = ld_sc1(x + cc[u]);
+    }
+    double s = upper ? ld_sc1(x + row) : s0;
+#pragma unroll
+    for (int u = 0; u < TRSV_UNROLL; ++u) s -= vv[u] * xv[u];
+    if (stamp) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      DDM_STAMP(t_gather)
+    }
+    if (D.w > TRSV_UNROLL) { // rows wider than a tile: the rest straight from global memory (rare)
+      const int r = (wk.c << 6) + lane;
+      const int rr = r < D.m ? r : D.m - 1;
+      for (int k = TRSV_UNROLL; k < D.w; ++k)
+        s -= valsA[D.ent_off + (int64_t)k * D.m + rr] * ld_sc1(x + colsA[D.ent_off + (int64_t)k * D.m + rr]);
+    }
+    const double out = upper ? s * s0 : s;
+    if (act) {
+      if (wt) st_sc1(x + row, out);
+      else x[row] = out;
+    }
+    // last chunk of this wave in this level -> drain and raise the flag
+    wk.advance();
+    const bool level_done = !wk.valid() || wk.grp != grp || wk.lev != lev;
+    if (level_done) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) {
+        unsigned *f = gflags + (int64_t)lev * TRSV_X_MAXW + rank;
+        if (wt) __hip_atomic_store(f, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *(volatile unsigned *)f = epoch;
+      }
+    }
+    DDM_STAMP(t_drain)
+    n_items += 1;
+  }
+  if (stamp && lane == 0) {
+    stamps[0] = t_tile;
+    stamps[1] = t_poll;
+    stamps[2] = t_gather;
+    stamps[3] = t_drain;
+    stamps[4] = n_items;
+    stamps[5] = __builtin_amdgcn_s_memtime() - t_begin;
+  }
+#undef DDM_STAMP
+}
+
+// ---------------------------------------------------------------------------------------------
 // K2 extend (schwarz.hh:121-122), K5 restrict (schwarz.hh:146), K4 POU scaling (schwarz.hh:141)
 __global__ void k_extend(int64_t n, const int32_t *__restrict__ ext_map, const double *__restrict__ d, double *__restrict__ dov)
 {

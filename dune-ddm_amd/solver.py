@@ -110,6 +110,11 @@ class TwoLevelSchwarz:
             self.ctx.set_comm(rank, nranks, comm.alltoall, comm.allreduce)
         rl = self.rl = RankLocal(dec, rank, nranks)
         ctx = self.ctx
+        if comm is not None and comm.backend != "nccl":
+            # gloo rehearsal: several ranks share one GPU.  The single-launch triangular solves need all
+            # their workgroups co-resident (one process per GPU); fall back to one launch per level.
+            import os
+            os.environ["DDM_TRSV_MODE"] = "levels"
         self.A = CsrMatrix(ctx, rl.A)
         self.A_dir = CsrMatrix(ctx, rl.A_dir)
         self.h_novlp = Halo(ctx, 1, Halo.ADD, rl.plan_novlp_add)

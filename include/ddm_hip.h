@@ -97,6 +97,8 @@ int64_t ddm_ilu0_num_levels(const ddm_ilu0 *F, int upper);
 /* status of the persistent (single-launch) triangular solve: 0 ok, 1 = a wave timed out waiting for a
  * dependency level (results invalid).  Synchronous.  DDM_TRSV_MODE=levels selects one launch per level. */
 int ddm_ilu0_status(ddm_ctx *ctx, const ddm_ilu0 *F, int *status);
+/* diagnostic: one solve with in-kernel cycle stamps of one compute wave */
+int ddm_ilu0_debug_stamps(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, unsigned long long *out6_host);
 /* factor values in the pattern of A (inverse pivots on the diagonal), for parity tests */
 int ddm_ilu0_get_factors_host(ddm_ctx *ctx, const ddm_ilu0 *F, double *lu_host);
 
