@@ -144,9 +144,19 @@ def main():
     if local_cnt > 0:
         avg_ms = local_ms / local_cnt
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "ilu0_trsv (k_trsv_lower_level / k_trsv_upper_level / k_trsv_small_levels)",
+        engine = os.environ.get("DDM_TRSV_MODE", "xcd")
+        kname = {"levels": "k_trsv_lower_level + k_trsv_upper_level + k_trsv_small_levels (one launch per level, HIP graph)",
+                 "persistent": "k_trsv_persistent", "syncfree": "k_trsv_syncfree", "xcd2": "k_trsv_xcd2<false>", "xcd3": "k_trsv_xcd2<true>"}.get(engine, "k_trsv_xcd")
+        traffic = None
+        try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command (profiles/), gfx950-corrected
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_b_pmc_traffic_grid216.json")))
+            if G == 216 and engine == "xcd":
+                traffic = pmc["kernels"]["ddm::k_trsv_xcd"]["hbm_bytes_per_dispatch_corrected"] * (8 // world) / 8.0
+        except Exception:
+            traffic = None
+        roofline = {"bound": "hbm", "kernel": f"ILU(0) triangular solve: {kname}",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
+                    "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
                     "launches_timed": int(local_cnt)}
     # whole-iteration algorithmic traffic: 12(z_o+z) + 16 k n + 56 n + 170 n_o
     k = 0 if tl.galerkin is None else max(tl.k_all)

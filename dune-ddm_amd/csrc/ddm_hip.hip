@@ -389,7 +389,7 @@ struct TriSchedule { // one triangular factor, level by level in sliced ELL
 
 struct ddm_ilu0 {
   int64_t n = 0, nnz = 0;
-  int mode = 4;                 // 4 = XCD-local + loader wave (default), 3 = XCD-local single wave, 1 = single launch + level counters, 2 = data-driven, 0 = launch per level
+  int mode = 3;                 // 3 = XCD-local single wave (default, fastest measured), 4 = + loader wave, 5 = dataflow + loader wave, 1 = single launch + level counters, 2 = data-driven, 0 = launch per level
   double *ywork = nullptr;      // forward-solve result of the data-driven kernel
   // XCD-local engine (mode 3): per-block (subdomain) level schedules, built on first use
   std::vector<int64_t> h_diag, h_block_ptr;
@@ -551,7 +551,7 @@ extern "C" int ddm_ilu0_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, 
     }
   int rc = build_schedule(ctx, A, F->h_lu, diag, false, F->L);
   if (!rc) rc = build_schedule(ctx, A, F->h_lu, diag, true, F->U);
-  if (const char *m = std::getenv("DDM_TRSV_MODE")) F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "syncfree") ? 2 : (!std::strcmp(m, "persistent") ? 1 : (!std::strcmp(m, "xcd") ? 3 : 4)));
+  if (const char *m = std::getenv("DDM_TRSV_MODE")) F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "syncfree") ? 2 : (!std::strcmp(m, "persistent") ? 1 : (!std::strcmp(m, "xcd2") ? 4 : (!std::strcmp(m, "xcd3") ? 5 : 3))));
   F->A = A;
   F->h_diag = diag;
   F->h_block_ptr.assign(block_ptr, block_ptr + nblocks + 1);
@@ -703,7 +703,8 @@ static int build_xcd_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
   HIPCHECK(ctx, hipMemset(F->xstate, 0, sizeof(XcdState)));
   F->xnrows = (int64_t)rows.size();
   HIPCHECK(ctx, hipMalloc((void **)&F->xdperm, sizeof(double) * (size_t)std::max<int64_t>(F->xnrows, 1)));
-  HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_xcd2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TrsvLds)));
+  HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_xcd2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TrsvLds)));
+  HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_xcd2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TrsvLds)));
   F->xcd_built = true;
   return DDM_OK;
 }
@@ -744,8 +745,8 @@ extern "C" int ddm_ilu0_debug_stamps(ddm_ctx *ctx, ddm_ilu0 *F, const double *d,
   HIPCHECK(ctx, hipMemset(st, 0, 64));
   hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
   hipLaunchKernelGGL(k_permute_rhs, dim3(grid_for(F->xnrows)), dim3(WG), 0, ctx->stream, F->xnrows, F->xrows, d, F->xdperm);
-  hipLaunchKernelGGL(k_trsv_xcd2, dim3(TRSV_P_GRID), dim3(128), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off, F->xrows,
-                     F->xcols, F->xvals, F->xdinv, F->xdperm, x, F->xflags, F->xstate, F->err, st);
+  hipLaunchKernelGGL(k_trsv_xcd2<false>, dim3(TRSV_P_GRID), dim3(128), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off, F->xrows,
+                     F->xcols, F->xvals, F->xdinv, F->xdperm, x, F->ywork, F->xflags, F->xstate, F->err, st);
   int rc = ddm_memcpy_d2h(ctx, out_host, st, 48);
   (void)hipFree(st);
   return rc;
@@ -768,11 +769,18 @@ extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double
   hipGraph_t g = nullptr;
   HIPCHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
   int rc = DDM_OK;
-  if (F->mode == 4) {
+  if (F->mode == 5) {
+    hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
+    (void)hipMemsetAsync(F->ywork, 0xFF, sizeof(double) * (size_t)F->n, ctx->stream); // sentinel = "not computed yet"
+    (void)hipMemsetAsync(x, 0xFF, sizeof(double) * (size_t)F->n, ctx->stream);
+    hipLaunchKernelGGL(k_permute_rhs, dim3(grid_for(F->xnrows)), dim3(WG), 0, ctx->stream, F->xnrows, F->xrows, d, F->xdperm);
+    hipLaunchKernelGGL(k_trsv_xcd2<true>, dim3(TRSV_P_GRID), dim3(128), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off,
+                       F->xrows, F->xcols, F->xvals, F->xdinv, F->xdperm, x, F->ywork, F->xflags, F->xstate, F->err, (unsigned long long *)nullptr);
+  } else if (F->mode == 4) {
     hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
     hipLaunchKernelGGL(k_permute_rhs, dim3(grid_for(F->xnrows)), dim3(WG), 0, ctx->stream, F->xnrows, F->xrows, d, F->xdperm);
-    hipLaunchKernelGGL(k_trsv_xcd2, dim3(TRSV_P_GRID), dim3(128), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off, F->xrows,
-                       F->xcols, F->xvals, F->xdinv, F->xdperm, x, F->xflags, F->xstate, F->err, (unsigned long long *)nullptr);
+    hipLaunchKernelGGL(k_trsv_xcd2<false>, dim3(TRSV_P_GRID), dim3(128), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off,
+                       F->xrows, F->xcols, F->xvals, F->xdinv, F->xdperm, x, F->ywork, F->xflags, F->xstate, F->err, (unsigned long long *)nullptr);
   } else if (F->mode == 3) {
     hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
     hipLaunchKernelGGL(k_trsv_xcd, dim3(TRSV_P_GRID), dim3(64), 0, ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off, F->xrows, F->xcols,

@@ -703,11 +703,15 @@ struct TrsvWork {
   }
 };
 
+// DATAFLOW = false: level flags (drain + flag per level).  DATAFLOW = true ("xcd3"): y / x are pre-filled with
+// the all-ones sentinel, a row polls its own dependencies in L2 until none is the sentinel and publishes its
+// value with a single 8-byte store: no flag, no drain, no level barrier on the critical path.
+template <bool DATAFLOW>
 __global__ __launch_bounds__(128) void k_trsv_xcd2(int ngroups, const GroupDesc *__restrict__ groups, const LevelDesc *__restrict__ desc,
                                                     const int64_t *__restrict__ flag_off, const int32_t *__restrict__ rowsA,
                                                     const int32_t *__restrict__ colsA, const double *__restrict__ valsA,
                                                     const double *__restrict__ dinvA, const double *__restrict__ dperm, double *x,
-                                                    unsigned *flags, XcdState *st, unsigned *err, unsigned long long *stamps)
+                                                    double *y, unsigned *flags, XcdState *st, unsigned *err, unsigned long long *stamps)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   TrsvLds &S = *reinterpret_cast<TrsvLds *>(smem_raw);
@@ -779,7 +783,7 @@ __global__ __launch_bounds__(128) void k_trsv_xcd2(int ngroups, const GroupDesc 
       R.w = D.w;
       // warm the XCD's L2 with the line of x[row]: the compute wave's store (write-allocate) and, in the
       // U phase, its read of the forward value would otherwise pay an HBM miss on the per-level critical path
-      (void)*(volatile const unsigned long long *)(x + row);
+      if (!DATAFLOW) (void)*(volatile const unsigned long long *)(x + row);
       R.s0 = upper ? dinvA[D.row_off + rr] : dperm[D.row_off + rr];
       const int32_t *cols = colsA + D.ent_off;
       const double *vals = valsA + D.ent_off;
@@ -868,6 +872,54 @@ __global__ __launch_bounds__(128) void k_trsv_xcd2(int ngroups, const GroupDesc 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) *consumed = seq + 1; // slot may be refilled
     DDM_STAMP(t_tile)
+    if (DATAFLOW) {
+      const double *src = upper ? x : y;
+      unsigned long long xb[TRSV_UNROLL], own = 0ull;
+      for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int u = 0; u < TRSV_UNROLL; ++u) {
+          xb[u] = 0ull;
+          if (u < D.w) {
+            xb[u] = ld_sc1_bits(src + cc[u]);
+            ok &= xb[u] != TRSV_SENTINEL;
+          }
+        }
+        if (upper) {
+          own = ld_sc1_bits(y + row);
+          ok &= own != TRSV_SENTINEL;
+        }
+        if (__all(ok)) break;
+        if (spins > (1u << 20)) {
+          if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      double s = upper ? __longlong_as_double((long long)own) : s0;
+#pragma unroll
+      for (int u = 0; u < TRSV_UNROLL; ++u) s -= vv[u] * __longlong_as_double((long long)xb[u]);
+      if (D.w > TRSV_UNROLL) { // rare: rows wider than a tile (their extra dependencies are polled one by one)
+        const int r = (wk.c << 6) + lane;
+        const int rr = r < D.m ? r : D.m - 1;
+        for (int k = TRSV_UNROLL; k < D.w; ++k) {
+          const int32_t c2 = colsA[D.ent_off + (int64_t)k * D.m + rr];
+          unsigned long long b2;
+          for (unsigned spins = 0;; ++spins) {
+            b2 = ld_sc1_bits(src + c2);
+            if (__all(b2 != TRSV_SENTINEL) || spins > (1u << 20)) break;
+          }
+          s -= valsA[D.ent_off + (int64_t)k * D.m + rr] * __longlong_as_double((long long)b2);
+        }
+      }
+      const double out = upper ? s * s0 : s;
+      double *dst = upper ? x : y;
+      if (act) {
+        if (wt) st_sc1(dst + row, out);
+        else dst[row] = out;
+      }
+      wk.advance();
+      continue;
+    }
     // previous level of this group complete?
     const bool first_chunk_of_level = wk.c == rank;
     if (lev > 0 && first_chunk_of_level) {
