@@ -144,14 +144,15 @@ def main():
     if local_cnt > 0:
         avg_ms = local_ms / local_cnt
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        engine = os.environ.get("DDM_TRSV_MODE", "xcd")
+        engine = os.environ.get("DDM_TRSV_MODE", "xcd2")
         kname = {"levels": "k_trsv_lower_level + k_trsv_upper_level + k_trsv_small_levels (one launch per level, HIP graph)",
-                 "persistent": "k_trsv_persistent", "syncfree": "k_trsv_syncfree", "xcd2": "k_trsv_xcd2<false>", "xcd3": "k_trsv_xcd2<true>"}.get(engine, "k_trsv_xcd")
+                 "persistent": "k_trsv_persistent", "syncfree": "k_trsv_syncfree", "xcd": "k_trsv_xcd", "xcd3": "k_trsv_xcd2<true>",
+                 "xcdw": "k_trsv_xcdw"}.get(engine, "k_trsv_xcd2<false>")
         traffic = None
         try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command (profiles/), gfx950-corrected
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_b_pmc_traffic_grid216.json")))
-            if G == 216 and engine == "xcd":
-                traffic = pmc["kernels"]["ddm::k_trsv_xcd"]["hbm_bytes_per_dispatch_corrected"] * (8 // world) / 8.0
+            if G == 216 and engine in pmc.get("engine_kernels", {}):
+                traffic = pmc["kernels"][pmc["engine_kernels"][engine]]["hbm_bytes_per_dispatch_corrected"] * (8 // world) / 8.0
         except Exception:
             traffic = None
         roofline = {"bound": "hbm", "kernel": f"ILU(0) triangular solve: {kname}",

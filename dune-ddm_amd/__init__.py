@@ -249,7 +249,7 @@ class Ilu0:
         return int(self.ctx.lib.ddm_ilu0_num_levels(self.h, int(upper)))
 
     def debug_stamps(self, d, x):
-        out = np.zeros(6, dtype=np.uint64)
+        out = np.zeros(8, dtype=np.uint64)
         self.ctx.check(self.ctx.lib.ddm_ilu0_debug_stamps(self.ctx.h, self.h, _ptr(d), _ptr(x), _hp(out)))
         return out
 

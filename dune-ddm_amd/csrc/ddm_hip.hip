@@ -389,7 +389,7 @@ struct TriSchedule { // one triangular factor, level by level in sliced ELL
 
 struct ddm_ilu0 {
   int64_t n = 0, nnz = 0;
-  int mode = 3;                 // 3 = XCD-local single wave (default, fastest measured), 4 = + loader wave, 5 = dataflow + loader wave, 1 = single launch + level counters, 2 = data-driven, 0 = launch per level
+  int mode = 4;                 // 4 = XCD-local + loader wave (default), 3 = XCD-local single wave, 5 = dataflow, 6 = LDS-staged windows, 1 = single launch + level counters, 2 = data-driven, 0 = launch per level
   double *ywork = nullptr;      // forward-solve result of the data-driven kernel
   // XCD-local engine (mode 3): per-block (subdomain) level schedules, built on first use
   std::vector<int64_t> h_diag, h_block_ptr;
@@ -405,6 +405,17 @@ struct ddm_ilu0 {
   XcdState *xstate = nullptr;
   double *xdperm = nullptr;     // right-hand side permuted into level order (loader engine)
   int64_t xnrows = 0;
+  // windowed level-permuted engine (mode 6)
+  int w_state = 0;              // 0 not built, 1 built, -1 not applicable (rows wider than a tile)
+  GroupDesc *wg = nullptr;
+  WLevel *wlev = nullptr;
+  WChunk *wchunk = nullptr;
+  int64_t *wflag_off = nullptr, *wlpos = nullptr, *wupos = nullptr;
+  int32_t *wrows = nullptr, *widx = nullptr, *wown = nullptr;
+  double *wvals = nullptr, *wdinv = nullptr, *wdperm = nullptr, *wxp = nullptr;
+  unsigned *wflags = nullptr;
+  int64_t wnpos = 0;
+  double w_direct_frac = 0.0;
   unsigned *cnt = nullptr;      // per-level sharded arrival counters, zeroed before every solve; last word block = error flag
   size_t cnt_bytes = 0;
   unsigned *err = nullptr;
@@ -551,7 +562,7 @@ extern "C" int ddm_ilu0_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, 
     }
   int rc = build_schedule(ctx, A, F->h_lu, diag, false, F->L);
   if (!rc) rc = build_schedule(ctx, A, F->h_lu, diag, true, F->U);
-  if (const char *m = std::getenv("DDM_TRSV_MODE")) F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "syncfree") ? 2 : (!std::strcmp(m, "persistent") ? 1 : (!std::strcmp(m, "xcd2") ? 4 : (!std::strcmp(m, "xcd3") ? 5 : 3))));
+  if (const char *m = std::getenv("DDM_TRSV_MODE")) F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "syncfree") ? 2 : (!std::strcmp(m, "persistent") ? 1 : (!std::strcmp(m, "xcd") ? 3 : (!std::strcmp(m, "xcd3") ? 5 : (!std::strcmp(m, "xcdw") ? 6 : 4)))));
   F->A = A;
   F->h_diag = diag;
   F->h_block_ptr.assign(block_ptr, block_ptr + nblocks + 1);
@@ -586,6 +597,20 @@ extern "C" void ddm_ilu0_destroy(ddm_ilu0 *F)
   (void)hipFree(F->xflags);
   (void)hipFree(F->xstate);
   (void)hipFree(F->xdperm);
+  (void)hipFree(F->wg);
+  (void)hipFree(F->wlev);
+  (void)hipFree(F->wchunk);
+  (void)hipFree(F->wflag_off);
+  (void)hipFree(F->wlpos);
+  (void)hipFree(F->wupos);
+  (void)hipFree(F->wrows);
+  (void)hipFree(F->widx);
+  (void)hipFree(F->wown);
+  (void)hipFree(F->wvals);
+  (void)hipFree(F->wdinv);
+  (void)hipFree(F->wdperm);
+  (void)hipFree(F->wxp);
+  (void)hipFree(F->wflags);
   free_schedule(F->L);
   free_schedule(F->U);
   delete F;
@@ -709,6 +734,230 @@ static int build_xcd_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
   return DDM_OK;
 }
 
+// Level-permuted schedule with dependency windows (engine "xcdw").  Position space: for every block its
+// L-level-sorted rows, then its U-level-sorted rows (2 n positions).  Per 64-row chunk the dependency
+// positions are merged into runs (gap <= 8), cut into pieces of <= 64; chunks that need more than
+// TRSV_W_MAXPIECE pieces fall back to direct gathers.  Blocks are processed by separate host threads.
+static int build_xcdw_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
+{
+  const ddm_csr *A = F->A;
+  const int64_t *rp = A->h_rp.data();
+  const int32_t *ci = A->h_ci.data();
+  const std::vector<double> &lu = F->h_lu;
+  const std::vector<int64_t> &diag = F->h_diag;
+  const int nb = (int)F->h_block_ptr.size() - 1;
+  const int64_t n = A->nrows;
+  (void)n;
+  struct Block {
+    std::vector<WLevel> lev;
+    std::vector<WChunk> chunk;
+    std::vector<int32_t> rows, idx, own;
+    std::vector<double> vals, dinv;
+    int nlevL = 0, nlevU = 0;
+    int64_t direct = 0;
+  };
+  std::vector<Block> blocks(nb);
+  std::vector<int64_t> pos_base(nb + 1, 0);
+  for (int b = 0; b < nb; ++b) pos_base[b + 1] = pos_base[b] + 2 * (F->h_block_ptr[b + 1] - F->h_block_ptr[b]);
+  auto work = [&](int b) {
+    Block &B = blocks[b];
+    const int64_t r0 = F->h_block_ptr[b], r1 = F->h_block_ptr[b + 1], nbk = r1 - r0;
+    std::vector<int32_t> level(nbk);
+    std::vector<int64_t> posL(nbk), posU(nbk);
+    B.rows.resize(2 * nbk);
+    B.dinv.assign(2 * nbk, 0.0);
+    B.own.assign(2 * nbk, 0);
+    for (int pass = 0; pass < 2; ++pass) {
+      const bool upper = pass == 1;
+      int32_t maxlev = -1;
+      if (!upper)
+        for (int64_t i = r0; i < r1; ++i) {
+          int32_t l = 0;
+          for (int64_t k = rp[i]; k < diag[i]; ++k) l = std::max(l, level[ci[k] - r0] + 1);
+          level[i - r0] = l;
+          maxlev = std::max(maxlev, l);
+        }
+      else
+        for (int64_t i = r1 - 1; i >= r0; --i) {
+          int32_t l = 0;
+          for (int64_t k = diag[i] + 1; k < rp[i + 1]; ++k) l = std::max(l, level[ci[k] - r0] + 1);
+          level[i - r0] = l;
+          maxlev = std::max(maxlev, l);
+        }
+      const int64_t nlev = (int64_t)maxlev + 1;
+      (upper ? B.nlevU : B.nlevL) = (int)nlev;
+      std::vector<int64_t> lptr(nlev + 1, 0);
+      for (int64_t i = 0; i < nbk; ++i) lptr[level[i] + 1]++;
+      for (int64_t l = 0; l < nlev; ++l) lptr[l + 1] += lptr[l];
+      const int64_t pbase = pos_base[b] + (upper ? nbk : 0); // absolute position of the first row of this pass
+      std::vector<int64_t> &pos = upper ? posU : posL;
+      {
+        std::vector<int64_t> fill(lptr.begin(), lptr.end() - 1);
+        for (int64_t i = 0; i < nbk; ++i) {
+          const int64_t p = fill[level[i]]++;
+          pos[i] = pbase + p;
+          B.rows[(upper ? nbk : 0) + p] = (int32_t)(r0 + i);
+        }
+      }
+      for (int64_t l = 0; l < nlev; ++l) {
+        const int64_t m = lptr[l + 1] - lptr[l];
+        int w = 0;
+        for (int64_t r = 0; r < m; ++r) {
+          const int64_t i = B.rows[(upper ? nbk : 0) + lptr[l] + r];
+          w = std::max(w, upper ? (int)(rp[i + 1] - diag[i] - 1) : (int)(diag[i] - rp[i]));
+        }
+        const int64_t ent = (int64_t)B.idx.size();
+        B.lev.push_back(WLevel{(int32_t)m, (int32_t)w, pbase + lptr[l], ent, (int64_t)B.chunk.size()});
+        B.idx.resize(ent + m * (int64_t)w);
+        B.vals.resize(ent + m * (int64_t)w);
+        std::vector<int64_t> dep;
+        for (int64_t c0 = 0; c0 < m; c0 += 64) {
+          const int64_t c1 = std::min<int64_t>(c0 + 64, m);
+          // dependency positions of the chunk
+          dep.clear();
+          for (int64_t r = c0; r < c1; ++r) {
+            const int64_t i = B.rows[(upper ? nbk : 0) + lptr[l] + r];
+            const int64_t k0 = upper ? diag[i] + 1 : rp[i], k1 = upper ? rp[i + 1] : diag[i];
+            for (int64_t p = k0; p < k1; ++p) dep.push_back(pos[ci[p] - r0]);
+          }
+          std::sort(dep.begin(), dep.end());
+          dep.erase(std::unique(dep.begin(), dep.end()), dep.end());
+          WChunk ch;
+          std::memset(&ch, 0, sizeof ch);
+          // runs with gaps <= 8, cut into pieces of <= 64 positions
+          std::vector<std::pair<int64_t, int64_t>> pieces; // (lo, len)
+          bool fits = true;
+          for (size_t a = 0; a < dep.size();) {
+            size_t e = a;
+            while (e + 1 < dep.size() && dep[e + 1] - dep[e] <= 8) ++e;
+            for (int64_t lo = dep[a]; lo <= dep[e]; lo += 64) pieces.emplace_back(lo, std::min<int64_t>(64, dep[e] - lo + 1));
+            a = e + 1;
+            if ((int)pieces.size() > TRSV_W_MAXPIECE) {
+              fits = false;
+              break;
+            }
+          }
+          if (fits && !pieces.empty()) {
+            int off = 0;
+            ch.npiece = (int32_t)pieces.size();
+            for (size_t q = 0; q < pieces.size(); ++q) {
+              ch.lo[q] = (int32_t)pieces[q].first;
+              ch.len[q] = (uint8_t)pieces[q].second;
+              ch.off[q] = (uint16_t)off;
+              off += (int)pieces[q].second;
+            }
+            ch.staged = off;
+          } else if (!pieces.empty() || !fits) {
+            ch.npiece = 0;
+            B.direct += 1;
+          }
+          // entries: staging index (or position)
+          for (int64_t r = c0; r < c1; ++r) {
+            const int64_t i = B.rows[(upper ? nbk : 0) + lptr[l] + r];
+            const int64_t k0 = upper ? diag[i] + 1 : rp[i], k1 = upper ? rp[i + 1] : diag[i];
+            int k = 0;
+            int32_t first = 0;
+            const int32_t first_pos = k1 > k0 ? (int32_t)pos[ci[k0] - r0] : 0;
+            for (int64_t p = k0; p < k1; ++p, ++k) {
+              const int64_t dp = pos[ci[p] - r0];
+              int32_t code = (int32_t)dp;
+              if (ch.npiece > 0 && k < TRSV_UNROLL) { // entries beyond the first tile are gathered by position
+                int q = (int)(std::upper_bound(pieces.begin(), pieces.end(), std::make_pair(dp, (int64_t)INT64_MAX)) - pieces.begin()) - 1;
+                code = (int32_t)(ch.off[q] + (dp - pieces[q].first));
+              }
+              if (k == 0) first = code;
+              B.idx[ent + (int64_t)k * m + r] = code;
+              B.vals[ent + (int64_t)k * m + r] = lu[p];
+            }
+            for (; k < w; ++k) {
+              B.idx[ent + (int64_t)k * m + r] = k < TRSV_UNROLL ? first : first_pos;
+              B.vals[ent + (int64_t)k * m + r] = 0.0;
+            }
+            if (upper) {
+              B.dinv[nbk + lptr[l] + r] = lu[diag[i]];
+              B.own[nbk + lptr[l] + r] = (int32_t)posL[i - r0];
+            }
+          }
+          B.chunk.push_back(ch);
+        }
+      }
+    }
+  };
+  {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int nthreads = (int)std::min<int64_t>(nb, hw);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t)
+      th.emplace_back([&, t]() {
+        for (int b = t; b < nb; b += nthreads) work(b);
+      });
+    for (auto &t : th) t.join();
+  }
+  if (pos_base[nb] >= ((int64_t)1 << 31)) { // positions are stored as int32
+    F->w_state = -1;
+    return DDM_OK;
+  }
+  // concatenate the blocks
+  std::vector<GroupDesc> groups(nb);
+  std::vector<WLevel> lev;
+  std::vector<WChunk> chunk;
+  std::vector<int64_t> flag_off(nb), lpos, upos;
+  std::vector<int32_t> rows, idx, own;
+  std::vector<double> vals, dinv;
+  int64_t nflag = 0, ndirect = 0;
+  for (int b = 0; b < nb; ++b) {
+    Block &B = blocks[b];
+    const int64_t nbk = F->h_block_ptr[b + 1] - F->h_block_ptr[b];
+    groups[b] = GroupDesc{B.nlevL, B.nlevU, (int64_t)lev.size()};
+    flag_off[b] = nflag;
+    nflag += (int64_t)(B.nlevL + B.nlevU) * TRSV_X_MAXW;
+    const int64_t ent0 = (int64_t)idx.size(), ch0 = (int64_t)chunk.size();
+    for (auto L : B.lev) {
+      L.ent_off += ent0;
+      L.chunk_off += ch0;
+      lev.push_back(L);
+    }
+    chunk.insert(chunk.end(), B.chunk.begin(), B.chunk.end());
+    rows.insert(rows.end(), B.rows.begin(), B.rows.end());
+    idx.insert(idx.end(), B.idx.begin(), B.idx.end());
+    own.insert(own.end(), B.own.begin(), B.own.end());
+    vals.insert(vals.end(), B.vals.begin(), B.vals.end());
+    dinv.insert(dinv.end(), B.dinv.begin(), B.dinv.end());
+    for (int64_t p = 0; p < nbk; ++p) {
+      lpos.push_back(pos_base[b] + p);
+      upos.push_back(pos_base[b] + nbk + p);
+    }
+    ndirect += B.direct;
+    B = Block();
+  }
+  F->w_direct_frac = chunk.empty() ? 0.0 : (double)ndirect / (double)chunk.size();
+  F->ngroups = nb;
+  F->wnpos = pos_base[nb];
+  DDMCHECK(upload(ctx, groups.data(), (int64_t)groups.size(), &F->wg));
+  DDMCHECK(upload(ctx, lev.data(), (int64_t)lev.size(), &F->wlev));
+  DDMCHECK(upload(ctx, chunk.data(), (int64_t)chunk.size(), &F->wchunk));
+  DDMCHECK(upload(ctx, flag_off.data(), (int64_t)flag_off.size(), &F->wflag_off));
+  DDMCHECK(upload(ctx, lpos.data(), (int64_t)lpos.size(), &F->wlpos));
+  DDMCHECK(upload(ctx, upos.data(), (int64_t)upos.size(), &F->wupos));
+  DDMCHECK(upload(ctx, rows.data(), (int64_t)rows.size(), &F->wrows));
+  DDMCHECK(upload(ctx, idx.data(), (int64_t)idx.size(), &F->widx));
+  DDMCHECK(upload(ctx, own.data(), (int64_t)own.size(), &F->wown));
+  DDMCHECK(upload(ctx, vals.data(), (int64_t)vals.size(), &F->wvals));
+  DDMCHECK(upload(ctx, dinv.data(), (int64_t)dinv.size(), &F->wdinv));
+  HIPCHECK(ctx, hipMalloc((void **)&F->wdperm, sizeof(double) * (size_t)std::max<int64_t>(F->wnpos, 1)));
+  HIPCHECK(ctx, hipMalloc((void **)&F->wxp, sizeof(double) * (size_t)std::max<int64_t>(F->wnpos, 1)));
+  HIPCHECK(ctx, hipMemset(F->wxp, 0, sizeof(double) * (size_t)std::max<int64_t>(F->wnpos, 1)));
+  HIPCHECK(ctx, hipMalloc((void **)&F->wflags, sizeof(unsigned) * (size_t)std::max<int64_t>(nflag, 1)));
+  HIPCHECK(ctx, hipMemset(F->wflags, 0, sizeof(unsigned) * (size_t)std::max<int64_t>(nflag, 1)));
+  if (!F->xstate) {
+    HIPCHECK(ctx, hipMalloc((void **)&F->xstate, sizeof(XcdState)));
+    HIPCHECK(ctx, hipMemset(F->xstate, 0, sizeof(XcdState)));
+  }
+  HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_xcdw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WLds)));
+  F->w_state = 1;
+  return DDM_OK;
+}
+
 static int enqueue_tri(ddm_ctx *ctx, const TriSchedule &S, bool upper, const double *d, double *x)
 {
   for (const auto &p : S.plan) {
@@ -739,10 +988,22 @@ static int enqueue_tri(ddm_ctx *ctx, const TriSchedule &S, bool upper, const dou
 // store drain + flag; work items; total cycles (s_memtime ticks, 100 MHz constant clock on gfx9).
 extern "C" int ddm_ilu0_debug_stamps(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, unsigned long long *out_host)
 {
-  if (!F->xcd_built) DDMCHECK(build_xcd_schedule(ctx, F));
   unsigned long long *st = nullptr;
   HIPCHECK(ctx, hipMalloc((void **)&st, 64));
   HIPCHECK(ctx, hipMemset(st, 0, 64));
+  if (F->mode == 6) {
+    if (F->w_state == 0) DDMCHECK(build_xcdw_schedule(ctx, F));
+    const int64_t nn = F->n;
+    hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
+    hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(nn)), dim3(WG), 0, ctx->stream, nn, F->wlpos, F->wrows, d, F->wdperm);
+    hipLaunchKernelGGL(k_trsv_xcdw, dim3(TRSV_P_GRID), dim3(128), sizeof(WLds), ctx->stream, F->ngroups, F->wg, F->wlev, F->wchunk, F->wflag_off,
+                       F->widx, F->wvals, F->wdinv, F->wown, F->wdperm, F->wxp, F->wflags, F->xstate, F->err, st);
+    hipLaunchKernelGGL(k_w_permute_out, dim3(grid_for(nn)), dim3(WG), 0, ctx->stream, nn, F->wupos, F->wrows, F->wxp, x);
+    int rc6 = ddm_memcpy_d2h(ctx, out_host, st, 56);
+    (void)hipFree(st);
+    return rc6;
+  }
+  if (!F->xcd_built) DDMCHECK(build_xcd_schedule(ctx, F));
   hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
   hipLaunchKernelGGL(k_permute_rhs, dim3(grid_for(F->xnrows)), dim3(WG), 0, ctx->stream, F->xnrows, F->xrows, d, F->xdperm);
   hipLaunchKernelGGL(k_trsv_xcd2<false>, dim3(TRSV_P_GRID), dim3(128), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off, F->xrows,
@@ -765,11 +1026,20 @@ extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double
     (void)hipGraphExecDestroy(F->graph);
     F->graph = nullptr;
   }
-  if (F->mode >= 3 && !F->xcd_built) DDMCHECK(build_xcd_schedule(ctx, F));
+  if (F->mode == 6 && F->w_state == 0) DDMCHECK(build_xcdw_schedule(ctx, F));
+  if (F->mode == 6 && F->w_state < 0) F->mode = 3; // rows wider than a tile: use the gather-based XCD engine
+  if (F->mode >= 3 && F->mode <= 5 && !F->xcd_built) DDMCHECK(build_xcd_schedule(ctx, F));
   hipGraph_t g = nullptr;
   HIPCHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
   int rc = DDM_OK;
-  if (F->mode == 5) {
+  if (F->mode == 6) {
+    const int64_t nn = F->n;
+    hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
+    hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(nn)), dim3(WG), 0, ctx->stream, nn, F->wlpos, F->wrows, d, F->wdperm);
+    hipLaunchKernelGGL(k_trsv_xcdw, dim3(TRSV_P_GRID), dim3(128), sizeof(WLds), ctx->stream, F->ngroups, F->wg, F->wlev, F->wchunk, F->wflag_off,
+                       F->widx, F->wvals, F->wdinv, F->wown, F->wdperm, F->wxp, F->wflags, F->xstate, F->err, (unsigned long long *)nullptr);
+    hipLaunchKernelGGL(k_w_permute_out, dim3(grid_for(nn)), dim3(WG), 0, ctx->stream, nn, F->wupos, F->wrows, F->wxp, x);
+  } else if (F->mode == 5) {
     hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
     (void)hipMemsetAsync(F->ywork, 0xFF, sizeof(double) * (size_t)F->n, ctx->stream); // sentinel = "not computed yet"
     (void)hipMemsetAsync(x, 0xFF, sizeof(double) * (size_t)F->n, ctx->stream);

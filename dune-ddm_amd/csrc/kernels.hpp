@@ -986,6 +986,336 @@ __global__ __launch_bounds__(128) void k_trsv_xcd2(int ngroups, const GroupDesc 
 }
 
 // ---------------------------------------------------------------------------------------------
+// "xcdw" engine: XCD-local solve on LEVEL-PERMUTED vectors with LDS-staged dependency windows.
+// Stamps of the xcd2 engine (ddm_ilu0_debug_stamps, 216^3): per 64-row chunk 0.8 us go into 17 x 64
+// scattered 8-byte L2 reads and 1.6 us into draining 64 scattered stores -- every 8-byte value costs a
+// whole L2 line transaction.  Here the solve runs in level order on xp[pos] (pos = position in the
+// level-sorted row list): the 64 results of a chunk are ONE contiguous 512-byte store, and because level
+// sorting preserves the spatial order inside a level, the dependencies of a chunk fall into a few short
+// position runs ("windows", found on the host).  A wave copies its windows into LDS with coalesced
+// loads and gathers from LDS.  Chunks whose windows do not fit (unstructured matrices) gather from
+// global memory by position.  Hand-off protocol, grouping by XCD, loader wave: as in k_trsv_xcd2.
+constexpr int TRSV_W_MAXPIECE = 24;  // windows are cut into pieces of <= 64 positions = one coalesced load each
+constexpr int TRSV_W_STAGE = 64 * TRSV_W_MAXPIECE; // doubles of LDS staging per compute wave
+struct WChunk {
+  int32_t npiece;                // 0 => gather directly from global memory (entries hold positions)
+  int32_t staged;
+  int32_t lo[TRSV_W_MAXPIECE];   // first position of the piece
+  uint16_t off[TRSV_W_MAXPIECE]; // offset of the piece in the staging buffer
+  uint8_t len[TRSV_W_MAXPIECE];  // 1..64
+};
+constexpr int TRSV_W_META_DWORDS = (int)(sizeof(WChunk) / 4);
+struct WLevel {
+  int32_t m, w;
+  int64_t pos_off, ent_off, chunk_off; // first position / first ELL entry / first WChunk of the level
+};
+struct WTile {
+  double s0[64];                 // L: permuted right-hand side; U: inverse pivot
+  int32_t idx[TRSV_UNROLL][64];  // staging index (or position, if nwin == 0)
+  double vv[TRSV_UNROLL][64];
+  WChunk meta;
+};
+struct WLds {
+  WTile tile[TRSV_L_SLOTS];
+  double stage[TRSV_W_STAGE];
+  unsigned produced, consumed;
+};
+// xp[pos] <- d[row(pos)] for the L positions of every group; x[row(pos)] <- xp[pos] for the U positions
+__global__ void k_w_permute_in(int64_t n, const int64_t *__restrict__ lpos, const int32_t *__restrict__ rows, const double *__restrict__ d,
+                               double *__restrict__ dperm)
+{
+  for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG) dperm[lpos[i]] = d[rows[lpos[i]]];
+}
+__global__ void k_w_permute_out(int64_t n, const int64_t *__restrict__ upos, const int32_t *__restrict__ rows, const double *__restrict__ xp,
+                                double *__restrict__ x)
+{
+  for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG) x[rows[upos[i]]] = xp[upos[i]];
+}
+
+struct WWork { // work items (level, chunk) of one wave, in processing order
+  const GroupDesc *groups;
+  const WLevel *lev_;
+  int ngroups, gstep, grp, lev, c, rank, W;
+  __device__ bool valid() const { return grp < ngroups; }
+  __device__ void init(const GroupDesc *g, const WLevel *l, int ng, int first, int step, int rank_, int W_)
+  {
+    groups = g; lev_ = l; ngroups = ng; gstep = step; grp = first; lev = 0; c = rank_; rank = rank_; W = W_;
+    settle();
+  }
+  __device__ void settle()
+  {
+    while (grp < ngroups) {
+      const GroupDesc G = groups[grp];
+      const int nlev = G.nlevL + G.nlevU;
+      while (lev < nlev) {
+        if (c < ((lev_[G.lev_off + lev].m + 63) >> 6)) return;
+        ++lev;
+        c = rank;
+      }
+      grp += gstep;
+      lev = 0;
+      c = rank;
+    }
+  }
+  __device__ void advance()
+  {
+    c += W;
+    settle();
+  }
+};
+
+__global__ __launch_bounds__(128) void k_trsv_xcdw(int ngroups, const GroupDesc *__restrict__ groups, const WLevel *__restrict__ levels,
+                                                    const WChunk *__restrict__ chunks, const int64_t *__restrict__ flag_off,
+                                                    const int32_t *__restrict__ idxA, const double *__restrict__ valsA,
+                                                    const double *__restrict__ dinvA, const int32_t *__restrict__ ownA,
+                                                    const double *__restrict__ dperm, double *xp, unsigned *flags, XcdState *st, unsigned *err,
+                                                    unsigned long long *stamps)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  WLds &S = *reinterpret_cast<WLds *>(smem_raw);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  __shared__ unsigned sh_xcc, sh_t, sh_gt, sh_fail;
+  if (threadIdx.x == 0) {
+    S.produced = 0;
+    S.consumed = 0;
+    const unsigned xcc = hw_xcc_id();
+    sh_xcc = xcc;
+    sh_t = __hip_atomic_fetch_add(&st->tickets[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh_gt = __hip_atomic_fetch_add(&st->global_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&st->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned fail_ = 0;
+    for (unsigned spins = 0; __hip_atomic_load(&st->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x; ++spins) {
+      if (spins > (1u << 22)) {
+        __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fail_ = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    sh_fail = fail_;
+  }
+  __syncthreads();
+  if (sh_fail) return;
+  const unsigned xcc = sh_xcc, t = sh_t, gt = sh_gt;
+  const unsigned epoch = __hip_atomic_load(&st->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned tk = lane < 8 ? __hip_atomic_load(&st->tickets[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+  const int owners = ngroups < 8 ? ngroups : 8;
+  const bool local_ok = __all(lane >= owners || tk > 0u);
+  int W, rank, first, step;
+  bool wt;
+  if (local_ok) {
+    W = (int)__shfl((int)tk, (int)xcc, 64);
+    if (W > TRSV_X_MAXW) W = TRSV_X_MAXW;
+    rank = (int)t; first = (int)xcc; step = 8; wt = false;
+  } else {
+    W = (int)gridDim.x < TRSV_X_MAXW ? (int)gridDim.x : TRSV_X_MAXW;
+    rank = (int)gt; first = 0; step = 1; wt = true;
+  }
+  if (rank >= W) return;
+  WWork wk;
+  wk.init(groups, levels, ngroups, first, step, rank, W);
+  volatile unsigned *produced = &S.produced;
+  volatile unsigned *consumed = &S.consumed;
+
+  if (wave == 1) {
+    // ---------------- loader: HBM -> LDS tile ring, two tiles in flight ----------------
+    struct Regs {
+      int32_t w, metaw[2];
+      double s0;
+      int32_t idx[TRSV_UNROLL];
+      double vv[TRSV_UNROLL];
+    };
+    static_assert(sizeof(WChunk) % 4 == 0 && TRSV_W_META_DWORDS <= 64, "WChunk layout");
+    auto issue = [&](Regs &R, const WWork &k) {
+      const GroupDesc G = groups[k.grp];
+      const WLevel D = levels[G.lev_off + k.lev];
+      const bool upper = k.lev >= G.nlevL;
+      const int r = (k.c << 6) + lane;
+      const int rr = r < D.m ? r : D.m - 1;
+      R.w = D.w;
+      R.s0 = upper ? dinvA[D.pos_off + rr] : dperm[D.pos_off + rr];
+      const int32_t *mp = reinterpret_cast<const int32_t *>(chunks + D.chunk_off + k.c);
+      R.metaw[0] = lane < TRSV_W_META_DWORDS ? mp[lane] : 0;
+      const int32_t *idx = idxA + D.ent_off;
+      const double *vals = valsA + D.ent_off;
+#pragma unroll
+      for (int u = 0; u < TRSV_UNROLL; ++u) {
+        R.idx[u] = 0;
+        R.vv[u] = 0.0;
+        if (u < D.w) {
+          R.idx[u] = idx[(int64_t)u * D.m + rr];
+          R.vv[u] = vals[(int64_t)u * D.m + rr];
+        }
+      }
+    };
+    Regs A, B;
+    if (!wk.valid()) return;
+    issue(A, wk);
+    for (unsigned seq = 0;; ++seq) {
+      wk.advance();
+      const bool more = wk.valid();
+      if (more) issue(B, wk);
+      for (unsigned spins = 0; seq >= *consumed + TRSV_L_SLOTS; ++spins) {
+        if (spins > (1u << 24)) {
+          if (lane == 0) __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      WTile &T = S.tile[seq % TRSV_L_SLOTS];
+      T.s0[lane] = A.s0;
+      if (lane < TRSV_W_META_DWORDS) reinterpret_cast<int32_t *>(&T.meta)[lane] = A.metaw[0];
+#pragma unroll
+      for (int u = 0; u < TRSV_UNROLL; ++u)
+        if (u < A.w) {
+          T.idx[u][lane] = A.idx[u];
+          T.vv[u][lane] = A.vv[u];
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) *produced = seq + 1;
+      if (!more) return;
+      A = B;
+    }
+  }
+
+  // ---------------- compute wave ----------------
+  const bool stamp = stamps != nullptr && rank == 0 && (local_ok ? xcc == 0 : true);
+  unsigned long long t_tile = 0, t_poll = 0, t_gather = 0, t_drain = 0, n_items = 0, n_direct = 0, t_begin = 0, tq = 0;
+#define DDM_STAMP(acc)                                                 \
+  if (stamp) {                                                         \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();      \
+    acc += now_ - tq;                                                  \
+    tq = now_;                                                         \
+  }
+  if (stamp) t_begin = tq = __builtin_amdgcn_s_memtime();
+  for (unsigned seq = 0; wk.valid(); ++seq) {
+    const int grp = wk.grp, lev = wk.lev, c = wk.c;
+    const GroupDesc G = groups[grp];
+    const WLevel D = levels[G.lev_off + lev];
+    const bool upper = lev >= G.nlevL;
+    unsigned *gflags = flags + flag_off[grp];
+    for (unsigned spins = 0; *produced <= seq; ++spins) {
+      if (spins > (1u << 24)) {
+        if (lane == 0) __hip_atomic_store(err, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    const WTile &T = S.tile[seq % TRSV_L_SLOTS];
+    const int r = (c << 6) + lane;
+    const bool act = r < D.m;
+    const double s0 = T.s0[lane];
+    int32_t idx[TRSV_UNROLL];
+    double vv[TRSV_UNROLL];
+#pragma unroll
+    for (int u = 0; u < TRSV_UNROLL; ++u) {
+      idx[u] = 0;
+      vv[u] = 0.0;
+      if (u < D.w) {
+        idx[u] = T.idx[u][lane];
+        vv[u] = T.vv[u][lane];
+      }
+    }
+    const int npiece = T.meta.npiece;
+    const int plo = lane < TRSV_W_MAXPIECE ? T.meta.lo[lane] : 0;
+    const int plen = lane < TRSV_W_MAXPIECE ? (int)T.meta.len[lane] : 0;
+    const int poff = lane < TRSV_W_MAXPIECE ? (int)T.meta.off[lane] : 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) *consumed = seq + 1;
+    DDM_STAMP(t_tile)
+    if (npiece == 0) n_direct += 1;
+    // previous level of this group complete?
+    if (lev > 0 && c == rank) {
+      const unsigned *fp = gflags + (int64_t)(lev - 1) * TRSV_X_MAXW;
+      const int ncp = (levels[G.lev_off + lev - 1].m + 63) >> 6;
+      const int nact = ncp < W ? ncp : W;
+      for (unsigned spins = 0;; ++spins) {
+        const unsigned v = lane < nact ? __hip_atomic_load(fp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+        if (__all(v == epoch)) break;
+        if (spins > (1u << 22)) {
+          if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    DDM_STAMP(t_poll)
+    // own forward value (U phase): one scattered read per row
+    const int rr = act ? r : D.m - 1;
+    double s = s0;
+    if (upper) s = ld_sc1(xp + ownA[D.pos_off + rr]);
+    double xv[TRSV_UNROLL];
+    if (npiece > 0) {
+      // stage the dependency windows: one coalesced sc1 load per piece, 8 in flight, then LDS
+      for (int p0 = 0; p0 < npiece; p0 += 8) {
+        double buf[8];
+        int offs[8], lens[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int lo = __shfl(plo, p0 + u, 64);
+          lens[u] = p0 + u < npiece ? __shfl(plen, p0 + u, 64) : 0;
+          offs[u] = __shfl(poff, p0 + u, 64);
+          buf[u] = 0.0;
+          if (p0 + u < npiece) buf[u] = ld_sc1(xp + lo + (lane < lens[u] ? lane : 0));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (lane < lens[u]) S.stage[offs[u] + lane] = buf[u];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < TRSV_UNROLL; ++u) {
+        xv[u] = 0.0;
+        if (u < D.w) xv[u] = S.stage[idx[u]];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < TRSV_UNROLL; ++u) {
+        xv[u] = 0.0;
+        if (u < D.w) xv[u] = ld_sc1(xp + idx[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TRSV_UNROLL; ++u) s -= vv[u] * xv[u];
+    for (int k = TRSV_UNROLL; k < D.w; ++k) // rows wider than a tile (rare): the rest by position from global memory
+      s -= valsA[D.ent_off + (int64_t)k * D.m + rr] * ld_sc1(xp + idxA[D.ent_off + (int64_t)k * D.m + rr]);
+    if (stamp) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      DDM_STAMP(t_gather)
+    }
+    const double out = upper ? s * s0 : s;
+    if (act) {
+      if (wt) st_sc1(xp + D.pos_off + r, out);
+      else xp[D.pos_off + r] = out; // contiguous: one 512-byte store per wave
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // staging buffer is free again
+    wk.advance();
+    const bool level_done = !wk.valid() || wk.grp != grp || wk.lev != lev;
+    if (level_done) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) {
+        unsigned *f = gflags + (int64_t)lev * TRSV_X_MAXW + rank;
+        if (wt) __hip_atomic_store(f, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *(volatile unsigned *)f = epoch;
+      }
+    }
+    DDM_STAMP(t_drain)
+    n_items += 1;
+  }
+  if (stamp && lane == 0) {
+    stamps[0] = t_tile;
+    stamps[1] = t_poll;
+    stamps[2] = t_gather;
+    stamps[3] = t_drain;
+    stamps[4] = n_items;
+    stamps[5] = __builtin_amdgcn_s_memtime() - t_begin;
+    stamps[6] = n_direct;
+  }
+#undef DDM_STAMP
+}
+
+// ---------------------------------------------------------------------------------------------
 // K2 extend (schwarz.hh:121-122), K5 restrict (schwarz.hh:146), K4 POU scaling (schwarz.hh:141)
 __global__ void k_extend(int64_t n, const int32_t *__restrict__ ext_map, const double *__restrict__ d, double *__restrict__ dov)
 {

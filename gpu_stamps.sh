@@ -23,8 +23,10 @@ ctx.sync()
 print("solve ms", (time.time()-t)*100, "levels", F.num_levels())
 st = F.debug_stamps(d, x)
 items = int(st[4])
-tick_us = 0.01   # s_memtime: 100 MHz
-print("items", items, "total us", st[5]*tick_us, "per item us", st[5]*tick_us/items)
+print("direct chunks", int(st[6]))
+tick_us = 1.0
+tot = float(st[5])
+print("items", items, "per item share of the kernel:")
 for name, v in zip(("tile","poll","gather","drain"), st[:4]):
-    print(f"  {name:7s} {v*tick_us/items:7.3f} us per item")
+    print(f"  {name:7s} {100.0*float(v)/tot:6.1f} %")
 PY
