@@ -91,6 +91,7 @@ SYMBOLS = {
     "ddm_combined_destroy": (None, [_P]),
     "ddm_combined_apply": (_I32, [_P, _P, _P, _P]),
     "ddm_cg_solve": (_I32, [_P, _P, _P, _P, _P, _D, _I32, _I32, _P, ctypes.POINTER(SolveResult)]),
+    "ddm_gmres_solve": (_I32, [_P, _P, _P, _P, _P, _D, _I32, _I32, _P, ctypes.POINTER(SolveResult)]),
     "ddm_cg_begin": (_I32, [_P, _P, _P, _P, _P, _PP]),
     "ddm_cg_steps": (_I32, [_P, _P, _I32]),
     "ddm_cg_defect": (_I32, [_P, _P, ctypes.POINTER(ctypes.c_double)]),
@@ -411,6 +412,16 @@ def cg_solve(ctx: Context, op: NonOverlappingOperator, prec: CombinedPreconditio
     hist = np.zeros(max(maxit, fixed_iterations) + 1, dtype=np.float64) if history else None
     ctx.check(ctx.lib.ddm_cg_solve(ctx.h, op.h, prec.h, _ptr(x), _ptr(b), float(reduction), int(maxit), int(fixed_iterations),
                                    _hp(hist), ctypes.byref(res)))
+    return res, (hist[:res.iterations + 1] if history else None)
+
+
+def gmres_solve(ctx: Context, op: NonOverlappingOperator, prec: CombinedPreconditioner, x, b, reduction=1e-10, maxit=1000, restart=100,
+                history=True):
+    """dune-istl RestartedGMResSolver::apply ([solver] type = restartedgmressolver, examples/poisson.ini:12-17)."""
+    res = SolveResult()
+    hist = np.zeros(maxit + 1, dtype=np.float64) if history else None
+    ctx.check(ctx.lib.ddm_gmres_solve(ctx.h, op.h, prec.h, _ptr(x), _ptr(b), float(reduction), int(maxit), int(restart), _hp(hist),
+                                      ctypes.byref(res)))
     return res, (hist[:res.iterations + 1] if history else None)
 
 

@@ -404,6 +404,7 @@ struct ddm_ilu0 {
   unsigned *xflags = nullptr;
   XcdState *xstate = nullptr;
   double *xdperm = nullptr;     // right-hand side permuted into level order (loader engine)
+  int64_t *xlpos = nullptr;     // positions of the L parts (only those need the permuted right-hand side)
   int64_t xnrows = 0;
   // windowed level-permuted engine (mode 6)
   int w_state = 0;              // 0 not built, 1 built, -1 not applicable (rows wider than a tile)
@@ -597,6 +598,7 @@ extern "C" void ddm_ilu0_destroy(ddm_ilu0 *F)
   (void)hipFree(F->xflags);
   (void)hipFree(F->xstate);
   (void)hipFree(F->xdperm);
+  (void)hipFree(F->xlpos);
   (void)hipFree(F->wg);
   (void)hipFree(F->wlev);
   (void)hipFree(F->wchunk);
@@ -727,6 +729,17 @@ static int build_xcd_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
   HIPCHECK(ctx, hipMalloc((void **)&F->xstate, sizeof(XcdState)));
   HIPCHECK(ctx, hipMemset(F->xstate, 0, sizeof(XcdState)));
   F->xnrows = (int64_t)rows.size();
+  {
+    std::vector<int64_t> lpos;
+    lpos.reserve((size_t)A->nrows);
+    int64_t base = 0;
+    for (int b = 0; b < nb; ++b) {
+      const int64_t nbk = F->h_block_ptr[b + 1] - F->h_block_ptr[b];
+      for (int64_t p = 0; p < nbk; ++p) lpos.push_back(base + p);
+      base += 2 * nbk;
+    }
+    DDMCHECK(upload(ctx, lpos.data(), (int64_t)lpos.size(), &F->xlpos));
+  }
   HIPCHECK(ctx, hipMalloc((void **)&F->xdperm, sizeof(double) * (size_t)std::max<int64_t>(F->xnrows, 1)));
   HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_xcd2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TrsvLds)));
   HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_xcd2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TrsvLds)));
@@ -1005,7 +1018,7 @@ extern "C" int ddm_ilu0_debug_stamps(ddm_ctx *ctx, ddm_ilu0 *F, const double *d,
   }
   if (!F->xcd_built) DDMCHECK(build_xcd_schedule(ctx, F));
   hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
-  hipLaunchKernelGGL(k_permute_rhs, dim3(grid_for(F->xnrows)), dim3(WG), 0, ctx->stream, F->xnrows, F->xrows, d, F->xdperm);
+  hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, F->xlpos, F->xrows, d, F->xdperm);
   hipLaunchKernelGGL(k_trsv_xcd2<false>, dim3(TRSV_P_GRID), dim3(128), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off, F->xrows,
                      F->xcols, F->xvals, F->xdinv, F->xdperm, x, F->ywork, F->xflags, F->xstate, F->err, st);
   int rc = ddm_memcpy_d2h(ctx, out_host, st, 48);
@@ -1043,12 +1056,12 @@ extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double
     hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
     (void)hipMemsetAsync(F->ywork, 0xFF, sizeof(double) * (size_t)F->n, ctx->stream); // sentinel = "not computed yet"
     (void)hipMemsetAsync(x, 0xFF, sizeof(double) * (size_t)F->n, ctx->stream);
-    hipLaunchKernelGGL(k_permute_rhs, dim3(grid_for(F->xnrows)), dim3(WG), 0, ctx->stream, F->xnrows, F->xrows, d, F->xdperm);
+    hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, F->xlpos, F->xrows, d, F->xdperm);
     hipLaunchKernelGGL(k_trsv_xcd2<true>, dim3(TRSV_P_GRID), dim3(128), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off,
                        F->xrows, F->xcols, F->xvals, F->xdinv, F->xdperm, x, F->ywork, F->xflags, F->xstate, F->err, (unsigned long long *)nullptr);
   } else if (F->mode == 4) {
     hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
-    hipLaunchKernelGGL(k_permute_rhs, dim3(grid_for(F->xnrows)), dim3(WG), 0, ctx->stream, F->xnrows, F->xrows, d, F->xdperm);
+    hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, F->xlpos, F->xrows, d, F->xdperm);
     hipLaunchKernelGGL(k_trsv_xcd2<false>, dim3(TRSV_P_GRID), dim3(128), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off,
                        F->xrows, F->xcols, F->xvals, F->xdinv, F->xdperm, x, F->ywork, F->xflags, F->xstate, F->err, (unsigned long long *)nullptr);
   } else if (F->mode == 3) {
@@ -1704,4 +1717,151 @@ extern "C" int ddm_cg_solve(ddm_ctx *ctx, ddm_op *op, ddm_combined *prec, double
   }
   ddm_cg_end(ctx, S);
   return rc;
+}
+
+// ---- restarted GMRES -----------------------------------------------------------------------------
+// dune-istl RestartedGMResSolver::apply (DUNE 2.10 solvers.hh; not in the snapshot, restated from the
+// published implementation): left preconditioning, modified Gram-Schmidt, Givens rotations; the
+// monitored quantity is the norm of the PRECONDITIONED defect.  Selected by [solver] type =
+// restartedgmressolver in examples/poisson.ini:12-17 (restart = 100) and the default of
+// dune/ddm/twolevel_schwarz.hh:121-130 (restart = 30).  Krylov basis, dots and updates stay on the
+// device; per iteration the i+2 Hessenberg entries are read back for the rotations on the host.
+static void gmres_generate_rotation(double dx, double dy, double &cs, double &sn)
+{
+  const double ndx = std::fabs(dx), ndy = std::fabs(dy);
+  if (ndy < 1e-15) {
+    cs = 1.0;
+    sn = 0.0;
+  } else if (ndx < 1e-15) {
+    cs = 0.0;
+    sn = 1.0;
+  } else if (ndy > ndx) {
+    const double t = ndx / ndy;
+    cs = 1.0 / std::sqrt(1.0 + t * t);
+    sn = cs;
+    cs *= t;
+    sn *= dx / ndx;
+    sn *= dy / ndy;
+  } else {
+    const double t = ndy / ndx;
+    cs = 1.0 / std::sqrt(1.0 + t * t);
+    sn = cs;
+    sn *= dy / dx;
+  }
+}
+static void gmres_apply_rotation(double &dx, double &dy, double cs, double sn)
+{
+  const double t = cs * dx + sn * dy;
+  dy = -sn * dx + cs * dy;
+  dx = t;
+}
+
+extern "C" int ddm_gmres_solve(ddm_ctx *ctx, ddm_op *op, ddm_combined *prec, double *x, double *b, double reduction, int maxit,
+                               int restart, double *hist_host, ddm_solve_result *res)
+{
+  if (!ctx || !op || !prec || !x || !b || !res || restart < 1) return fail(ctx, DDM_EINVAL, "ddm_gmres_solve: bad arguments");
+  const int64_t n = op->n;
+  const int m = restart;
+  const int G = grid_for(n);
+  double *V = nullptr, *w = nullptr, *hdev = nullptr;
+  HIPCHECK(ctx, hipMalloc((void **)&V, sizeof(double) * (size_t)std::max<int64_t>(n, 1) * (size_t)(m + 1)));
+  HIPCHECK(ctx, hipMalloc((void **)&w, sizeof(double) * (size_t)std::max<int64_t>(n, 1)));
+  HIPCHECK(ctx, hipMalloc((void **)&hdev, sizeof(double) * (size_t)(m + 2)));
+  auto v = [&](int k) { return V + (size_t)k * (size_t)n; };
+  auto cleanup = [&](int rc) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(V);
+    (void)hipFree(w);
+    (void)hipFree(hdev);
+    return rc;
+  };
+  std::vector<double> s(m + 1), cs(m), sn(m), hcol(m + 2), y(m);
+  std::vector<std::vector<double>> H(m + 1, std::vector<double>(m, 0.0));
+  int rc = ddm_op_applyscaleadd(ctx, op, -1.0, x, b); // b -= A x
+  if (!rc) rc = ddm_combined_apply(ctx, prec, v(0), b); // v0 = M^-1 b
+  double nn = 0.0;
+  if (!rc) rc = dot_device(ctx, n, op->owner, v(0), v(0), hdev);
+  if (!rc) rc = ddm_memcpy_d2h(ctx, &nn, hdev, sizeof(double));
+  if (rc) return cleanup(rc);
+  double norm = std::sqrt(nn);
+  const double def0 = norm;
+  res->def0 = def0;
+  res->iterations = 0;
+  res->converged = 0;
+  res->reduction = 1.0;
+  res->elapsed_s = 0.0;
+  if (hist_host) hist_host[0] = def0;
+  if (!(def0 == def0)) return cleanup(fail(ctx, DDM_ENUMERIC, "initial defect is NaN"));
+  if (def0 < 1e-30) {
+    res->converged = 1;
+    return cleanup(DDM_OK);
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  int j = 0;
+  bool conv = false;
+  while (j < maxit && !conv && !rc) {
+    hipLaunchKernelGGL(k_scal, dim3(G), dim3(WG), 0, ctx->stream, n, 1.0 / norm, v(0));
+    std::fill(s.begin(), s.end(), 0.0);
+    s[0] = norm;
+    int i = 0;
+    for (; i < m && j < maxit && !conv; ++i, ++j) {
+      rc = ddm_op_apply(ctx, op, v(i), v(i + 1));                 // v[i+1] = A v[i] (temporary)
+      if (!rc) rc = ddm_combined_apply(ctx, prec, w, v(i + 1));   // w = M^-1 A v[i]
+      for (int k = 0; k <= i && !rc; ++k) {                       // modified Gram-Schmidt
+        rc = dot_device(ctx, n, op->owner, v(k), w, hdev + k);
+        hipLaunchKernelGGL(k_axpy_negdev, dim3(G), dim3(WG), 0, ctx->stream, n, hdev + k, v(k), w);
+      }
+      if (!rc) rc = dot_device(ctx, n, op->owner, w, w, hdev + i + 1);
+      if (!rc) rc = ddm_memcpy_d2h(ctx, hcol.data(), hdev, sizeof(double) * (size_t)(i + 2));
+      if (rc) break;
+      for (int k = 0; k <= i; ++k) H[k][i] = hcol[k];
+      H[i + 1][i] = std::sqrt(hcol[i + 1]);
+      if (std::fabs(H[i + 1][i]) < 1e-80) {
+        rc = fail(ctx, DDM_ENUMERIC, "breakdown in GMRes - |w| == 0.0 after %d iterations", j);
+        break;
+      }
+      HIPCHECK(ctx, hipMemcpyAsync(v(i + 1), w, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream));
+      hipLaunchKernelGGL(k_scal, dim3(G), dim3(WG), 0, ctx->stream, n, 1.0 / H[i + 1][i], v(i + 1));
+      for (int k = 0; k < i; ++k) gmres_apply_rotation(H[k][i], H[k + 1][i], cs[k], sn[k]);
+      gmres_generate_rotation(H[i][i], H[i + 1][i], cs[i], sn[i]);
+      gmres_apply_rotation(H[i][i], H[i + 1][i], cs[i], sn[i]);
+      gmres_apply_rotation(s[i], s[i + 1], cs[i], sn[i]);
+      norm = std::fabs(s[i + 1]);
+      res->iterations = j + 1;
+      if (hist_host) hist_host[j + 1] = norm;
+      if (!(norm == norm)) {
+        rc = fail(ctx, DDM_ENUMERIC, "defect is NaN in iteration %d", j + 1);
+        break;
+      }
+      if (norm < def0 * reduction || norm < 1e-30) conv = true;
+    }
+    if (rc) break;
+    // update(w, i, H, s, v): solve the triangular system, w = sum_k y_k v[k]; x += w
+    for (int a = i - 1; a >= 0; --a) {
+      double t = s[a];
+      for (int c = a + 1; c < i; ++c) t -= H[a][c] * y[c];
+      y[a] = t / H[a][a];
+    }
+    HIPCHECK(ctx, hipMemsetAsync(w, 0, sizeof(double) * (size_t)n, ctx->stream));
+    for (int a = 0; a < i; ++a) hipLaunchKernelGGL(k_axpy, dim3(G), dim3(WG), 0, ctx->stream, n, y[a], v(a), w);
+    hipLaunchKernelGGL(k_axpy, dim3(G), dim3(WG), 0, ctx->stream, n, 1.0, w, x);
+    if (!conv && j < maxit) { // restart: b -= A w; v0 = M^-1 b
+      rc = ddm_op_applyscaleadd(ctx, op, -1.0, w, b);
+      if (!rc) rc = ddm_combined_apply(ctx, prec, v(0), b);
+      if (!rc) rc = dot_device(ctx, n, op->owner, v(0), v(0), hdev);
+      if (!rc) rc = ddm_memcpy_d2h(ctx, &nn, hdev, sizeof(double));
+      norm = std::sqrt(nn);
+    }
+  }
+  if (!rc && hipGetLastError() != hipSuccess) rc = fail(ctx, DDM_EHIP, "kernel launch failed in GMRES");
+  (void)hipStreamSynchronize(ctx->stream);
+  res->elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  res->converged = conv ? 1 : 0;
+  res->reduction = norm / def0;
+  if (!rc && prec->schwarz) {
+    int st = 0;
+    rc = ddm_ilu0_status(ctx, prec->schwarz->solver, &st);
+    if (!rc && st) rc = fail(ctx, DDM_ENUMERIC, "persistent triangular solve timed out waiting for a level (results invalid)");
+  }
+  return cleanup(rc);
 }

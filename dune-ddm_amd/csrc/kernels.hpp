@@ -1351,6 +1351,17 @@ __global__ void k_axpy(int64_t n, double a, const double *__restrict__ x, double
   for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG) y[i] += a * x[i];
 }
 
+// y -= (*h) x with the coefficient in device memory (modified Gram-Schmidt of restarted GMRES), x *= a
+__global__ void k_axpy_negdev(int64_t n, const double *__restrict__ h, const double *__restrict__ x, double *__restrict__ y)
+{
+  const double a = h[0];
+  for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG) y[i] -= a * x[i];
+}
+__global__ void k_scal(int64_t n, double a, double *__restrict__ x)
+{
+  for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG) x[i] *= a;
+}
+
 // ---------------------------------------------------------------------------------------------
 // halo exchange: pack (gather) and deterministic unpack (copy / add), SURVEY.md 2.3 C1-C4
 __global__ void k_pack(int64_t n, const int64_t *__restrict__ idx, const double *__restrict__ v, double *__restrict__ buf)

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import (CombinedPreconditioner, Context, torch_context, CsrMatrix, GalerkinPreconditioner, Halo, NonOverlappingOperator,
+from . import (CombinedPreconditioner, Context, torch_context, gmres_solve, CsrMatrix, GalerkinPreconditioner, Halo, NonOverlappingOperator,
                SchwarzPreconditioner, cg_solve, galerkin_products)
 from .problem import Decomposition, RankLocal
 
@@ -239,9 +239,15 @@ class TwoLevelSchwarz:
         return cache[dst][src]
 
     # -- solve -------------------------------------------------------------------------------
-    def solve(self, reduction=1e-10, maxit=1000, fixed_iterations=0, history=True, x0=None, b=None):
-        """v = 0; solver->apply(v, b, res)  (examples/poisson.cc:318-319).  Returns (res, hist, x)."""
+    def solve(self, reduction=1e-10, maxit=1000, fixed_iterations=0, history=True, x0=None, b=None, solver="cgsolver", restart=100):
+        """v = 0; solver->apply(v, b, res)  (examples/poisson.cc:318-319).  solver: "cgsolver" or
+        "restartedgmressolver" (the [solver] type keys of examples/poisson.ini).  Returns (res, hist, x)."""
         x = self.zeros(self.rl.n_o) if x0 is None else self.to_device(x0)
         bd = self.to_device(self.rl.b if b is None else b)
+        if solver == "restartedgmressolver":
+            res, hist = gmres_solve(self.ctx, self.op, self.prec, x, bd, reduction, maxit, restart, history)
+            return res, hist, x
+        if solver != "cgsolver":
+            raise NotImplementedError("solver type '" + str(solver) + "' (cgsolver and restartedgmressolver are available on the device)")
         res, hist = cg_solve(self.ctx, self.op, self.prec, x, bd, reduction, maxit, fixed_iterations, history)
         return res, hist, x

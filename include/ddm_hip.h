@@ -181,6 +181,14 @@ typedef struct {
 int ddm_cg_solve(ddm_ctx *ctx, ddm_op *op, ddm_combined *prec, double *x, double *b, double reduction, int maxit,
                  int fixed_iterations, double *hist_host, ddm_solve_result *res);
 
+/* dune-istl RestartedGMResSolver::apply (left-preconditioned, modified Gram-Schmidt, Givens rotations; the
+ * monitored norm is that of the preconditioned defect): [solver] type = restartedgmressolver,
+ * examples/poisson.ini:12-17; default of dune/ddm/twolevel_schwarz.hh:121-130.  Needed for the
+ * non-symmetric preconditioners (restricted Schwarz, multiplicative combination) and operators.
+ * hist_host (may be NULL): maxit+1 doubles. */
+int ddm_gmres_solve(ddm_ctx *ctx, ddm_op *op, ddm_combined *prec, double *x, double *b, double reduction, int maxit,
+                    int restart, double *hist_host, ddm_solve_result *res);
+
 /* The same loop in pieces, so that a caller can bracket an exact number of iterations
  * (bench.py): begin = "b -= A x; def0 = ||b||" (synchronous); steps = k iterations enqueued
  * without host synchronisation; defect = ||b|| of the last enqueued iteration (synchronous). */

@@ -440,3 +440,105 @@ def pou_coarse_space(pou, template_vecs=None):
             fin.append(v * (1.0 / np.sqrt(float(np.dot(v, v)))))
         out.append(fin)
     return out
+
+
+def _generate_plane_rotation(dx, dy):
+    ndx, ndy = abs(dx), abs(dy)
+    if ndy < 1e-15:
+        return 1.0, 0.0
+    if ndx < 1e-15:
+        return 0.0, 1.0
+    if ndy > ndx:
+        t = ndx / ndy
+        cs = 1.0 / np.sqrt(1.0 + t * t)
+        sn = cs
+        cs *= t
+        sn *= dx / ndx
+        sn *= dy / ndy
+        return cs, sn
+    t = ndy / ndx
+    cs = 1.0 / np.sqrt(1.0 + t * t)
+    return cs, cs * (dy / dx)
+
+
+def gmres_solve(op, sp_, prec, x, b, reduction=1e-10, maxit=1000, restart=100):
+    """dune-istl RestartedGMResSolver::apply (DUNE 2.10 solvers.hh, not in the snapshot; selected by
+    examples/poisson.ini:12-17 and dune/ddm/twolevel_schwarz.hh:121-130): left preconditioning,
+    modified Gram-Schmidt, Givens rotations; the monitored norm is the preconditioned defect.
+    Returns (iterations, converged, [norm_0, norm_1, ...])."""
+    P = len(x)
+    m = restart
+
+    def zeros():
+        return [np.zeros_like(v) for v in x]
+
+    op.applyscaleadd(-1.0, x, b)
+    V = [zeros()]
+    prec.apply(V[0], b)
+    norm = sp_.norm(V[0])
+    def0 = norm
+    hist = [def0]
+    if def0 < 1e-30:
+        return 0, True, hist
+    j, conv = 0, False
+    w = zeros()
+    while j < maxit and not conv:
+        for r in range(P):
+            V[0][r] *= 1.0 / norm
+        s = np.zeros(m + 1)
+        s[0] = norm
+        H = np.zeros((m + 1, m))
+        cs, sn = np.zeros(m), np.zeros(m)
+        i = 0
+        while i < m and j < maxit and not conv:
+            if len(V) <= i + 1:
+                V.append(zeros())
+            op.apply(V[i], V[i + 1])
+            for v in w:
+                v[:] = 0.0
+            prec.apply(w, V[i + 1])
+            for k in range(i + 1):
+                H[k, i] = sp_.dot(V[k], w)
+                for r in range(P):
+                    lib().orc_axpy(len(w[r]), -H[k, i], _p(V[k][r]), _p(w[r]))
+            H[i + 1, i] = sp_.norm(w)
+            if abs(H[i + 1, i]) < 1e-80:
+                raise ZeroDivisionError("breakdown in GMRes - |w| == 0.0")
+            for r in range(P):
+                V[i + 1][r][:] = w[r] * (1.0 / H[i + 1, i])
+            for k in range(i):
+                t = cs[k] * H[k, i] + sn[k] * H[k + 1, i]
+                H[k + 1, i] = -sn[k] * H[k, i] + cs[k] * H[k + 1, i]
+                H[k, i] = t
+            cs[i], sn[i] = _generate_plane_rotation(H[i, i], H[i + 1, i])
+            t = cs[i] * H[i, i] + sn[i] * H[i + 1, i]
+            H[i + 1, i] = -sn[i] * H[i, i] + cs[i] * H[i + 1, i]
+            H[i, i] = t
+            t = cs[i] * s[i] + sn[i] * s[i + 1]
+            s[i + 1] = -sn[i] * s[i] + cs[i] * s[i + 1]
+            s[i] = t
+            norm = abs(s[i + 1])
+            hist.append(norm)
+            i += 1
+            j += 1
+            if norm < def0 * reduction or norm < 1e-30:
+                conv = True
+        y = np.zeros(i)
+        for a in range(i - 1, -1, -1):
+            t = s[a]
+            for c in range(a + 1, i):
+                t -= H[a, c] * y[c]
+            y[a] = t / H[a, a]
+        upd = zeros()
+        for a in range(i):
+            for r in range(P):
+                lib().orc_axpy(len(upd[r]), float(y[a]), _p(V[a][r]), _p(upd[r]))
+        for r in range(P):
+            x[r] += upd[r]
+        if not conv and j < maxit:
+            op.applyscaleadd(-1.0, upd, b)
+            for v in V[0]:
+                v[:] = 0.0
+            prec.apply(V[0], b)
+            norm = sp_.norm(V[0])
+    return j, conv, hist

@@ -36,11 +36,14 @@ def oracle_objects(dec, schwarz_type="standard", mode="additive", coarse="pou", 
     return op, sp_, prec, sch, gal
 
 
-def oracle_solve(dec, reduction=1e-10, maxit=1000, **kw):
+def oracle_solve(dec, reduction=1e-10, maxit=1000, solver="cgsolver", restart=100, **kw):
     op, sp_, prec, sch, gal = oracle_objects(dec, **kw)
     x = [np.zeros(sd.n_o) for sd in dec.subs]
     b = [sd.b.copy() for sd in dec.subs]
-    it, conv, hist = ao.cg_solve(op, sp_, prec, x, b, reduction, maxit)
+    if solver == "restartedgmressolver":
+        it, conv, hist = ao.gmres_solve(op, sp_, prec, x, b, reduction, maxit, restart)
+    else:
+        it, conv, hist = ao.cg_solve(op, sp_, prec, x, b, reduction, maxit)
     return it, conv, hist, x
 
 

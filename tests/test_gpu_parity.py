@@ -190,3 +190,27 @@ def test_halo_exchange_bit_exact(ddm, torch_cuda):
         fn(vs)
         assert (vd.cpu().numpy() == np.concatenate(vs)).all()
     ctx.close()
+
+
+@pytest.mark.parametrize("cfg", [
+    # the reference's shipped configuration: restricted additive Schwarz + multiplicative coarse level + GMRES (examples/poisson.ini)
+    dict(N=(17, 16, 15), P=(2, 2, 2), overlap=2, stype="restricted", mode="multiplicative", restart=100),
+    dict(N=(17, 16, 15), P=(2, 2, 2), overlap=2, stype="restricted", mode="additive", restart=6),       # exercises restarts
+    dict(N=(30, 27), P=(2, 2), overlap=1, stype="standard", mode="additive", restart=30),               # TwoLevelSchwarzSolver default (twolevel_schwarz.hh:121-130)
+])
+def test_gmres_history_matches_oracle(ddm, torch_cuda, cfg):
+    """restartedgmressolver: identical iteration count, per-iteration (preconditioned) defect norms within tolerance."""
+    from dune_ddm_amd.solver import TwoLevelSchwarz
+    from tests.oracle_bridge import oracle_solve
+    dec = _build(ddm, cfg["N"], cfg["P"], overlap=cfg["overlap"])
+    tl = TwoLevelSchwarz(dec, coarse="pou", schwarz_type=cfg["stype"], mode=cfg["mode"])
+    res, hist, x = tl.solve(reduction=1e-10, maxit=200, solver="restartedgmressolver", restart=cfg["restart"])
+    it, conv, hist_o, xo = oracle_solve(dec, reduction=1e-10, maxit=200, solver="restartedgmressolver", restart=cfg["restart"], coarse="pou",
+                                        schwarz_type=cfg["stype"], mode=cfg["mode"])
+    assert res.converged and conv and res.iterations == it
+    ho = np.array(hist_o)
+    assert (np.abs(hist - ho) <= RTOL_HIST * ho + 1e-12 * ho[0]).all()
+    assert _relerr(x.cpu().numpy(), np.concatenate(xo)) < 1e-8
+    with pytest.raises(NotImplementedError):
+        tl.solve(solver="bicgstabsolver")
+    tl.ctx.close()
