@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", type=int, default=216, help="nodes per axis (216 -> 10M DoF)")
     ap.add_argument("--overlap", type=int, default=2)
+    ap.add_argument("--parts", type=int, default=2, help="subdomains per axis (2 -> 8 subdomains; 1 = BASELINE config 2: one subdomain, ILU(0)-CG)")
     ap.add_argument("--coarse", default="auto", choices=["auto", "geneo", "pou", "none"])
     ap.add_argument("--nev", type=int, default=20)
     ap.add_argument("--no-solve", action="store_true", help="skip the full solve to 1e-10 (iteration count / residual check)")
@@ -74,10 +75,14 @@ def main():
     # ---- setup (host): what DUNE/PDELab + dune-ddm's L3 hand to the hot path -------------------
     t_setup0 = time.perf_counter()
     G = args.grid
-    grid = synth.StructuredPoisson((G, G, G), (2, 2, 2))
+    P = args.parts
+    assert (P ** 3) % world == 0, "number of subdomains must be a multiple of the number of GPUs"
+    grid = synth.StructuredPoisson((G, G, G), (P, P, P))
     coarse = args.coarse
     if coarse == "auto":
         coarse = "geneo" if hasattr(pkg, "GENEO_AVAILABLE") and pkg.GENEO_AVAILABLE else "pou"
+    if P == 1:
+        coarse = "none"     # a single subdomain has no overlap region: ILU(0)-preconditioned CG
     dec = build_structured(grid, overlap=args.overlap, pou_type="distance", shrink=0, neumann=(coarse == "geneo"))
     t_host = time.perf_counter() - t_setup0
     log(rank, f"host setup (assembly, overlap extension, POU): {t_host:.1f} s")
@@ -152,7 +157,7 @@ def main():
         try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command (profiles/), gfx950-corrected
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_b_pmc_traffic_grid216.json")))
             if G == 216 and engine in pmc.get("engine_kernels", {}):
-                traffic = pmc["kernels"][pmc["engine_kernels"][engine]]["hbm_bytes_per_dispatch_corrected"] * (8 // world) / 8.0
+                traffic = pmc["kernels"][pmc["engine_kernels"][engine]]["hbm_bytes_per_dispatch_corrected"] / world if P == 2 else None
         except Exception:
             traffic = None
         roofline = {"bound": "hbm", "kernel": f"ILU(0) triangular solve: {kname}",
@@ -173,11 +178,11 @@ def main():
         from tests.oracle_bridge import oracle_time_iterations
         threads = max(1, min(args.cpu_threads, os.cpu_count() or 1, dec.nsub))
         ao.set_threads(threads)
-        basis_o = "pou" if coarse == "pou" else ("none" if coarse == "none" else tl.host_basis())
+        basis_o = coarse if coarse in ("pou", "none") else tl.host_basis()
         t_cpu, it_cpu = oracle_time_iterations(dec, args.cpu_iters, coarse=basis_o, schwarz_type="standard", mode="additive")
         ao.set_threads(1)
         cpu = {"value": it_cpu / t_cpu, "unit": "iterations/s", "cores": threads, "kind": "port",
-               "sample": f"{it_cpu} CG iterations of the same {G}^3 / 8-subdomain problem (setup excluded), one host thread per subdomain"}
+               "sample": f"{it_cpu} CG iterations of the same {G}^3 / {P ** 3}-subdomain problem (setup excluded), one host thread per subdomain"}
         log(rank, f"cpu_baseline: {it_cpu} iterations in {t_cpu:.1f} s on {threads} threads")
 
     if rank == 0:
@@ -186,9 +191,9 @@ def main():
             "value": its_per_s, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"3D Q1 Poisson {G}^3 = {ndof} DoF, 8 overlapping subdomains (2x2x2, overlap {args.overlap}), "
+            "config": {"workload": f"3D Q1 Poisson {G}^3 = {ndof} DoF, {P ** 3} overlapping subdomains ({P}x{P}x{P}, overlap {args.overlap}), "
                                    f"ILU(0) subdomain solves, coarse space '{coarse}' (K = {0 if tl.galerkin is None else tl.K}), additive, CG",
-                       "subdomains_per_gpu": 8 // world, "parallelism": f"dd{world}"},
+                       "subdomains_per_gpu": (P ** 3) // world, "parallelism": f"dd{world}"},
             "dof_iters_per_sec": ndof * its_per_s,
             "solve": solve_info,
             "setup_s": {"host": t_host, "device": t_dev},

@@ -36,6 +36,7 @@ struct ddm_ctx {
   void *user = nullptr;
   double *partial = nullptr; // RED_MAX_BLOCKS doubles
   double *scal = nullptr;    // 16 device scalars
+  int num_cu = 256;           // compute units of the device: persistent kernels launch at most this many workgroups
   bool timing = false;
   std::map<std::string, TimerEntry> timers;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -61,6 +62,9 @@ static int fail(ddm_ctx *ctx, int code, const char *fmt, ...)
     int rc_ = (call);             \
     if (rc_ != DDM_OK) return rc_; \
   } while (0)
+
+// single-launch triangular solves need every workgroup resident: one workgroup per CU at most
+static inline int persistent_grid(const ddm_ctx *ctx) { return std::max(8, std::min(TRSV_P_GRID, ctx->num_cu) / 8 * 8); }
 
 static inline int grid_for(int64_t n, int per_block = WG, int cap = 2048)
 {
@@ -154,6 +158,10 @@ extern "C" int ddm_ctx_create(int device, void *hip_stream, ddm_ctx **out)
     return DDM_EHIP;
   }
   (void)hipMemset(ctx->scal, 0, sizeof(double) * 16);
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cu = prop.multiProcessorCount;
+  }
   *out = ctx;
   return DDM_OK;
 }
@@ -1009,7 +1017,7 @@ extern "C" int ddm_ilu0_debug_stamps(ddm_ctx *ctx, ddm_ilu0 *F, const double *d,
     const int64_t nn = F->n;
     hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
     hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(nn)), dim3(WG), 0, ctx->stream, nn, F->wlpos, F->wrows, d, F->wdperm);
-    hipLaunchKernelGGL(k_trsv_xcdw, dim3(TRSV_P_GRID), dim3(128), sizeof(WLds), ctx->stream, F->ngroups, F->wg, F->wlev, F->wchunk, F->wflag_off,
+    hipLaunchKernelGGL(k_trsv_xcdw, dim3(persistent_grid(ctx)), dim3(128), sizeof(WLds), ctx->stream, F->ngroups, F->wg, F->wlev, F->wchunk, F->wflag_off,
                        F->widx, F->wvals, F->wdinv, F->wown, F->wdperm, F->wxp, F->wflags, F->xstate, F->err, st);
     hipLaunchKernelGGL(k_w_permute_out, dim3(grid_for(nn)), dim3(WG), 0, ctx->stream, nn, F->wupos, F->wrows, F->wxp, x);
     int rc6 = ddm_memcpy_d2h(ctx, out_host, st, 56);
@@ -1019,7 +1027,7 @@ extern "C" int ddm_ilu0_debug_stamps(ddm_ctx *ctx, ddm_ilu0 *F, const double *d,
   if (!F->xcd_built) DDMCHECK(build_xcd_schedule(ctx, F));
   hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
   hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, F->xlpos, F->xrows, d, F->xdperm);
-  hipLaunchKernelGGL(k_trsv_xcd2<false>, dim3(TRSV_P_GRID), dim3(128), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off, F->xrows,
+  hipLaunchKernelGGL(k_trsv_xcd2<false>, dim3(persistent_grid(ctx)), dim3(128), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off, F->xrows,
                      F->xcols, F->xvals, F->xdinv, F->xdperm, x, F->ywork, F->xflags, F->xstate, F->err, st);
   int rc = ddm_memcpy_d2h(ctx, out_host, st, 48);
   (void)hipFree(st);
@@ -1049,7 +1057,7 @@ extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double
     const int64_t nn = F->n;
     hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
     hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(nn)), dim3(WG), 0, ctx->stream, nn, F->wlpos, F->wrows, d, F->wdperm);
-    hipLaunchKernelGGL(k_trsv_xcdw, dim3(TRSV_P_GRID), dim3(128), sizeof(WLds), ctx->stream, F->ngroups, F->wg, F->wlev, F->wchunk, F->wflag_off,
+    hipLaunchKernelGGL(k_trsv_xcdw, dim3(persistent_grid(ctx)), dim3(128), sizeof(WLds), ctx->stream, F->ngroups, F->wg, F->wlev, F->wchunk, F->wflag_off,
                        F->widx, F->wvals, F->wdinv, F->wown, F->wdperm, F->wxp, F->wflags, F->xstate, F->err, (unsigned long long *)nullptr);
     hipLaunchKernelGGL(k_w_permute_out, dim3(grid_for(nn)), dim3(WG), 0, ctx->stream, nn, F->wupos, F->wrows, F->wxp, x);
   } else if (F->mode == 5) {
@@ -1057,26 +1065,26 @@ extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double
     (void)hipMemsetAsync(F->ywork, 0xFF, sizeof(double) * (size_t)F->n, ctx->stream); // sentinel = "not computed yet"
     (void)hipMemsetAsync(x, 0xFF, sizeof(double) * (size_t)F->n, ctx->stream);
     hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, F->xlpos, F->xrows, d, F->xdperm);
-    hipLaunchKernelGGL(k_trsv_xcd2<true>, dim3(TRSV_P_GRID), dim3(128), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off,
+    hipLaunchKernelGGL(k_trsv_xcd2<true>, dim3(persistent_grid(ctx)), dim3(128), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off,
                        F->xrows, F->xcols, F->xvals, F->xdinv, F->xdperm, x, F->ywork, F->xflags, F->xstate, F->err, (unsigned long long *)nullptr);
   } else if (F->mode == 4) {
     hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
     hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, F->xlpos, F->xrows, d, F->xdperm);
-    hipLaunchKernelGGL(k_trsv_xcd2<false>, dim3(TRSV_P_GRID), dim3(128), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off,
+    hipLaunchKernelGGL(k_trsv_xcd2<false>, dim3(persistent_grid(ctx)), dim3(128), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off,
                        F->xrows, F->xcols, F->xvals, F->xdinv, F->xdperm, x, F->ywork, F->xflags, F->xstate, F->err, (unsigned long long *)nullptr);
   } else if (F->mode == 3) {
     hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
-    hipLaunchKernelGGL(k_trsv_xcd, dim3(TRSV_P_GRID), dim3(64), 0, ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off, F->xrows, F->xcols,
+    hipLaunchKernelGGL(k_trsv_xcd, dim3(persistent_grid(ctx)), dim3(64), 0, ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off, F->xrows, F->xcols,
                        F->xvals, F->xdinv, d, x, F->xflags, F->xstate, F->err);
   } else if (F->mode == 2) {
     // poison both result vectors (all-ones = "not computed yet"), then one data-driven launch
     (void)hipMemsetAsync(F->ywork, 0xFF, sizeof(double) * (size_t)F->n, ctx->stream);
     (void)hipMemsetAsync(x, 0xFF, sizeof(double) * (size_t)F->n, ctx->stream);
-    hipLaunchKernelGGL(k_trsv_syncfree, dim3(TRSV_P_GRID), dim3(64), 0, ctx->stream, (int)F->L.nlev, (int)F->U.nlev, F->L.d_desc, F->U.d_desc,
+    hipLaunchKernelGGL(k_trsv_syncfree, dim3(persistent_grid(ctx)), dim3(64), 0, ctx->stream, (int)F->L.nlev, (int)F->U.nlev, F->L.d_desc, F->U.d_desc,
                        F->L.rows, F->L.cols, F->L.vals, F->U.rows, F->U.cols, F->U.vals, F->U.dinv, d, F->ywork, x, F->err);
   } else if (F->mode == 1) {
     (void)hipMemsetAsync(F->cnt, 0, F->cnt_bytes, ctx->stream); // counters are re-initialised by every replay
-    hipLaunchKernelGGL(k_trsv_persistent, dim3(TRSV_P_GRID), dim3(64), 0, ctx->stream, (int)F->L.nlev, (int)F->U.nlev, F->L.d_desc, F->U.d_desc,
+    hipLaunchKernelGGL(k_trsv_persistent, dim3(persistent_grid(ctx)), dim3(64), 0, ctx->stream, (int)F->L.nlev, (int)F->U.nlev, F->L.d_desc, F->U.d_desc,
                        F->L.rows, F->L.cols, F->L.vals, F->U.rows, F->U.cols, F->U.vals, F->U.dinv, d, x, F->cnt, F->err);
   } else {
     rc = enqueue_tri(ctx, F->L, false, d, x);

@@ -49,6 +49,55 @@ def _drop_dofs(C, mask):
     return C
 
 
+class EigensolverParams:
+    """The keys of ``<prefix>.eigensolver`` with the reference's defaults and quirks
+    (dune/ddm/eigensolvers/eigensolver_params.hh:8-62): ``nev_max`` overwrites **ncv** (:23); ``maxit``,
+    ``seed``, ``blocksize`` are parsed but unused by the reference driver (spectra.hh:137 hard-codes 100).
+    ``ncv`` has no meaning for the block method (the block size is nev + 4)."""
+
+    def __init__(self, ptree=None):
+        ptree = dict(ptree or {})
+        self.type = ptree.get("type", "Spectra")
+        if self.type != "Spectra":
+            raise NotImplementedError("Unknown eigensolver type '" + str(self.type) + "'")   # :35
+        self.nev = int(ptree.get("nev", 16))
+        self.ncv = int(ptree["ncv"]) if "ncv" in ptree else 2 * self.nev
+        self.nev_max = None
+        if "nev_max" in ptree:
+            self.ncv = int(ptree["nev_max"])
+        else:
+            self.nev_max = 2 * self.nev
+        self.maxit = int(ptree.get("maxit", 1000))
+        self.tolerance = float(ptree.get("tolerance", 1e-5))
+        self.shift = float(ptree.get("shift", 1e-3))
+        self.seed = int(ptree.get("seed", 1))
+        self.blocksize = int(ptree.get("blocksize", 8))
+        self.threshold = float(ptree.get("threshold", -0.5))
+
+
+def geneo_basis_from_params(tl, eig_ptree=None, **kw):
+    """GenEOCoarseSpace driven by the eigensolver sub-tree, incl. the threshold mode of
+    spectra_gevp_op (eigensolvers/spectra.hh:157-163,186-189): with threshold > 0 keep the eigenvalues
+    below it (at least one) and double nev until the largest computed one exceeds it or nev >= nev_max."""
+    p = EigensolverParams(eig_ptree)
+    nev = p.nev
+    while True:
+        basis, info = geneo_basis(tl, nev=nev, tol=p.tolerance, shift=p.shift, return_info=True, **kw)
+        if p.threshold <= 0:
+            return basis, info
+        lam = info["eigenvalues"]
+        done = all(l[-1] >= p.threshold for l in lam.values()) or (p.nev_max is not None and nev >= p.nev_max)
+        if done:
+            out = {}
+            for s, vecs in basis.items():
+                cnt = 0
+                while cnt < len(lam[s]) - 1 and lam[s][cnt] < p.threshold:
+                    cnt += 1
+                out[s] = vecs[:max(cnt, 1)]
+            return out, info
+        nev *= 2
+
+
 def geneo_basis(tl, nev=20, tol=1e-5, shift=1e-3, maxit=400, extra=4, seed=0, verbose=False, return_info=False):
     """Returns {local subdomain id: (k, n_s) ndarray} ready for TwoLevelSchwarz.set_coarse_basis
     (POU-scaled, 2-normalised, zero at Dirichlet DoFs)."""

@@ -83,15 +83,21 @@ class TorchComm:
         return 0
 
 
-def pou_basis(rl: RankLocal):
-    """POUCoarseSpace (coarse_spaces.hh:1175-1231): 1 * pou / ||pou||_2 per subdomain, then
-    zero_at_dirichlet (examples/poisson.cc:235-238,282).  Returns {sub id: (1, n_s) array}."""
+def pou_basis(rl: RankLocal, template_vecs=None):
+    """POUCoarseSpace (coarse_spaces.hh:1175-1231): 1 * pou / ||pou||_2 per subdomain -- or, with
+    ``template_vecs`` = {sub id: (t, n_s)}, the POU-scaled template vectors of the second constructor
+    (:1226-1230, used by TwoLevelSchwarzSolver with 1, x, y, xy, twolevel_schwarz.hh:68-107) -- then
+    zero_at_dirichlet (examples/poisson.cc:235-238,282).  Returns {sub id: (k, n_s) array}."""
     out = {}
     for sd in rl.subs:
-        v = np.ones(sd.n) * sd.pou
-        v = v * (1.0 / np.sqrt(float(np.dot(v, v))))
-        v[sd.dirichlet_ovlp > 0] = 0.0
-        out[sd.id] = v[None, :]
+        T = np.ones((1, sd.n)) if template_vecs is None else np.asarray(template_vecs[sd.id], dtype=np.float64)
+        vecs = []
+        for t in T:
+            v = t * sd.pou                                          # finalize_eigenvectors (:52-61)
+            v = v * (1.0 / np.sqrt(float(np.dot(v, v))))
+            v[sd.dirichlet_ovlp > 0] = 0.0
+            vecs.append(v)
+        out[sd.id] = np.array(vecs)
     return out
 
 
