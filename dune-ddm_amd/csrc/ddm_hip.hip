@@ -414,6 +414,15 @@ struct ddm_ilu0 {
   double *xdperm = nullptr;     // right-hand side permuted into level order (loader engine)
   int64_t *xlpos = nullptr;     // positions of the L parts (only those need the permuted right-hand side)
   int64_t xnrows = 0;
+  // slab-ownership engine (mode 7)
+  bool slab_built = false;
+  SlabGroup *sg = nullptr;
+  int64_t *s_wave_ptr = nullptr, *s_lpos = nullptr;
+  SlabStep *s_steps = nullptr;
+  int32_t *s_rows = nullptr, *s_cols = nullptr;
+  double *s_vals = nullptr, *s_dinv = nullptr, *s_dperm = nullptr;
+  unsigned *s_progress = nullptr;
+  int64_t s_npos = 0;
   // windowed level-permuted engine (mode 6)
   int w_state = 0;              // 0 not built, 1 built, -1 not applicable (rows wider than a tile)
   GroupDesc *wg = nullptr;
@@ -571,7 +580,7 @@ extern "C" int ddm_ilu0_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, 
     }
   int rc = build_schedule(ctx, A, F->h_lu, diag, false, F->L);
   if (!rc) rc = build_schedule(ctx, A, F->h_lu, diag, true, F->U);
-  if (const char *m = std::getenv("DDM_TRSV_MODE")) F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "syncfree") ? 2 : (!std::strcmp(m, "persistent") ? 1 : (!std::strcmp(m, "xcd") ? 3 : (!std::strcmp(m, "xcd3") ? 5 : (!std::strcmp(m, "xcdw") ? 6 : 4)))));
+  if (const char *m = std::getenv("DDM_TRSV_MODE")) F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "syncfree") ? 2 : (!std::strcmp(m, "persistent") ? 1 : (!std::strcmp(m, "xcd") ? 3 : (!std::strcmp(m, "xcd3") ? 5 : (!std::strcmp(m, "xcdw") ? 6 : (!std::strcmp(m, "slab") ? 7 : 4))))));
   F->A = A;
   F->h_diag = diag;
   F->h_block_ptr.assign(block_ptr, block_ptr + nblocks + 1);
@@ -607,6 +616,16 @@ extern "C" void ddm_ilu0_destroy(ddm_ilu0 *F)
   (void)hipFree(F->xstate);
   (void)hipFree(F->xdperm);
   (void)hipFree(F->xlpos);
+  (void)hipFree(F->sg);
+  (void)hipFree(F->s_wave_ptr);
+  (void)hipFree(F->s_lpos);
+  (void)hipFree(F->s_steps);
+  (void)hipFree(F->s_rows);
+  (void)hipFree(F->s_cols);
+  (void)hipFree(F->s_vals);
+  (void)hipFree(F->s_dinv);
+  (void)hipFree(F->s_dperm);
+  (void)hipFree(F->s_progress);
   (void)hipFree(F->wg);
   (void)hipFree(F->wlev);
   (void)hipFree(F->wchunk);
@@ -979,6 +998,136 @@ static int build_xcdw_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
   return DDM_OK;
 }
 
+// Slab-ownership schedule (engine "slab"): every block is cut into SLAB_W contiguous row ranges; for each
+// range and sweep the rows are sorted by dependency level and stored step by step (one step = the rows of
+// one level inside one slab) in sliced ELL with natural row indices as columns.
+static int build_slab_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
+{
+  const ddm_csr *A = F->A;
+  const int64_t *rp = A->h_rp.data();
+  const int32_t *ci = A->h_ci.data();
+  const std::vector<double> &lu = F->h_lu;
+  const std::vector<int64_t> &diag = F->h_diag;
+  const int nb = (int)F->h_block_ptr.size() - 1;
+  std::vector<SlabGroup> groups(nb);
+  std::vector<int64_t> wave_ptr, lpos;
+  std::vector<SlabStep> steps;
+  std::vector<int32_t> rows, cols;
+  std::vector<double> vals, dinv;
+  rows.reserve(2 * (size_t)A->nrows);
+  cols.reserve((size_t)A->nnz);
+  vals.reserve((size_t)A->nnz);
+  std::vector<int32_t> level(A->nrows);
+  int64_t nprog = 0;
+  for (int b = 0; b < nb; ++b) {
+    const int64_t r0 = F->h_block_ptr[b], r1 = F->h_block_ptr[b + 1], nbk = r1 - r0;
+    // slab size = the reach of the dependencies in natural order (lower / upper bandwidth): a row then depends only on
+    // its own and the adjacent slab; slabs are dealt round-robin to the SLAB_W waves, so that the rows of one
+    // dependency level are spread over all waves
+    int64_t bw = 64;
+    for (int64_t i = r0; i < r1; ++i) {
+      if (diag[i] > rp[i]) bw = std::max<int64_t>(bw, i - ci[rp[i]]);
+      if (rp[i + 1] - 1 > diag[i]) bw = std::max<int64_t>(bw, ci[rp[i + 1] - 1] - i);
+    }
+    const int64_t slab = std::min<int64_t>(std::max<int64_t>((nbk + SLAB_W - 1) / SLAB_W / 8, std::min(bw, (nbk + SLAB_W - 1) / SLAB_W)), nbk);
+    auto owner = [&](int64_t i) { return (int)(((i - r0) / slab) % SLAB_W); };
+    groups[b].step_ptr = (int64_t)wave_ptr.size();
+    groups[b].prog_off = nprog;
+    nprog += 2 * SLAB_W * 32;
+    for (int sweep = 0; sweep < 2; ++sweep) {
+      const bool upper = sweep == 1;
+      int32_t maxlev = -1;
+      if (!upper)
+        for (int64_t i = r0; i < r1; ++i) {
+          int32_t l = 0;
+          for (int64_t k = rp[i]; k < diag[i]; ++k) l = std::max(l, level[ci[k]] + 1);
+          level[i] = l;
+          maxlev = std::max(maxlev, l);
+        }
+      else
+        for (int64_t i = r1 - 1; i >= r0; --i) {
+          int32_t l = 0;
+          for (int64_t k = diag[i] + 1; k < rp[i + 1]; ++k) l = std::max(l, level[ci[k]] + 1);
+          level[i] = l;
+          maxlev = std::max(maxlev, l);
+        }
+      const int32_t nlev = maxlev + 1;
+      (upper ? groups[b].nlevU : groups[b].nlevL) = nlev;
+      for (int k = 0; k < SLAB_W; ++k) {
+        wave_ptr.push_back((int64_t)steps.size());
+        std::vector<int32_t> order;
+        for (int64_t a = r0 + k * slab; a < r1; a += (int64_t)SLAB_W * slab)
+          for (int64_t i = a; i < std::min(a + slab, r1); ++i) order.push_back((int32_t)i);
+        if (order.empty()) continue;
+        std::stable_sort(order.begin(), order.end(), [&](int32_t p, int32_t q) { return level[p] < level[q]; });
+        size_t first_step = steps.size();
+        for (size_t q0 = 0; q0 < order.size();) {
+          size_t q1 = q0;
+          while (q1 < order.size() && level[order[q1]] == level[order[q0]]) ++q1;
+          const int64_t m = (int64_t)(q1 - q0);
+          int w = 0;
+          for (size_t q = q0; q < q1; ++q) {
+            const int64_t i = order[q];
+            w = std::max(w, upper ? (int)(rp[i + 1] - diag[i] - 1) : (int)(diag[i] - rp[i]));
+          }
+          const int64_t pos = (int64_t)rows.size(), ent = (int64_t)cols.size();
+          uint32_t mask = 0;
+          for (size_t q = q0; q < q1; ++q) {
+            const int64_t i = order[q];
+            const int64_t k0 = upper ? diag[i] + 1 : rp[i], k1 = upper ? rp[i + 1] : diag[i];
+            for (int64_t p = k0; p < k1; ++p) {
+              const int ow = owner(ci[p]);
+              if (ow != k) mask |= 1u << ow;
+            }
+          }
+          steps.push_back(SlabStep{level[order[q0]], (int32_t)m, (int32_t)w, nlev, pos, ent, mask, 0u});
+          cols.resize(ent + m * (int64_t)w);
+          vals.resize(ent + m * (int64_t)w);
+          for (size_t q = q0; q < q1; ++q) {
+            const int64_t i = order[q], r = (int64_t)(q - q0);
+            rows.push_back((int32_t)i);
+            dinv.push_back(upper ? lu[diag[i]] : 0.0);
+            if (!upper) lpos.push_back(pos + r);
+            const int64_t k0 = upper ? diag[i] + 1 : rp[i], k1 = upper ? rp[i + 1] : diag[i];
+            int k = 0;
+            for (int64_t p = k0; p < k1; ++p, ++k) {
+              cols[ent + (int64_t)k * m + r] = ci[p];
+              vals[ent + (int64_t)k * m + r] = lu[p];
+            }
+            for (; k < w; ++k) {
+              cols[ent + (int64_t)k * m + r] = ci[k0];
+              vals[ent + (int64_t)k * m + r] = 0.0;
+            }
+          }
+          q0 = q1;
+        }
+        for (size_t si = first_step; si + 1 < steps.size(); ++si) steps[si].next_level = steps[si + 1].level;
+      }
+      wave_ptr.push_back((int64_t)steps.size());
+    }
+  }
+  F->ngroups = nb;
+  F->s_npos = (int64_t)rows.size();
+  DDMCHECK(upload(ctx, groups.data(), (int64_t)groups.size(), &F->sg));
+  DDMCHECK(upload(ctx, wave_ptr.data(), (int64_t)wave_ptr.size(), &F->s_wave_ptr));
+  DDMCHECK(upload(ctx, lpos.data(), (int64_t)lpos.size(), &F->s_lpos));
+  DDMCHECK(upload(ctx, steps.data(), (int64_t)steps.size(), &F->s_steps));
+  DDMCHECK(upload(ctx, rows.data(), (int64_t)rows.size(), &F->s_rows));
+  DDMCHECK(upload(ctx, cols.data(), (int64_t)cols.size(), &F->s_cols));
+  DDMCHECK(upload(ctx, vals.data(), (int64_t)vals.size(), &F->s_vals));
+  DDMCHECK(upload(ctx, dinv.data(), (int64_t)dinv.size(), &F->s_dinv));
+  HIPCHECK(ctx, hipMalloc((void **)&F->s_dperm, sizeof(double) * (size_t)std::max<int64_t>(F->s_npos, 1)));
+  HIPCHECK(ctx, hipMalloc((void **)&F->s_progress, sizeof(unsigned) * (size_t)std::max<int64_t>(nprog, 1)));
+  HIPCHECK(ctx, hipMemset(F->s_progress, 0, sizeof(unsigned) * (size_t)std::max<int64_t>(nprog, 1)));
+  if (!F->xstate) {
+    HIPCHECK(ctx, hipMalloc((void **)&F->xstate, sizeof(XcdState)));
+    HIPCHECK(ctx, hipMemset(F->xstate, 0, sizeof(XcdState)));
+  }
+  HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_slab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TrsvLds)));
+  F->slab_built = true;
+  return DDM_OK;
+}
+
 static int enqueue_tri(ddm_ctx *ctx, const TriSchedule &S, bool upper, const double *d, double *x)
 {
   for (const auto &p : S.plan) {
@@ -1027,7 +1176,7 @@ extern "C" int ddm_ilu0_debug_stamps(ddm_ctx *ctx, ddm_ilu0 *F, const double *d,
   if (!F->xcd_built) DDMCHECK(build_xcd_schedule(ctx, F));
   hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
   hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, F->xlpos, F->xrows, d, F->xdperm);
-  hipLaunchKernelGGL(k_trsv_xcd2<false>, dim3(persistent_grid(ctx)), dim3(128), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off, F->xrows,
+  hipLaunchKernelGGL(k_trsv_xcd2<false>, dim3(persistent_grid(ctx)), dim3(64 * (1 + TRSV_L_LOADERS)), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off, F->xrows,
                      F->xcols, F->xvals, F->xdinv, F->xdperm, x, F->ywork, F->xflags, F->xstate, F->err, st);
   int rc = ddm_memcpy_d2h(ctx, out_host, st, 48);
   (void)hipFree(st);
@@ -1047,13 +1196,19 @@ extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double
     (void)hipGraphExecDestroy(F->graph);
     F->graph = nullptr;
   }
+  if (F->mode == 7 && !F->slab_built) DDMCHECK(build_slab_schedule(ctx, F));
   if (F->mode == 6 && F->w_state == 0) DDMCHECK(build_xcdw_schedule(ctx, F));
   if (F->mode == 6 && F->w_state < 0) F->mode = 3; // rows wider than a tile: use the gather-based XCD engine
   if (F->mode >= 3 && F->mode <= 5 && !F->xcd_built) DDMCHECK(build_xcd_schedule(ctx, F));
   hipGraph_t g = nullptr;
   HIPCHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
   int rc = DDM_OK;
-  if (F->mode == 6) {
+  if (F->mode == 7) {
+    hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
+    hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, F->s_lpos, F->s_rows, d, F->s_dperm);
+    hipLaunchKernelGGL(k_trsv_slab, dim3(persistent_grid(ctx)), dim3(128), sizeof(TrsvLds), ctx->stream, F->ngroups, F->sg, F->s_wave_ptr, F->s_steps,
+                       F->s_rows, F->s_cols, F->s_vals, F->s_dinv, F->s_dperm, F->ywork, x, F->s_progress, F->xstate, F->err);
+  } else if (F->mode == 6) {
     const int64_t nn = F->n;
     hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
     hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(nn)), dim3(WG), 0, ctx->stream, nn, F->wlpos, F->wrows, d, F->wdperm);
@@ -1065,12 +1220,12 @@ extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double
     (void)hipMemsetAsync(F->ywork, 0xFF, sizeof(double) * (size_t)F->n, ctx->stream); // sentinel = "not computed yet"
     (void)hipMemsetAsync(x, 0xFF, sizeof(double) * (size_t)F->n, ctx->stream);
     hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, F->xlpos, F->xrows, d, F->xdperm);
-    hipLaunchKernelGGL(k_trsv_xcd2<true>, dim3(persistent_grid(ctx)), dim3(128), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off,
+    hipLaunchKernelGGL(k_trsv_xcd2<true>, dim3(persistent_grid(ctx)), dim3(64 * (1 + TRSV_L_LOADERS)), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off,
                        F->xrows, F->xcols, F->xvals, F->xdinv, F->xdperm, x, F->ywork, F->xflags, F->xstate, F->err, (unsigned long long *)nullptr);
   } else if (F->mode == 4) {
     hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
     hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, F->xlpos, F->xrows, d, F->xdperm);
-    hipLaunchKernelGGL(k_trsv_xcd2<false>, dim3(persistent_grid(ctx)), dim3(128), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off,
+    hipLaunchKernelGGL(k_trsv_xcd2<false>, dim3(persistent_grid(ctx)), dim3(64 * (1 + TRSV_L_LOADERS)), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off,
                        F->xrows, F->xcols, F->xvals, F->xdinv, F->xdperm, x, F->ywork, F->xflags, F->xstate, F->err, (unsigned long long *)nullptr);
   } else if (F->mode == 3) {
     hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);

@@ -654,15 +654,22 @@ __global__ __launch_bounds__(64) void k_trsv_xcd(int ngroups, const GroupDesc *_
 // The two waves synchronise through two LDS words per ring (produced / consumed counts); they never
 // meet at a barrier.  Cross-workgroup protocol and XCD grouping are those of k_trsv_xcd.
 constexpr int TRSV_L_SLOTS = 8;
+struct TrsvTileHdr { // everything the compute wave needs to know about a work item: no descriptor loads on its path
+  int32_t valid, grp, lev, c, m, w, upper, nact_prev, level_done, pad;
+  int64_t flag_base, ent_off;
+};
 struct TrsvLdsTile {
   int32_t row[64];
   double s0[64];  // L: right-hand side d[row];  U: inverse pivot
   int32_t cc[TRSV_UNROLL][64];
   double vv[TRSV_UNROLL][64];
+  TrsvTileHdr hdr;
 };
+constexpr int TRSV_L_LOADERS = 2;
 struct TrsvLds {
   TrsvLdsTile tile[TRSV_L_SLOTS];
-  unsigned produced, consumed; // work items written by the loader / released by the compute wave
+  unsigned ready[TRSV_L_SLOTS]; // ready[slot] = seq + 1 once work item seq is in the slot (several loader waves)
+  unsigned produced, consumed;  // work items written by the (single) loader / released by the compute wave
 };
 __global__ void k_permute_rhs(int64_t n, const int32_t *__restrict__ rows, const double *__restrict__ d, double *__restrict__ dperm)
 {
@@ -707,7 +714,7 @@ struct TrsvWork {
 // the all-ones sentinel, a row polls its own dependencies in L2 until none is the sentinel and publishes its
 // value with a single 8-byte store: no flag, no drain, no level barrier on the critical path.
 template <bool DATAFLOW>
-__global__ __launch_bounds__(128) void k_trsv_xcd2(int ngroups, const GroupDesc *__restrict__ groups, const LevelDesc *__restrict__ desc,
+__global__ __launch_bounds__(64 * (1 + TRSV_L_LOADERS)) void k_trsv_xcd2(int ngroups, const GroupDesc *__restrict__ groups, const LevelDesc *__restrict__ desc,
                                                     const int64_t *__restrict__ flag_off, const int32_t *__restrict__ rowsA,
                                                     const int32_t *__restrict__ colsA, const double *__restrict__ valsA,
                                                     const double *__restrict__ dinvA, const double *__restrict__ dperm, double *x,
@@ -717,6 +724,7 @@ __global__ __launch_bounds__(128) void k_trsv_xcd2(int ngroups, const GroupDesc 
   TrsvLds &S = *reinterpret_cast<TrsvLds *>(smem_raw);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  if (threadIdx.x < TRSV_L_SLOTS) S.ready[threadIdx.x] = 0;
   if (threadIdx.x == 0) {
     S.produced = 0;
     S.consumed = 0;
@@ -760,17 +768,22 @@ __global__ __launch_bounds__(128) void k_trsv_xcd2(int ngroups, const GroupDesc 
   if (rank >= W) return;
   TrsvWork wk;
   wk.init(groups, desc, ngroups, first, step, rank, W);
-  volatile unsigned *produced = &S.produced;
+  volatile unsigned *ready = S.ready;
   volatile unsigned *consumed = &S.consumed;
 
-  if (wave == 1) {
-    // =========================== loader: HBM -> LDS ring ===========================
-    // two tiles in flight: the loads of item seq+1 are issued before item seq is written to LDS
+  if (wave >= 1) {
+    // =========================== loaders: HBM -> LDS ring ===========================
+    // TRSV_L_LOADERS loader waves; loader j handles the work items seq = j, j + L, j + 2L, ... and announces each
+    // slot separately (ready[slot] = seq + 1), so tiles of different loaders may land out of order.
+    const int lj = wave - 1;
+    // two tiles in flight: the loads of item seq+1 are issued before item seq is written to LDS.  The loader also
+    // resolves all schedule descriptors and hands them over in the tile header.
     struct Regs {
-      int32_t rowm, w;
+      int32_t rowm;
       double s0;
       int32_t cc[TRSV_UNROLL];
       double vv[TRSV_UNROLL];
+      TrsvTileHdr h;
     };
     auto issue = [&](Regs &R, const TrsvWork &k) {
       const GroupDesc G = groups[k.grp];
@@ -780,11 +793,8 @@ __global__ __launch_bounds__(128) void k_trsv_xcd2(int ngroups, const GroupDesc 
       const int rr = r < D.m ? r : D.m - 1;
       const int32_t row = rowsA[D.row_off + rr];
       R.rowm = r < D.m ? row : -1 - row; // negative = shadow lane (no store)
-      R.w = D.w;
-      // warm the XCD's L2 with the line of x[row]: the compute wave's store (write-allocate) and, in the
-      // U phase, its read of the forward value would otherwise pay an HBM miss on the per-level critical path
-      if (!DATAFLOW) (void)*(volatile const unsigned long long *)(x + row);
       R.s0 = upper ? dinvA[D.row_off + rr] : dperm[D.row_off + rr];
+      if (!DATAFLOW) (void)*(volatile const unsigned long long *)(x + row); // warm this XCD's L2 with the line of x[row]
       const int32_t *cols = colsA + D.ent_off;
       const double *vals = valsA + D.ent_off;
 #pragma unroll
@@ -796,12 +806,43 @@ __global__ __launch_bounds__(128) void k_trsv_xcd2(int ngroups, const GroupDesc 
           R.vv[u] = vals[(int64_t)u * D.m + rr];
         }
       }
+      const int nchunk = (D.m + 63) >> 6;
+      int ncp = 0;
+      if (k.lev > 0) ncp = (desc[G.lev_off + k.lev - 1].m + 63) >> 6;
+      R.h.valid = 1;
+      R.h.grp = k.grp;
+      R.h.lev = k.lev;
+      R.h.c = k.c;
+      R.h.m = D.m;
+      R.h.w = D.w;
+      R.h.upper = upper ? 1 : 0;
+      R.h.nact_prev = (k.lev > 0 && k.c == k.rank) ? (ncp < k.W ? ncp : k.W) : 0; // > 0: poll the previous level's flags first
+      R.h.level_done = (k.c + k.W >= nchunk) ? 1 : 0;                               // last chunk of this wave in this level
+      R.h.pad = 0;
+      R.h.flag_base = flag_off[k.grp] + (int64_t)k.lev * TRSV_X_MAXW;
+      R.h.ent_off = D.ent_off;
     };
     Regs A, B;
-    if (!wk.valid()) return;
+    for (int q = 0; q < lj && wk.valid(); ++q) wk.advance(); // first item of this loader
+    unsigned seq = (unsigned)lj;
+    auto end_marker = [&](unsigned sq) { // the first loader that runs out of items writes the end marker at its next sequence number
+      for (unsigned spins = 0; sq >= *consumed + TRSV_L_SLOTS; ++spins) {
+        if (spins > (1u << 24)) return;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (lane == 0) {
+        S.tile[sq % TRSV_L_SLOTS].hdr.valid = 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ready[sq % TRSV_L_SLOTS] = sq + 1;
+      }
+    };
+    if (!wk.valid()) {
+      end_marker(seq);
+      return;
+    }
     issue(A, wk);
-    for (unsigned seq = 0;; ++seq) {
-      wk.advance();
+    for (;; seq += TRSV_L_LOADERS) {
+      for (int q = 0; q < TRSV_L_LOADERS && wk.valid(); ++q) wk.advance();
       const bool more = wk.valid();
       if (more) issue(B, wk);
       for (unsigned spins = 0; seq >= *consumed + TRSV_L_SLOTS; ++spins) { // free ring slot?
@@ -816,20 +857,23 @@ __global__ __launch_bounds__(128) void k_trsv_xcd2(int ngroups, const GroupDesc 
       T.s0[lane] = A.s0;
 #pragma unroll
       for (int u = 0; u < TRSV_UNROLL; ++u)
-        if (u < A.w) {
+        if (u < A.h.w) {
           T.cc[u][lane] = A.cc[u];
           T.vv[u][lane] = A.vv[u];
         }
+      if (lane == 0) T.hdr = A.h;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // tile is in LDS before it is announced
-      if (lane == 0) *produced = seq + 1;
-      if (!more) return;
+      if (lane == 0) ready[seq % TRSV_L_SLOTS] = seq + 1;
+      if (!more) {
+        end_marker(seq + TRSV_L_LOADERS);
+        return;
+      }
       A = B;
     }
   }
 
   // =========================== compute wave ===========================
-  // diagnostic stamps (only when a buffer is passed; production launches pass nullptr): cycles spent by the
-  // rank-0 wave of XCD 0 waiting for its LDS tile / for the flags / for the gathers / for the store drain
+  // diagnostic stamps (only when a buffer is passed; production launches pass nullptr)
   const bool stamp = stamps != nullptr && rank == 0 && (local_ok ? xcc == 0 : true);
   unsigned long long t_tile = 0, t_poll = 0, t_gather = 0, t_drain = 0, n_items = 0, t_begin = 0, tq = 0;
 #define DDM_STAMP(acc)                                                 \
@@ -839,14 +883,8 @@ __global__ __launch_bounds__(128) void k_trsv_xcd2(int ngroups, const GroupDesc 
     tq = now_;                                                         \
   }
   if (stamp) t_begin = tq = __builtin_amdgcn_s_memtime();
-  for (unsigned seq = 0; wk.valid(); ++seq) {
-    const int grp = wk.grp, lev = wk.lev;
-    const GroupDesc G = groups[grp];
-    const LevelDesc D = desc[G.lev_off + lev];
-    const bool upper = lev >= G.nlevL;
-    unsigned *gflags = flags + flag_off[grp];
-    // tile from the ring
-    for (unsigned spins = 0; *produced <= seq; ++spins) {
+  for (unsigned seq = 0;; ++seq) {
+    for (unsigned spins = 0; ready[seq % TRSV_L_SLOTS] != seq + 1; ++spins) {
       if (spins > (1u << 24)) {
         if (lane == 0) __hip_atomic_store(err, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
@@ -854,6 +892,9 @@ __global__ __launch_bounds__(128) void k_trsv_xcd2(int ngroups, const GroupDesc 
       __builtin_amdgcn_s_sleep(1);
     }
     const TrsvLdsTile &T = S.tile[seq % TRSV_L_SLOTS];
+    const TrsvTileHdr H = T.hdr;
+    if (!H.valid) break;
+    const bool upper = H.upper != 0;
     const int32_t rowm = T.row[lane];
     const bool act = rowm >= 0;
     const int32_t row = act ? rowm : -1 - rowm;
@@ -864,7 +905,7 @@ __global__ __launch_bounds__(128) void k_trsv_xcd2(int ngroups, const GroupDesc 
     for (int u = 0; u < TRSV_UNROLL; ++u) {
       cc[u] = 0;
       vv[u] = 0.0;
-      if (u < D.w) {
+      if (u < H.w) {
         cc[u] = T.cc[u][lane];
         vv[u] = T.vv[u][lane];
       }
@@ -880,7 +921,7 @@ __global__ __launch_bounds__(128) void k_trsv_xcd2(int ngroups, const GroupDesc 
 #pragma unroll
         for (int u = 0; u < TRSV_UNROLL; ++u) {
           xb[u] = 0ull;
-          if (u < D.w) {
+          if (u < H.w) {
             xb[u] = ld_sc1_bits(src + cc[u]);
             ok &= xb[u] != TRSV_SENTINEL;
           }
@@ -898,17 +939,17 @@ __global__ __launch_bounds__(128) void k_trsv_xcd2(int ngroups, const GroupDesc 
       double s = upper ? __longlong_as_double((long long)own) : s0;
 #pragma unroll
       for (int u = 0; u < TRSV_UNROLL; ++u) s -= vv[u] * __longlong_as_double((long long)xb[u]);
-      if (D.w > TRSV_UNROLL) { // rare: rows wider than a tile (their extra dependencies are polled one by one)
-        const int r = (wk.c << 6) + lane;
-        const int rr = r < D.m ? r : D.m - 1;
-        for (int k = TRSV_UNROLL; k < D.w; ++k) {
-          const int32_t c2 = colsA[D.ent_off + (int64_t)k * D.m + rr];
+      if (H.w > TRSV_UNROLL) { // rare: rows wider than a tile (their extra dependencies are polled one by one)
+        const int r = (H.c << 6) + lane;
+        const int rr = r < H.m ? r : H.m - 1;
+        for (int k = TRSV_UNROLL; k < H.w; ++k) {
+          const int32_t c2 = colsA[H.ent_off + (int64_t)k * H.m + rr];
           unsigned long long b2;
           for (unsigned spins = 0;; ++spins) {
             b2 = ld_sc1_bits(src + c2);
             if (__all(b2 != TRSV_SENTINEL) || spins > (1u << 20)) break;
           }
-          s -= valsA[D.ent_off + (int64_t)k * D.m + rr] * __longlong_as_double((long long)b2);
+          s -= valsA[H.ent_off + (int64_t)k * H.m + rr] * __longlong_as_double((long long)b2);
         }
       }
       const double out = upper ? s * s0 : s;
@@ -917,17 +958,13 @@ __global__ __launch_bounds__(128) void k_trsv_xcd2(int ngroups, const GroupDesc 
         if (wt) st_sc1(dst + row, out);
         else dst[row] = out;
       }
-      wk.advance();
       continue;
     }
     // previous level of this group complete?
-    const bool first_chunk_of_level = wk.c == rank;
-    if (lev > 0 && first_chunk_of_level) {
-      const unsigned *fp = gflags + (int64_t)(lev - 1) * TRSV_X_MAXW;
-      const int ncp = (desc[G.lev_off + lev - 1].m + 63) >> 6;
-      const int nact = ncp < W ? ncp : W;
+    if (H.nact_prev > 0) {
+      const unsigned *fp = flags + H.flag_base - TRSV_X_MAXW;
       for (unsigned spins = 0;; ++spins) {
-        const unsigned v = lane < nact ? __hip_atomic_load(fp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+        const unsigned v = lane < H.nact_prev ? __hip_atomic_load(fp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
         if (__all(v == epoch)) break;
         if (spins > (1u << 22)) {
           if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -940,33 +977,30 @@ __global__ __launch_bounds__(128) void k_trsv_xcd2(int ngroups, const GroupDesc 
 #pragma unroll
     for (int u = 0; u < TRSV_UNROLL; ++u) {
       xv[u] = 0.0;
-      if (u < D.w) xv[u] = ld_sc1(x + cc[u]);
+      if (u < H.w) xv[u] = ld_sc1(x + cc[u]);
     }
     double s = upper ? ld_sc1(x + row) : s0;
 #pragma unroll
     for (int u = 0; u < TRSV_UNROLL; ++u) s -= vv[u] * xv[u];
+    if (H.w > TRSV_UNROLL) { // rows wider than a tile: the rest straight from global memory (rare)
+      const int r = (H.c << 6) + lane;
+      const int rr = r < H.m ? r : H.m - 1;
+      for (int k = TRSV_UNROLL; k < H.w; ++k)
+        s -= valsA[H.ent_off + (int64_t)k * H.m + rr] * ld_sc1(x + colsA[H.ent_off + (int64_t)k * H.m + rr]);
+    }
     if (stamp) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       DDM_STAMP(t_gather)
-    }
-    if (D.w > TRSV_UNROLL) { // rows wider than a tile: the rest straight from global memory (rare)
-      const int r = (wk.c << 6) + lane;
-      const int rr = r < D.m ? r : D.m - 1;
-      for (int k = TRSV_UNROLL; k < D.w; ++k)
-        s -= valsA[D.ent_off + (int64_t)k * D.m + rr] * ld_sc1(x + colsA[D.ent_off + (int64_t)k * D.m + rr]);
     }
     const double out = upper ? s * s0 : s;
     if (act) {
       if (wt) st_sc1(x + row, out);
       else x[row] = out;
     }
-    // last chunk of this wave in this level -> drain and raise the flag
-    wk.advance();
-    const bool level_done = !wk.valid() || wk.grp != grp || wk.lev != lev;
-    if (level_done) {
+    if (H.level_done) { // last chunk of this wave in this level -> drain and raise the flag
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) {
-        unsigned *f = gflags + (int64_t)lev * TRSV_X_MAXW + rank;
+        unsigned *f = flags + H.flag_base + rank;
         if (wt) __hip_atomic_store(f, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else *(volatile unsigned *)f = epoch;
       }
@@ -1313,6 +1347,282 @@ __global__ __launch_bounds__(128) void k_trsv_xcdw(int ngroups, const GroupDesc 
     stamps[6] = n_direct;
   }
 #undef DDM_STAMP
+}
+
+// ---------------------------------------------------------------------------------------------
+// "slab" engine: XCD-local solve with ROW OWNERSHIP.  The level-barrier engines need four dependent L2
+// round trips per level (flag poll, gathers, store drain, flag visibility).  Here every wave owns a
+// contiguous slab of rows of its subdomain (natural order => a few grid planes) for the whole solve and
+// walks its own rows level by level:
+//   * dependencies inside the slab were stored by the same wave: the sc1 gather simply follows the
+//     store through L2 (same wave, same address: in order) -- no flag, no drain;
+//   * dependencies on other slabs (lower slabs in the L sweep, higher slabs in the U sweep) are guarded
+//     by one monotone progress word per wave ("all my rows of levels < p are stored"), published every
+//     SLAB_PUB steps after a drain; the value is cached, so a wave that runs behind its neighbours
+//     (the natural pipeline skew) polls rarely;
+//   * the forward result goes to y, the backward result to x, so the two sweeps never race.
+// tools/xcd_handoff_bench.hip mode 2 measures 1.76 us per level for this pattern (13 x 64 scattered
+// gathers + 64 stores) against 5-6 us per level for the level-barrier engines.
+constexpr int SLAB_W = 32;      // waves (slabs) per subdomain; one XCD normally hosts 32 single-CU workgroups
+constexpr int SLAB_PUB = 4;     // (unused by the lazy-publish protocol; kept for the schedule builder's gap rule)
+struct SlabStep {
+  int32_t level, m, w, next_level; // next_level = level of the wave's next step (or #levels of the sweep)
+  int64_t pos_off, ent_off;        // first position (rows / rhs / inverse pivots) and first ELL entry of the step
+  uint32_t dep_mask, pad;          // waves (other than the owner) that own a dependency of this step
+};
+struct SlabGroup {
+  int32_t nlevL, nlevU;
+  int64_t step_ptr;                // index into wave_step_ptr: SLAB_W + 1 offsets for this group
+  int64_t prog_off;                // first progress word (2 * SLAB_W words of 32 uint32 each: L then U)
+};
+
+__global__ __launch_bounds__(128) void k_trsv_slab(int ngroups, const SlabGroup *__restrict__ groups, const int64_t *__restrict__ wave_step_ptr,
+                                                    const SlabStep *__restrict__ steps, const int32_t *__restrict__ rowsA,
+                                                    const int32_t *__restrict__ colsA, const double *__restrict__ valsA,
+                                                    const double *__restrict__ dinvA, const double *__restrict__ dperm, double *y, double *x,
+                                                    unsigned *progress, XcdState *st, unsigned *err)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  TrsvLds &S = *reinterpret_cast<TrsvLds *>(smem_raw);
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  __shared__ unsigned sh_xcc, sh_t, sh_gt, sh_fail;
+  if (threadIdx.x == 0) {
+    S.produced = 0;
+    S.consumed = 0;
+    const unsigned xcc = hw_xcc_id();
+    sh_xcc = xcc;
+    sh_t = __hip_atomic_fetch_add(&st->tickets[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh_gt = __hip_atomic_fetch_add(&st->global_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&st->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned fail_ = 0;
+    for (unsigned spins = 0; __hip_atomic_load(&st->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x; ++spins) {
+      if (spins > (1u << 22)) {
+        __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fail_ = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    sh_fail = fail_;
+  }
+  __syncthreads();
+  if (sh_fail) return;
+  const unsigned xcc = sh_xcc, t = sh_t, gt = sh_gt;
+  const unsigned epoch = __hip_atomic_load(&st->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x3FFu;
+  const unsigned tk = lane < 8 ? __hip_atomic_load(&st->tickets[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (unsigned)SLAB_W;
+  const int owners = ngroups < 8 ? ngroups : 8;
+  const bool local_ok = __all(lane >= owners || tk >= (unsigned)SLAB_W); // every owning XCD hosts a full set of slab waves
+  int rank, first, step;
+  bool wt;
+  if (local_ok) {
+    rank = (int)t; first = (int)xcc; step = 8; wt = false;
+  } else { // placement-independent path: the first SLAB_W workgroups, write-through stores
+    rank = (int)gt; first = 0; step = 1; wt = true;
+  }
+  if (rank >= SLAB_W) return;
+  volatile unsigned *produced = &S.produced;
+  volatile unsigned *consumed = &S.consumed;
+
+  if (wave == 1) {
+    // ---------------- loader: HBM -> LDS tile ring, two tiles in flight ----------------
+    struct Regs {
+      int32_t rowm, w;
+      double s0;
+      int32_t cc[TRSV_UNROLL];
+      double vv[TRSV_UNROLL];
+    };
+    struct Cursor {
+      int grp, sweep;
+      int64_t s, s_end;
+      int c;
+    };
+    auto settle = [&](Cursor &k) { // advance to the next existing (step, chunk)
+      while (k.grp < ngroups) {
+        const SlabGroup G = groups[k.grp];
+        while (k.sweep < 2) {
+          if (k.s < 0) {
+            const int64_t *sp = wave_step_ptr + G.step_ptr + (int64_t)k.sweep * (SLAB_W + 1);
+            k.s = sp[rank];
+            k.s_end = sp[rank + 1];
+            k.c = 0;
+          }
+          while (k.s < k.s_end) {
+            if (k.c < ((steps[k.s].m + 63) >> 6)) return;
+            ++k.s;
+            k.c = 0;
+          }
+          ++k.sweep;
+          k.s = -1;
+        }
+        k.grp += step;
+        k.sweep = 0;
+        k.s = -1;
+      }
+    };
+    auto issue = [&](Regs &R, const Cursor &k) {
+      const SlabStep D = steps[k.s];
+      const bool upper = k.sweep == 1;
+      const int r = (k.c << 6) + lane;
+      const int rr = r < D.m ? r : D.m - 1;
+      const int32_t row = rowsA[D.pos_off + rr];
+      R.rowm = r < D.m ? row : -1 - row;
+      R.w = D.w;
+      R.s0 = upper ? dinvA[D.pos_off + rr] : dperm[D.pos_off + rr];
+      const int32_t *cols = colsA + D.ent_off;
+      const double *vals = valsA + D.ent_off;
+#pragma unroll
+      for (int u = 0; u < TRSV_UNROLL; ++u) {
+        R.cc[u] = 0;
+        R.vv[u] = 0.0;
+        if (u < D.w) {
+          R.cc[u] = cols[(int64_t)u * D.m + rr];
+          R.vv[u] = vals[(int64_t)u * D.m + rr];
+        }
+      }
+    };
+    Cursor cur{first, 0, -1, 0, 0};
+    settle(cur);
+    if (cur.grp >= ngroups) return;
+    Regs A, B;
+    issue(A, cur);
+    for (unsigned seq = 0;; ++seq) {
+      ++cur.c;
+      settle(cur);
+      const bool more = cur.grp < ngroups;
+      if (more) issue(B, cur);
+      for (unsigned spins = 0; seq >= *consumed + TRSV_L_SLOTS; ++spins) {
+        if (spins > (1u << 24)) {
+          if (lane == 0) __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      TrsvLdsTile &T = S.tile[seq % TRSV_L_SLOTS];
+      T.row[lane] = A.rowm;
+      T.s0[lane] = A.s0;
+#pragma unroll
+      for (int u = 0; u < TRSV_UNROLL; ++u)
+        if (u < A.w) {
+          T.cc[u][lane] = A.cc[u];
+          T.vv[u][lane] = A.vv[u];
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) *produced = seq + 1;
+      if (!more) return;
+      A = B;
+    }
+  }
+
+  // ---------------- compute wave ----------------
+  unsigned seq = 0;
+  for (int grp = first; grp < ngroups; grp += step) {
+    const SlabGroup G = groups[grp];
+    for (int sweep = 0; sweep < 2; ++sweep) {
+      const bool upper = sweep == 1;
+      const int64_t *sp = wave_step_ptr + G.step_ptr + (int64_t)sweep * (SLAB_W + 1);
+      const int64_t s_begin = sp[rank], s_end = sp[rank + 1];
+      unsigned *prog = progress + G.prog_off + (int64_t)sweep * SLAB_W * 32;
+      const int nlev = upper ? G.nlevU : G.nlevL;
+      const double *src = upper ? x : y;
+      double *dst = upper ? x : y;
+      // progress protocol: word[k] = (epoch, p) means "every row of wave k with level < p is stored".
+      //  * lazy publish: once the gathers of a step have returned, all earlier stores of this wave are complete
+      //    (vmcnt retires in order), so p = level of the current step can be published without a drain;
+      //  * before blocking on other waves the wave drains and publishes, so nobody waits on a wave that waits.
+      int pl = 0; // lane j: last progress seen of wave j
+      unsigned *myword = prog + rank * 32;
+      auto publish = [&](int p) {
+        if (lane == 0) {
+          const unsigned word = (epoch << 22) | (unsigned)p;
+          if (wt) __hip_atomic_store(myword, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else *(volatile unsigned *)myword = word;
+        }
+      };
+      for (int64_t si = s_begin; si < s_end; ++si) {
+        const SlabStep D = steps[si];
+        const int nchunk = (D.m + 63) >> 6;
+        for (int c = 0; c < nchunk; ++c, ++seq) {
+          for (unsigned spins = 0; *produced <= seq; ++spins) {
+            if (spins > (1u << 24)) {
+              if (lane == 0) __hip_atomic_store(err, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              return;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          const TrsvLdsTile &T = S.tile[seq % TRSV_L_SLOTS];
+          const int32_t rowm = T.row[lane];
+          const bool act = rowm >= 0;
+          const int32_t row = act ? rowm : -1 - rowm;
+          const double s0 = T.s0[lane];
+          int32_t cc[TRSV_UNROLL];
+          double vv[TRSV_UNROLL], xv[TRSV_UNROLL];
+#pragma unroll
+          for (int u = 0; u < TRSV_UNROLL; ++u) {
+            cc[u] = 0;
+            vv[u] = 0.0;
+            if (u < D.w) {
+              cc[u] = T.cc[u][lane];
+              vv[u] = T.vv[u][lane];
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (lane == 0) *consumed = seq + 1;
+          // rows of level D.level need the rows of levels < D.level of the waves in dep_mask
+          if (c == 0) {
+            const bool dep = lane < SLAB_W && ((D.dep_mask >> lane) & 1u);
+            if (!__all(!dep || pl >= D.level)) {
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // about to wait: first tell the others how far this wave is
+              publish(D.level);
+              for (unsigned spins = 0;; ++spins) {
+                if (dep) {
+                  const unsigned v = __hip_atomic_load(prog + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  pl = (v >> 22) == epoch ? (int)(v & 0x3FFFFFu) : 0;
+                }
+                if (__all(!dep || pl >= D.level)) break;
+                if (spins > (1u << 22)) {
+                  if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  break;
+                }
+              }
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < TRSV_UNROLL; ++u) {
+            xv[u] = 0.0;
+            if (u < D.w) xv[u] = ld_sc1(src + cc[u]);
+          }
+          double s = upper ? ld_sc1(y + row) : s0;
+#pragma unroll
+          for (int u = 0; u < TRSV_UNROLL; ++u) s -= vv[u] * xv[u];
+          if (D.w > TRSV_UNROLL) {
+            const int r = (c << 6) + lane;
+            const int rr = r < D.m ? r : D.m - 1;
+            for (int k = TRSV_UNROLL; k < D.w; ++k)
+              s -= valsA[D.ent_off + (int64_t)k * D.m + rr] * ld_sc1(src + colsA[D.ent_off + (int64_t)k * D.m + rr]);
+          }
+          asm volatile("" ::"v"(s)); // the gathers have returned here => every earlier store of this wave is complete
+          if (c == 0) publish(D.level);
+          const double out = upper ? s * s0 : s;
+          if (act) {
+            if (wt) st_sc1(dst + row, out);
+            else dst[row] = out;
+          }
+        }
+      }
+      if (s_begin < s_end) { // end of the sweep: everything is stored
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        publish(nlev);
+      }
+      if (s_begin == s_end && lane == 0) { // a wave without rows in this sweep still reports completion
+        const unsigned word = (epoch << 22) | (unsigned)nlev;
+        unsigned *f = prog + rank * 32;
+        if (wt) __hip_atomic_store(f, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *(volatile unsigned *)f = word;
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

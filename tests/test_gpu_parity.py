@@ -64,7 +64,7 @@ def test_csr_mv_usmv_random_and_edge_cases(ddm, torch_cuda):
     ctx.close()
 
 
-@pytest.mark.parametrize("trsv_mode", ["xcdw", "xcd3", "xcd2", "xcd", "syncfree", "persistent", "levels"])
+@pytest.mark.parametrize("trsv_mode", ["slab", "xcdw", "xcd3", "xcd2", "xcd", "syncfree", "persistent", "levels"])
 def test_ilu0_factor_and_solve(ddm, torch_cuda, trsv_mode, monkeypatch):
     """all triangular-solve engines: XCD-local single launch (default), data-driven, level counters, one launch per level"""
     monkeypatch.setenv("DDM_TRSV_MODE", trsv_mode)

@@ -66,6 +66,55 @@ __global__ __launch_bounds__(64) void k_chain(int mode, int nlev, unsigned *tick
   }
 }
 
+// mode 2: "slab ownership": a wave reads back values IT stored one level earlier (no flag, no drain: same-wave
+// store -> sc1 load through L2) plus ONE progress word of its predecessor wave; 13 x 64 scattered gathers,
+// 64 scattered stores per level, progress published lazily once the gathers have returned (in-order vmcnt
+// then implies that the previous level's stores are complete).
+__global__ __launch_bounds__(64) void k_slab(int nlev, unsigned *tickets, unsigned *arrived, unsigned *progress, double *x, unsigned *err, double *sink)
+{
+  const int lane = threadIdx.x;
+  unsigned xcc = 0, t = 0;
+  if (lane == 0) {
+    xcc = xcc_id();
+    t = atomicAdd(&tickets[xcc], 1u);
+    __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  xcc = __builtin_amdgcn_readfirstlane(xcc);
+  t = __builtin_amdgcn_readfirstlane(t);
+  for (unsigned spins = 0; __hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x; ++spins) {
+    if (spins > (1u << 22)) { *err = 1; return; }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  const unsigned W = __hip_atomic_load(&tickets[xcc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  double *xs = x + ((size_t)xcc * 64 + t) * (size_t)(1 << 17);   // 1 MB slab per wave
+  unsigned *prog = progress + xcc * 64 * 32;                      // one 128-B line per wave
+  double acc = 1.0 + lane;
+  for (int lev = 0; lev < nlev; ++lev) {
+    if (t > 0 && lev > 0) { // predecessor must have completed level lev-1
+      for (unsigned spins = 0;; ++spins) {
+        const unsigned p = __hip_atomic_load(prog + (t - 1) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p >= (unsigned)lev) break;
+        if (spins > (1u << 22)) { *err = 2; return; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    double s = 0.0;
+    if (lev > 0) {
+#pragma unroll
+      for (int u = 0; u < 13; ++u) {
+        const size_t idx = ((size_t)(lev - 1) * 64 + ((lane * 7 + u * 5) & 63)) * 17 % (1 << 17); // scattered, written one level ago
+        s += __longlong_as_double((long long)__hip_atomic_load((unsigned long long *)(xs + idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      }
+    }
+    // gathers returned => stores of level lev-1 are complete (vmcnt retires in order): publish lazily
+    if (lev > 0 && lane == 0) *(volatile unsigned *)(prog + t * 32) = (unsigned)lev;
+    acc = 0.5 * acc + 1e-3 * s;
+    xs[((size_t)lev * 64 + lane) * 17 % (1 << 17)] = acc; // plain store: stays in this XCD's L2
+  }
+  if (lane == 0) sink[blockIdx.x] = acc;
+  (void)W;
+}
+
 int main()
 {
   const int nlev = 2000, G = 256;
@@ -104,5 +153,27 @@ int main()
       for (int i = 0; i < 8; ++i) printf(" %d", hist[i]);
       printf("\n");
     }
+  {
+    unsigned *progress;
+    double *xs, *sink;
+    CHECK(hipMalloc(&progress, 8 * 64 * 32 * 4));
+    CHECK(hipMalloc(&xs, (size_t)8 * 64 * (1 << 17) * 8));
+    CHECK(hipMalloc(&sink, G * 8));
+    for (int rep = 0; rep < 3; ++rep) {
+      CHECK(hipMemset(tickets, 0, 64));
+      CHECK(hipMemset(arrived, 0, 64));
+      CHECK(hipMemset(err, 0, 64));
+      CHECK(hipMemset(progress, 0, 8 * 64 * 32 * 4));
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(k_slab, dim3(G), dim3(64), 0, 0, nlev, tickets, arrived, progress, xs, err, sink);
+      hipEventRecord(e1);
+      CHECK(hipDeviceSynchronize());
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      unsigned herr;
+      hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost);
+      printf("mode 2 (slab ownership) rep %d: %.3f ms total, %.3f us per level, err %u\n", rep, ms, 1e3 * ms / nlev, herr);
+    }
+  }
   return 0;
 }
