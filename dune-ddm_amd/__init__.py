@@ -66,6 +66,7 @@ SYMBOLS = {
     "ddm_ilu0_solve": (_I32, [_P, _P, _P, _P]),
     "ddm_ilu0_debug_stamps": (_I32, [_P, _P, _P, _P, _P]),
     "ddm_ilu0_status": (_I32, [_P, _P, ctypes.POINTER(ctypes.c_int)]),
+    "ddm_ilu0_pipe_trace": (_I32, [_P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(ctypes.c_int64)]),
     "ddm_ilu0_num_levels": (_I64, [_P, _I32]),
     "ddm_ilu0_get_factors_host": (_I32, [_P, _P, _P]),
     "ddm_halo_create": (_I32, [_P, _I32, _I32, _I64, _P, _P, _P, _I64, _P, _P, _P, _PP]),
@@ -253,6 +254,15 @@ class Ilu0:
         out = np.zeros(8, dtype=np.uint64)
         self.ctx.check(self.ctx.lib.ddm_ilu0_debug_stamps(self.ctx.h, self.h, _ptr(d), _ptr(x), _hp(out)))
         return out
+
+    def pipe_trace(self, d, x):
+        """diagnostic: (stamps[ntasks, 8] uint64, meta[ntasks, 2] int32 = group, sweep) of one pipe-engine solve"""
+        nt = ctypes.c_int64()
+        self.ctx.check(self.ctx.lib.ddm_ilu0_pipe_trace(self.ctx.h, self.h, None, None, None, None, 0, ctypes.byref(nt)))
+        out = np.zeros((nt.value, 8), dtype=np.uint64)
+        meta = np.zeros((nt.value, 2), dtype=np.int32)
+        self.ctx.check(self.ctx.lib.ddm_ilu0_pipe_trace(self.ctx.h, self.h, _ptr(d), _ptr(x), _hp(out), _hp(meta), nt.value, ctypes.byref(nt)))
+        return out, meta
 
     def status(self):
         st = ctypes.c_int()

@@ -2,6 +2,7 @@
 // HIP graphs, the CG driver) around the kernels in kernels.hpp.  gfx950 only, no fallback path.
 #include "../../include/ddm_hip.h"
 #include "kernels.hpp"
+#include "trsv_pipe.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -414,6 +415,19 @@ struct ddm_ilu0 {
   double *xdperm = nullptr;     // right-hand side permuted into level order (loader engine)
   int64_t *xlpos = nullptr;     // positions of the L parts (only those need the permuted right-hand side)
   int64_t xnrows = 0;
+  // pipe engine (mode 8): chains x tasks, see trsv_pipe_host.hpp
+  int pipe_state = 0;           // 0 not built, 1 built, -1 not applicable
+  pipe::Group *p_groups = nullptr;
+  pipe::Task *p_tasks = nullptr;
+  unsigned char *p_stream = nullptr;
+  int32_t *p_koff = nullptr, *p_rowL = nullptr, *p_posU = nullptr;
+  double *p_dperm = nullptr, *p_ypos = nullptr, *p_xpos = nullptr;
+  unsigned long long *p_progress = nullptr;
+  unsigned *p_queue = nullptr;
+  int64_t p_nposL = 0, p_nposU = 0;
+  int p_grid = 0, p_lazy = 1;
+  pipe::Stats p_stats;
+  int64_t p_stream_bytes = 0;
   // slab-ownership engine (mode 7)
   bool slab_built = false;
   SlabGroup *sg = nullptr;
@@ -580,7 +594,7 @@ extern "C" int ddm_ilu0_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, 
     }
   int rc = build_schedule(ctx, A, F->h_lu, diag, false, F->L);
   if (!rc) rc = build_schedule(ctx, A, F->h_lu, diag, true, F->U);
-  if (const char *m = std::getenv("DDM_TRSV_MODE")) F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "syncfree") ? 2 : (!std::strcmp(m, "persistent") ? 1 : (!std::strcmp(m, "xcd") ? 3 : (!std::strcmp(m, "xcd3") ? 5 : (!std::strcmp(m, "xcdw") ? 6 : (!std::strcmp(m, "slab") ? 7 : 4))))));
+  if (const char *m = std::getenv("DDM_TRSV_MODE")) F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "syncfree") ? 2 : (!std::strcmp(m, "persistent") ? 1 : (!std::strcmp(m, "xcd") ? 3 : (!std::strcmp(m, "xcd3") ? 5 : (!std::strcmp(m, "xcdw") ? 6 : (!std::strcmp(m, "slab") ? 7 : (!std::strcmp(m, "pipe") ? 8 : 4)))))));
   F->A = A;
   F->h_diag = diag;
   F->h_block_ptr.assign(block_ptr, block_ptr + nblocks + 1);
@@ -616,6 +630,17 @@ extern "C" void ddm_ilu0_destroy(ddm_ilu0 *F)
   (void)hipFree(F->xstate);
   (void)hipFree(F->xdperm);
   (void)hipFree(F->xlpos);
+  (void)hipFree(F->p_groups);
+  (void)hipFree(F->p_tasks);
+  (void)hipFree(F->p_stream);
+  (void)hipFree(F->p_koff);
+  (void)hipFree(F->p_rowL);
+  (void)hipFree(F->p_posU);
+  (void)hipFree(F->p_dperm);
+  (void)hipFree(F->p_ypos);
+  (void)hipFree(F->p_xpos);
+  (void)hipFree(F->p_progress);
+  (void)hipFree(F->p_queue);
   (void)hipFree(F->sg);
   (void)hipFree(F->s_wave_ptr);
   (void)hipFree(F->s_lpos);
@@ -1128,6 +1153,98 @@ static int build_slab_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
   return DDM_OK;
 }
 
+// Chain/task schedule of the pipe engine (mode 8); falls back to the loader engine (mode 4) when the builder
+// reports that the matrix does not fit the tile format.
+static int build_pipe_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
+{
+  const ddm_csr *A = F->A;
+  pipe::Options opt;
+  if (const char *e = std::getenv("DDM_PIPE_DELTA")) opt.delta = std::atoi(e);
+  if (const char *e = std::getenv("DDM_PIPE_SPAN")) opt.max_span = std::atoi(e);
+  if (const char *e = std::getenv("DDM_PIPE_REUSE")) opt.vote = std::atoi(e);
+  if (const char *e = std::getenv("DDM_PIPE_LAZY")) F->p_lazy = std::atoi(e);
+  pipe::Schedule S;
+  const int nb = (int)F->h_block_ptr.size() - 1;
+  if (!pipe::build(A->nrows, A->h_rp.data(), A->h_ci.data(), F->h_lu.data(), F->h_diag.data(), nb, F->h_block_ptr.data(), opt, S)) {
+    F->pipe_state = -1;
+    if (std::getenv("DDM_PIPE_VERBOSE")) std::fprintf(stderr, "[ddm] pipe engine not applicable: %s\n", S.error.c_str());
+    return DDM_OK;
+  }
+  F->ngroups = nb;
+  F->p_stats = S.stats;
+  F->p_stream_bytes = (int64_t)S.stream.size();
+  F->p_nposL = S.nposL;
+  F->p_nposU = S.nposU;
+  DDMCHECK(upload(ctx, S.groups.data(), (int64_t)S.groups.size(), &F->p_groups));
+  DDMCHECK(upload(ctx, S.tasks.data(), (int64_t)S.tasks.size(), &F->p_tasks));
+  DDMCHECK(upload(ctx, S.stream.data(), (int64_t)S.stream.size(), &F->p_stream));
+  DDMCHECK(upload(ctx, S.koff.data(), (int64_t)S.koff.size(), &F->p_koff));
+  DDMCHECK(upload(ctx, S.rowL.data(), (int64_t)S.rowL.size(), &F->p_rowL));
+  DDMCHECK(upload(ctx, S.posU.data(), (int64_t)S.posU.size(), &F->p_posU));
+  HIPCHECK(ctx, hipMalloc((void **)&F->p_dperm, sizeof(double) * (size_t)std::max<int64_t>(S.nposL, 1)));
+  HIPCHECK(ctx, hipMalloc((void **)&F->p_ypos, sizeof(double) * (size_t)std::max<int64_t>(S.nposL, 1)));
+  HIPCHECK(ctx, hipMalloc((void **)&F->p_xpos, sizeof(double) * (size_t)std::max<int64_t>(S.nposU, 1)));
+  HIPCHECK(ctx, hipMemset(F->p_ypos, 0, sizeof(double) * (size_t)std::max<int64_t>(S.nposL, 1)));
+  HIPCHECK(ctx, hipMemset(F->p_xpos, 0, sizeof(double) * (size_t)std::max<int64_t>(S.nposU, 1)));
+  const size_t pbytes = sizeof(unsigned long long) * 16 * std::max<size_t>(S.tasks.size(), 1);
+  HIPCHECK(ctx, hipMalloc((void **)&F->p_progress, pbytes));
+  HIPCHECK(ctx, hipMemset(F->p_progress, 0, pbytes));
+  HIPCHECK(ctx, hipMalloc((void **)&F->p_queue, sizeof(unsigned) * 32 * 4 * (size_t)nb));
+  HIPCHECK(ctx, hipMemset(F->p_queue, 0, sizeof(unsigned) * 32 * 4 * (size_t)nb));
+  if (!F->xstate) {
+    HIPCHECK(ctx, hipMalloc((void **)&F->xstate, sizeof(XcdState)));
+    HIPCHECK(ctx, hipMemset(F->xstate, 0, sizeof(XcdState)));
+  }
+  HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_pipe<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS_BYTES));
+  HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_pipe<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS_BYTES));
+  HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_pipe<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS_BYTES));
+  int per_cu = 0;
+  HIPCHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_trsv_pipe<true, false>, 64 * (1 + PIPE_NL), PIPE_LDS_BYTES));
+  per_cu = std::max(1, std::min(per_cu, 2));
+  if (const char *e = std::getenv("DDM_PIPE_WG_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(e)));
+  F->p_grid = per_cu * (ctx->num_cu / 8 * 8);
+  if (std::getenv("DDM_PIPE_VERBOSE")) {
+    const pipe::Stats &st = S.stats;
+    std::fprintf(stderr,
+                 "[ddm] pipe schedule: %lld rows, tasks %lld+%lld, steps %lld+%lld (lane occupancy %.3f / %.3f), entries %lld: local %.3f self-global %.3f remote %.3f, "
+                 "stream %.1f MB (%.2fx of 12 B/entry), max producers %lld, max steps %lld, regrouped %lld, grid %d\n",
+                 (long long)st.rows, (long long)st.ntasks[0], (long long)st.ntasks[1], (long long)st.nsteps[0], (long long)st.nsteps[1],
+                 (double)st.rows / (64.0 * std::max<int64_t>(st.nsteps[0], 1)), (double)st.rows / (64.0 * std::max<int64_t>(st.nsteps[1], 1)), (long long)st.entries,
+                 (double)st.entries_local / std::max<int64_t>(st.entries, 1), (double)st.entries_self_global / std::max<int64_t>(st.entries, 1),
+                 (double)st.entries_remote / std::max<int64_t>(st.entries, 1), S.stream.size() / 1e6, S.stream.size() / (12.0 * std::max<int64_t>(st.entries, 1)),
+                 (long long)st.max_prod, (long long)st.max_steps, (long long)st.regrouped, F->p_grid);
+  }
+  F->pipe_state = 1;
+  return DDM_OK;
+}
+
+static void enqueue_pipe(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, unsigned long long *stamps, unsigned long long *dbg = nullptr)
+{
+  PipeParams P;
+  P.ngroups = F->ngroups;
+  P.groups = F->p_groups;
+  P.tasks = F->p_tasks;
+  P.stream = F->p_stream;
+  P.koff = F->p_koff;
+  P.dperm = F->p_dperm;
+  P.ypos = F->p_ypos;
+  P.xpos = F->p_xpos;
+  P.progress = F->p_progress;
+  P.queue = F->p_queue;
+  P.st = F->xstate;
+  P.err = F->err;
+  P.stamps = stamps;
+  P.dbg = dbg;
+  P.nposL_bytes = (unsigned)(F->p_nposL * 8);
+  P.nposU_bytes = (unsigned)(F->p_nposU * 8);
+  hipLaunchKernelGGL(k_pipe_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate, F->p_queue, F->ngroups * 4);
+  hipLaunchKernelGGL(k_pipe_permute_in, dim3(grid_for(F->p_nposL)), dim3(WG), 0, ctx->stream, F->p_nposL, F->p_rowL, d, F->p_dperm);
+  if (stamps) hipLaunchKernelGGL((k_trsv_pipe<true, true>), dim3(F->p_grid), dim3(64 * (1 + PIPE_NL)), PIPE_LDS_BYTES, ctx->stream, P);
+  else if (F->p_lazy) hipLaunchKernelGGL((k_trsv_pipe<true, false>), dim3(F->p_grid), dim3(64 * (1 + PIPE_NL)), PIPE_LDS_BYTES, ctx->stream, P);
+  else hipLaunchKernelGGL((k_trsv_pipe<false, false>), dim3(F->p_grid), dim3(64 * (1 + PIPE_NL)), PIPE_LDS_BYTES, ctx->stream, P);
+  hipLaunchKernelGGL(k_pipe_permute_out, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, F->p_posU, F->p_xpos, x);
+}
+
 static int enqueue_tri(ddm_ctx *ctx, const TriSchedule &S, bool upper, const double *d, double *x)
 {
   for (const auto &p : S.plan) {
@@ -1183,6 +1300,41 @@ extern "C" int ddm_ilu0_debug_stamps(ddm_ctx *ctx, ddm_ilu0 *F, const double *d,
   return rc;
 }
 
+// Diagnostic (not part of the product path): one solve with the stamped build of the pipe kernel.  Per task 8 words
+// (layout: trsv_pipe.hpp, STAMP) followed by nothing; returns the number of tasks in *ntasks.  out_host may be null
+// to query the size.  Also reports group / sweep of every task in meta_host[2 * ntasks] when given.
+extern "C" int ddm_ilu0_pipe_trace(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, unsigned long long *out_host, int32_t *meta_host,
+                                   int64_t capacity_tasks, int64_t *ntasks)
+{
+  if (!F || !ntasks) return fail(ctx, DDM_EINVAL, "ddm_ilu0_pipe_trace: bad arguments");
+  if (F->pipe_state == 0) DDMCHECK(build_pipe_schedule(ctx, F));
+  if (F->pipe_state < 0) return fail(ctx, DDM_EINVAL, "pipe engine not applicable to this matrix");
+  const int64_t nt = F->p_stats.ntasks[0] + F->p_stats.ntasks[1];
+  *ntasks = nt;
+  if (!out_host) return DDM_OK;
+  if (capacity_tasks < nt || !d || !x || d == x) return fail(ctx, DDM_EINVAL, "ddm_ilu0_pipe_trace: bad arguments");
+  unsigned long long *st = nullptr;
+  HIPCHECK(ctx, hipMalloc((void **)&st, sizeof(unsigned long long) * 8 * (size_t)(nt + 1)));
+  HIPCHECK(ctx, hipMemsetAsync(st, 0, sizeof(unsigned long long) * 8 * (size_t)(nt + 1), ctx->stream));
+  enqueue_pipe(ctx, F, d, x, st, st + 8 * nt);
+  int rc = ddm_memcpy_d2h(ctx, out_host, st, (int64_t)sizeof(unsigned long long) * 8 * nt);
+  unsigned long long dbg[8] = {0};
+  if (!rc) rc = ddm_memcpy_d2h(ctx, dbg, st + 8 * nt, (int64_t)sizeof(dbg));
+  if (!rc && dbg[0])
+    std::fprintf(stderr, "[ddm] pipe trace: %llu out-of-range operands; first: task %llu step %llu lane %llu own %llu entry %lld op %llu tile-pos %llu W %llu (limits L %lld U %lld bytes)\n", dbg[0],
+                 dbg[1], dbg[2], dbg[3], dbg[4], (long long)dbg[5], dbg[6], dbg[7] >> 32, dbg[7] & 0xffffffffull, (long long)F->p_nposL * 8, (long long)F->p_nposU * 8);
+  if (!rc && meta_host) {
+    std::vector<pipe::Task> tasks((size_t)nt);
+    rc = ddm_memcpy_d2h(ctx, tasks.data(), F->p_tasks, (int64_t)sizeof(pipe::Task) * nt);
+    for (int64_t t = 0; t < nt && !rc; ++t) {
+      meta_host[2 * t] = tasks[(size_t)t].group;
+      meta_host[2 * t + 1] = tasks[(size_t)t].sweep;
+    }
+  }
+  (void)hipFree(st);
+  return rc;
+}
+
 extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x)
 {
   if (F && F->n == 0) return DDM_OK;
@@ -1196,6 +1348,8 @@ extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double
     (void)hipGraphExecDestroy(F->graph);
     F->graph = nullptr;
   }
+  if (F->mode == 8 && F->pipe_state == 0) DDMCHECK(build_pipe_schedule(ctx, F));
+  if (F->mode == 8 && F->pipe_state < 0) F->mode = 4; // not applicable: the loader engine takes any matrix
   if (F->mode == 7 && !F->slab_built) DDMCHECK(build_slab_schedule(ctx, F));
   if (F->mode == 6 && F->w_state == 0) DDMCHECK(build_xcdw_schedule(ctx, F));
   if (F->mode == 6 && F->w_state < 0) F->mode = 3; // rows wider than a tile: use the gather-based XCD engine
@@ -1203,7 +1357,9 @@ extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double
   hipGraph_t g = nullptr;
   HIPCHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
   int rc = DDM_OK;
-  if (F->mode == 7) {
+  if (F->mode == 8) {
+    enqueue_pipe(ctx, F, d, x, nullptr);
+  } else if (F->mode == 7) {
     hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
     hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, F->s_lpos, F->s_rows, d, F->s_dperm);
     hipLaunchKernelGGL(k_trsv_slab, dim3(persistent_grid(ctx)), dim3(128), sizeof(TrsvLds), ctx->stream, F->ngroups, F->sg, F->s_wave_ptr, F->s_steps,
