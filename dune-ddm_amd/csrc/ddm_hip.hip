@@ -398,7 +398,7 @@ struct TriSchedule { // one triangular factor, level by level in sliced ELL
 
 struct ddm_ilu0 {
   int64_t n = 0, nnz = 0;
-  int mode = 4;                 // 4 = XCD-local + loader wave (default), 3 = XCD-local single wave, 5 = dataflow, 6 = LDS-staged windows, 1 = single launch + level counters, 2 = data-driven, 0 = launch per level
+  int mode = 8;                 // 8 = pipe (default; falls back to 4 when not applicable), 4 = XCD-local + loader wave, 3 = XCD-local single wave, 5 = dataflow, 6 = LDS-staged windows, 1 = single launch + level counters, 2 = data-driven, 0 = launch per level
   double *ywork = nullptr;      // forward-solve result of the data-driven kernel
   // XCD-local engine (mode 3): per-block (subdomain) level schedules, built on first use
   std::vector<int64_t> h_diag, h_block_ptr;
@@ -594,7 +594,7 @@ extern "C" int ddm_ilu0_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, 
     }
   int rc = build_schedule(ctx, A, F->h_lu, diag, false, F->L);
   if (!rc) rc = build_schedule(ctx, A, F->h_lu, diag, true, F->U);
-  if (const char *m = std::getenv("DDM_TRSV_MODE")) F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "syncfree") ? 2 : (!std::strcmp(m, "persistent") ? 1 : (!std::strcmp(m, "xcd") ? 3 : (!std::strcmp(m, "xcd3") ? 5 : (!std::strcmp(m, "xcdw") ? 6 : (!std::strcmp(m, "slab") ? 7 : (!std::strcmp(m, "pipe") ? 8 : 4)))))));
+  if (const char *m = std::getenv("DDM_TRSV_MODE")) F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "syncfree") ? 2 : (!std::strcmp(m, "persistent") ? 1 : (!std::strcmp(m, "xcd") ? 3 : (!std::strcmp(m, "xcd3") ? 5 : (!std::strcmp(m, "xcdw") ? 6 : (!std::strcmp(m, "slab") ? 7 : (!std::strcmp(m, "xcd2") ? 4 : 8)))))));
   F->A = A;
   F->h_diag = diag;
   F->h_block_ptr.assign(block_ptr, block_ptr + nblocks + 1);
