@@ -1199,7 +1199,7 @@ static int build_pipe_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
   HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_pipe<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS_BYTES));
   HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_pipe<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS_BYTES));
   int per_cu = 0;
-  HIPCHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_trsv_pipe<true, false>, 64 * (1 + PIPE_NL), PIPE_LDS_BYTES));
+  HIPCHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_trsv_pipe<true, false>, 64 * (PIPE_NC + PIPE_NL), PIPE_LDS_BYTES));
   per_cu = std::max(1, std::min(per_cu, 2));
   if (const char *e = std::getenv("DDM_PIPE_WG_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(e)));
   F->p_grid = per_cu * (ctx->num_cu / 8 * 8);
@@ -1239,9 +1239,9 @@ static void enqueue_pipe(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, 
   P.nposU_bytes = (unsigned)(F->p_nposU * 8);
   hipLaunchKernelGGL(k_pipe_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate, F->p_queue, F->ngroups * 4);
   hipLaunchKernelGGL(k_pipe_permute_in, dim3(grid_for(F->p_nposL)), dim3(WG), 0, ctx->stream, F->p_nposL, F->p_rowL, d, F->p_dperm);
-  if (stamps) hipLaunchKernelGGL((k_trsv_pipe<true, true>), dim3(F->p_grid), dim3(64 * (1 + PIPE_NL)), PIPE_LDS_BYTES, ctx->stream, P);
-  else if (F->p_lazy) hipLaunchKernelGGL((k_trsv_pipe<true, false>), dim3(F->p_grid), dim3(64 * (1 + PIPE_NL)), PIPE_LDS_BYTES, ctx->stream, P);
-  else hipLaunchKernelGGL((k_trsv_pipe<false, false>), dim3(F->p_grid), dim3(64 * (1 + PIPE_NL)), PIPE_LDS_BYTES, ctx->stream, P);
+  if (stamps) hipLaunchKernelGGL((k_trsv_pipe<true, true>), dim3(F->p_grid), dim3(64 * (PIPE_NC + PIPE_NL)), PIPE_LDS_BYTES, ctx->stream, P);
+  else if (F->p_lazy) hipLaunchKernelGGL((k_trsv_pipe<true, false>), dim3(F->p_grid), dim3(64 * (PIPE_NC + PIPE_NL)), PIPE_LDS_BYTES, ctx->stream, P);
+  else hipLaunchKernelGGL((k_trsv_pipe<false, false>), dim3(F->p_grid), dim3(64 * (PIPE_NC + PIPE_NL)), PIPE_LDS_BYTES, ctx->stream, P);
   hipLaunchKernelGGL(k_pipe_permute_out, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, F->p_posU, F->p_xpos, x);
 }
 
@@ -1314,12 +1314,12 @@ extern "C" int ddm_ilu0_pipe_trace(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, d
   if (!out_host) return DDM_OK;
   if (capacity_tasks < nt || !d || !x || d == x) return fail(ctx, DDM_EINVAL, "ddm_ilu0_pipe_trace: bad arguments");
   unsigned long long *st = nullptr;
-  HIPCHECK(ctx, hipMalloc((void **)&st, sizeof(unsigned long long) * 8 * (size_t)(nt + 1)));
-  HIPCHECK(ctx, hipMemsetAsync(st, 0, sizeof(unsigned long long) * 8 * (size_t)(nt + 1), ctx->stream));
-  enqueue_pipe(ctx, F, d, x, st, st + 8 * nt);
-  int rc = ddm_memcpy_d2h(ctx, out_host, st, (int64_t)sizeof(unsigned long long) * 8 * nt);
+  HIPCHECK(ctx, hipMalloc((void **)&st, sizeof(unsigned long long) * 16 * (size_t)(nt + 1)));
+  HIPCHECK(ctx, hipMemsetAsync(st, 0, sizeof(unsigned long long) * 16 * (size_t)(nt + 1), ctx->stream));
+  enqueue_pipe(ctx, F, d, x, st, st + 16 * nt);
+  int rc = ddm_memcpy_d2h(ctx, out_host, st, (int64_t)sizeof(unsigned long long) * 16 * nt);
   unsigned long long dbg[8] = {0};
-  if (!rc) rc = ddm_memcpy_d2h(ctx, dbg, st + 8 * nt, (int64_t)sizeof(dbg));
+  if (!rc) rc = ddm_memcpy_d2h(ctx, dbg, st + 16 * nt, (int64_t)sizeof(dbg));
   if (!rc && dbg[0])
     std::fprintf(stderr, "[ddm] pipe trace: %llu out-of-range operands; first: task %llu step %llu lane %llu own %llu entry %lld op %llu tile-pos %llu W %llu (limits L %lld U %lld bytes)\n", dbg[0],
                  dbg[1], dbg[2], dbg[3], dbg[4], (long long)dbg[5], dbg[6], dbg[7] >> 32, dbg[7] & 0xffffffffull, (long long)F->p_nposL * 8, (long long)F->p_nposU * 8);

@@ -1,9 +1,14 @@
 // Device side of the "pipe" triangular-solve engine; schedule format and rationale: trsv_pipe_host.hpp.
 //
-// One workgroup = one compute wave + PIPE_NL loader waves; two workgroups per CU.  Workgroups pull tasks (64 chains walked level by level)
-// from a per-(subdomain, sweep) queue in topological order.  The loader waves stream the task's tiles HBM -> LDS
-// with LDS-DMA (global_load_lds_dwordx4, 1 KiB per instruction) into a byte ring, far ahead of the compute wave.
-// The compute wave per step: operands of the own task from the LDS result ring, operands of other tasks by sc1
+// One workgroup = PIPE_NC compute waves + PIPE_NL loader waves; two workgroups per CU.  Workgroups pull tasks (64
+// chains walked level by level) from a per-(subdomain, sweep) queue in topological order.  The loader waves stream the
+// task's tiles HBM -> LDS with LDS-DMA (global_load_lds_dwordx4, 1 KiB per instruction) into a byte ring, far ahead of
+// the compute waves.  A lone wave issues one instruction every ~4 cycles and a step is ~300 instructions, so the steps
+// of a task ALTERNATE between the compute waves: wave w takes steps w, w + NC, ...; everything of its step that does
+// not depend on the previous step (tile reads, progress check, remote gathers, ring operands older than NC steps, the
+// products and the head of the row sum) runs while the other wave finishes the previous step; only the operands
+// flagged in the tile's late mask are read after the previous step has signalled (one LDS word).
+// Per step: operands of the own task from the LDS result ring, operands of other tasks by sc1
 // gathers from the position arrays (guarded by the producers' progress words, which are normally far ahead), the
 // row sum in ascending column order (= the sequential back-solve), one coalesced 512-byte store of the 64 results.
 //
@@ -19,25 +24,30 @@
 
 namespace ddm {
 
-constexpr int PIPE_NL = 2;          // loader waves per workgroup (two workgroups per CU = 6 waves: at most 256 VGPRs per wave)
+constexpr int PIPE_NC = 1;          // compute waves per workgroup (steps of a task alternate between them)
+constexpr int PIPE_NL = 2;          // loader waves per workgroup
 constexpr int PIPE_DEPTH = 3;       // tiles a loader keeps in flight
-constexpr int PIPE_RING_KIB = 64;   // LDS byte ring of tiles per workgroup
+constexpr int PIPE_RING_KIB = 64;   // LDS byte ring of tiles per workgroup: one workgroup per CU.  2 NC tiles (the current and the
+                                    // prefetched step of every compute wave) + one in flight must fit, or loaders and compute waves
+                                    // would wait for each other: 5 tiles of the widest row the builder accepts (pipe::MAX_W)
+constexpr int PIPE_WIDE = 6;        // further entries of a wide row handled with one gather latency
 constexpr int PIPE_READY = 32;      // ready words (tiles in flight < 32: the smallest tile is 3 KiB)
 constexpr int PIPE_CHUNK = pipe::MIN_W; // entries of a row held in registers; every tile has at least that many (padded), wider rows take the rest from the tile
-constexpr int PIPE_RINGAREA = (pipe::RING_BYTES + 4 * (PIPE_READY + 8) + 1023) / 1024 * 1024; // result ring + control words
+constexpr int PIPE_RINGAREA = (pipe::RING_BYTES + 4 * (PIPE_READY + 16) + 1023) / 1024 * 1024; // result ring + control words
 constexpr size_t PIPE_LDS_BYTES = (size_t)PIPE_RINGAREA + (size_t)PIPE_RING_KIB * 1024; // dynamic part
 
-struct PipeStep { // registers of one step, filled one step ahead of their use (the factor entries themselves are read
-                  // from the tile when the step is computed: two sets of them would not fit the register budget)
-  int32_t op[PIPE_CHUNK];
+struct PipeStep { // registers of one step, filled NC steps ahead of their use (operand words and factor entries are read
+                  // again from the tile when the step is computed: two sets of them would not fit the register budget)
   double xg[PIPE_CHUNK];
   double s0;
   int W;
+  unsigned late;       // entries whose ring operand may come from one of the NC - 1 steps before this one
   unsigned tpos, vend; // tile position in the LDS ring (KiB), virtual ring offset behind the tile
 };
 __device__ __forceinline__ double pipe_ld_sc1_off(const double *base, uint32_t byte_off)
 {
-  const unsigned long long *p = reinterpret_cast<const unsigned long long *>(reinterpret_cast<const unsigned char *>(base) + byte_off);
+  typedef const __attribute__((address_space(1))) unsigned char *gbytes; // global, not flat: base is a kernel-argument array
+  const __attribute__((address_space(1))) unsigned long long *p = (const __attribute__((address_space(1))) unsigned long long *)((gbytes)(uintptr_t)base + byte_off);
   return __longlong_as_double((long long)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 // waits until at most n of the wave's vector-memory operations are outstanding (rounded down to a multiple of 4: stricter)
@@ -111,6 +121,11 @@ __device__ __forceinline__ void pipe_wait_gathers(double &s0, double (&x)[PIPE_C
                : "n"(N)
                : "memory");
 }
+__device__ __forceinline__ void pipe_pin(double &s, double (&x)[PIPE_CHUNK])
+{
+  asm volatile("" : "+v"(s), "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]),
+               "+v"(x[12]), "+v"(x[13])::"memory");
+}
 __device__ __forceinline__ uint32_t pipe_lofs(int32_t op) { return min((uint32_t)op, (uint32_t)pipe::RING_Z); } // LDS byte offset (zero row if remote)
 __device__ __forceinline__ uint32_t pipe_gofs(int32_t op) { return max((uint32_t)op, (uint32_t)pipe::RING_Z); } // global byte offset (the reserved zero if local)
 __device__ __forceinline__ double pipe_or(double a, double b) { return __longlong_as_double(__double_as_longlong(a) | __double_as_longlong(b)); }
@@ -160,30 +175,36 @@ __device__ __forceinline__ void pipe_glds16(const unsigned char *gsrc, unsigned 
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc, (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
 }
 
-// STAMP (diagnostic build only): per task 8 words -- start / first step / end (s_memrealtime, 100 MHz), cycles waiting for
-// tiles / for producers / in the gather+sum part (s_memtime), steps, XCC id
+// STAMP (diagnostic build only): per task 8 words -- start / first step / end (s_memrealtime, 100 MHz), cycles of compute
+// wave 0 waiting for tiles / for producers / between the previous step's signal and its own (s_memtime), steps, XCC id
 template <bool LAZY, bool STAMP>
-__global__ __launch_bounds__(64 * (1 + PIPE_NL)) void k_trsv_pipe(PipeParams P)
+__global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipeParams P)
 {
+  static_assert(PIPE_NC >= 1 && PIPE_NC <= pipe::MAX_NC, "late masks exist for up to MAX_NC compute waves");
+  static_assert((2 * PIPE_NC + 1) * (pipe::Geometry(pipe::MAX_W).tile_bytes / 1024) <= PIPE_RING_KIB, "tile ring too small for the widest tiles");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   // All LDS is dynamic and the result ring sits at LDS address 0, so that ring operands are ds_read addresses as they
-  // stand.  Control words between the loader and the compute wave: relaxed workgroup-scope atomics (plain ds_read /
-  // ds_write; ordering is by the s_waitcnt instructions below).
+  // stand.  Control words between the waves: relaxed workgroup-scope atomics (plain ds_read / ds_write; ordering is by
+  // the s_waitcnt instructions below).
   double *ringd = reinterpret_cast<double *>(smem); // [RING rows of 64 results][zero row]
   unsigned *ctl = reinterpret_cast<unsigned *>(smem + pipe::RING_BYTES);
-  unsigned *sh_ready = ctl;                    // [PIPE_READY]
-  unsigned &sh_vconsumed = ctl[PIPE_READY];
+  unsigned *sh_ready = ctl;                    // [PIPE_READY] tile t is in LDS when sh_ready[t % PIPE_READY] == t + 1
+  unsigned &sh_vconsumed = ctl[PIPE_READY];    // virtual ring offset (KiB) behind the last tile that is no longer needed
   unsigned &sh_xcc = ctl[PIPE_READY + 1], &sh_gt = ctl[PIPE_READY + 2], &sh_fail = ctl[PIPE_READY + 3], &sh_q = ctl[PIPE_READY + 4];
+  unsigned &sh_stepdone = ctl[PIPE_READY + 5]; // steps of the task whose results are in the LDS ring
+  unsigned *sh_stored = ctl + PIPE_READY + 8;  // [PIPE_NC] own steps of compute wave w whose global stores have completed
   unsigned char *tiles = smem + PIPE_RINGAREA; // byte ring of tiles
   auto lds_load = [](const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
   auto lds_store = [](unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // (uniform: scalar control flow)
   XcdState *st = P.st;
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) { // static LDS in front of the ring: not this build
     if (threadIdx.x == 0) __hip_atomic_store(P.err, 6u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
+  // the ring is zeroed once: its last row stays zero for good, every other row is written before it is read
+  for (int k = wave; k <= pipe::RING; k += PIPE_NC + PIPE_NL) ringd[k * 64 + lane] = 0.0;
   if (threadIdx.x == 0) {
     const unsigned xcc = hw_xcc_id();
     sh_xcc = xcc;
@@ -224,6 +245,8 @@ __global__ __launch_bounds__(64 * (1 + PIPE_NL)) void k_trsv_pipe(PipeParams P)
           sh_q = __hip_atomic_fetch_add(qbase + sweep * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           for (int k = 0; k < PIPE_READY; ++k) lds_store(&sh_ready[k], 0u);
           lds_store(&sh_vconsumed, 0u);
+          lds_store(&sh_stepdone, 0u);
+          for (int k = 0; k < PIPE_NC; ++k) lds_store(&sh_stored[k], 0u);
         }
         __syncthreads();
         const unsigned q = sh_q;
@@ -234,14 +257,23 @@ __global__ __launch_bounds__(64 * (1 + PIPE_NL)) void k_trsv_pipe(PipeParams P)
         const int tid = __builtin_amdgcn_readfirstlane(task0 + (int)q);
         const pipe::Task *T = P.tasks + tid;
         const int nsteps = T->nsteps;
-        const int32_t *ko = P.koff + T->koff_base;
-        const unsigned char *src_tiles = P.stream + T->tile_off;
+        unsigned long long *myword = P.progress + (size_t)tid * 16;
+        auto publish = [&](int steps) __attribute__((always_inline)) {
+          if (lane == 0) {
+            const unsigned long long w = ((unsigned long long)epoch << 32) | (unsigned)steps;
+            if (wt) __hip_atomic_store(myword, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(myword), "v"(w) : "memory"); // plain store, no drain
+          }
+        };
 
-        if (wave > 0) {
-          // ---------------- loader: all tiles of the task by LDS-DMA, up to PIPE_DEPTH tiles in flight ----------------
+        if (wave >= PIPE_NC) {
+          // ---------------- loader: tiles wl, wl + NL, ... of the task by LDS-DMA, up to PIPE_DEPTH tiles in flight ----------------
+          const int wl = wave - PIPE_NC;
+          const int32_t *ko = P.koff + T->koff_base;
+          const unsigned char *src_tiles = P.stream + T->tile_off;
           unsigned v = 0;       // virtual ring offset in KiB
-          int head = wave - 1;  // oldest own tile not yet published (this wave loads tiles wave-1, wave-1+NL, ...)
-          int fl[PIPE_DEPTH];   // pieces of the tiles in flight (head, head+1, ...)
+          int head = wl;        // oldest own tile not yet published
+          int fl[PIPE_DEPTH];   // pieces of the own tiles in flight
           int nfl = 0;
 #pragma unroll
           for (int k = 0; k < PIPE_DEPTH; ++k) fl[k] = 0;
@@ -261,12 +293,12 @@ __global__ __launch_bounds__(64 * (1 + PIPE_NL)) void k_trsv_pipe(PipeParams P)
               v += PIPE_RING_KIB - pos;
               pos = 0;
             }
-            if (t % PIPE_NL != wave - 1) { // another loader's tile: only its ring space is accounted
+            if (t % PIPE_NL != wl) { // another loader's tile: only its ring space is accounted
               v += sz;
               continue;
             }
             if ((int)(v + sz - lds_load(&sh_vconsumed)) > PIPE_RING_KIB) {
-              // about to wait for ring space: first hand over everything that is in flight (the compute wave may need it)
+              // about to wait for ring space: first hand over everything that is in flight (the compute waves may need it)
               while (nfl > 0) publish_oldest(0);
               for (unsigned spins = 0; (int)(v + sz - lds_load(&sh_vconsumed)) > PIPE_RING_KIB; ++spins) {
                 if (spins > (1u << 24)) {
@@ -293,21 +325,19 @@ __global__ __launch_bounds__(64 * (1 + PIPE_NL)) void k_trsv_pipe(PipeParams P)
           }
           while (nfl > 0) publish_oldest(0);
         } else {
-          // ---------------- compute wave ----------------
-          // Software pipeline: fetch(t + 1) (tile -> registers, progress check, remote gathers issued) runs between the
-          // LDS ring reads of step t and its row sums, so the L2 latency of the gathers of step t + 1 overlaps step t.
+          // ---------------- compute wave w: steps w, w + NC, ... ----------------
+          const int w = wave;
           const int nprod = T->nprod;
           const int64_t pos_base = T->pos_base;
           const unsigned long long *pword = P.progress + (size_t)(lane < nprod ? T->prod[lane] : tid) * 16;
-          unsigned long long *myword = P.progress + (size_t)tid * 16;
           const double *src = pipe_uniform_ptr(upper ? P.xpos : P.ypos);
           const double *rhs = pipe_uniform_ptr(upper ? P.ypos : P.dperm);
           double *dst = upper ? P.xpos : P.ypos;
           int have = 0;
           unsigned long long st_start = 0, st_first = 0;
           unsigned st_tile = 0, st_prog = 0, st_sum = 0; // cycles (32 bits are plenty for one task)
+          unsigned st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_t = 0; // step top -> gathers issued -> early part done -> previous step signalled; signal -> step end
           if (STAMP) st_start = __builtin_amdgcn_s_memrealtime();
-          for (int k = 0; k <= pipe::RING; ++k) ringd[k * 64 + lane] = 0.0; // the last row stays zero
           if (upper) { // the forward sweep of this subdomain must be complete (its results are this sweep's right-hand side)
             for (unsigned spins = 0; __hip_atomic_load(qbase + 2 * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ntaskL; ++spins) {
               if (spins > (1u << 22)) {
@@ -318,24 +348,27 @@ __global__ __launch_bounds__(64 * (1 + PIPE_NL)) void k_trsv_pipe(PipeParams P)
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
           }
-          auto publish = [&](int steps) __attribute__((always_inline)) {
-            if (lane == 0) {
-              const unsigned long long w = ((unsigned long long)epoch << 32) | (unsigned)steps;
-              if (wt) __hip_atomic_store(myword, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              else asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(myword), "v"(w) : "memory"); // plain store, no drain
-            }
-          };
-          unsigned v = 0;
-          int next_kib = T->first_kib;
-          bool failed = false;
-          auto fetch = [&](int t, PipeStep &S) __attribute__((always_inline)) {
-            const int sz = next_kib; // (from the previous tile's header: no descriptor loads on this wave's path)
-            unsigned pos = v % PIPE_RING_KIB;
+          // ring positions of the tiles: every compute wave follows ALL tiles (sizes come with the headers it reads)
+          auto place = [](unsigned &v, int sz, unsigned &pos) __attribute__((always_inline)) {
+            pos = v % PIPE_RING_KIB;
             if (pos + sz > PIPE_RING_KIB) {
               v += PIPE_RING_KIB - pos;
               pos = 0;
             }
             v += sz;
+          };
+          unsigned v = 0;              // virtual offset in front of this wave's next tile
+          int next_kib = T->first_kib; // its size
+          if (PIPE_NC == 2 && w == 1) {
+            unsigned dummy;
+            place(v, next_kib, dummy);
+            next_kib = T->second_kib;
+          }
+          bool failed = false;
+          int nstored = 0; // own steps whose result store has completed
+          auto fetch = [&](int t, PipeStep &S, auto &&after_issue) __attribute__((always_inline)) {
+            unsigned pos;
+            place(v, next_kib, pos);
             S.tpos = pos;
             S.vend = v;
             unsigned c0 = 0;
@@ -347,21 +380,26 @@ __global__ __launch_bounds__(64 * (1 + PIPE_NL)) void k_trsv_pipe(PipeParams P)
             const int32_t *hdr = reinterpret_cast<const int32_t *>(tile);
             const int4 *idxp = reinterpret_cast<const int4 *>(tile + 1024 * (1 + PIPE_CHUNK / 2)) + lane;
             int need, own;
-            int2 wk;
+            int4 wk; // hdr[2..5]: W, size of tile t+1, late mask (1 step), size of tile t+2
+            int late2;
+            int32_t op[PIPE_CHUNK];
             for (unsigned spins = 0;; ++spins) {
               asm volatile("" ::: "memory");
-              const unsigned rdy = lds_load(&sh_ready[t % PIPE_READY]);
-              wk = *reinterpret_cast<const int2 *>(hdr + 2);
+              const unsigned rdy_v = lds_load(&sh_ready[t % PIPE_READY]);
+              wk = make_int4(hdr[2], hdr[3], hdr[4], hdr[5]);
+              late2 = hdr[6];
               need = hdr[pipe::HDR_REQ0 + (lane < nprod ? lane : 0)];
               own = reinterpret_cast<const int32_t *>(tile + 256)[lane];
 #pragma unroll
               for (int q4 = 0; q4 < (PIPE_CHUNK + 3) / 4; ++q4) {
                 const int4 o = idxp[q4 * 64];
-                if (4 * q4 < PIPE_CHUNK) S.op[4 * q4] = o.x;
-                if (4 * q4 + 1 < PIPE_CHUNK) S.op[4 * q4 + 1] = o.y;
-                if (4 * q4 + 2 < PIPE_CHUNK) S.op[4 * q4 + 2] = o.z;
-                if (4 * q4 + 3 < PIPE_CHUNK) S.op[4 * q4 + 3] = o.w;
+                if (4 * q4 < PIPE_CHUNK) op[4 * q4] = o.x;
+                if (4 * q4 + 1 < PIPE_CHUNK) op[4 * q4 + 1] = o.y;
+                if (4 * q4 + 2 < PIPE_CHUNK) op[4 * q4 + 2] = o.z;
+                if (4 * q4 + 3 < PIPE_CHUNK) op[4 * q4 + 3] = o.w;
               }
+              if (spins == 0) after_issue(); // further LDS reads of the caller, queued behind the batch
+              const unsigned rdy = (unsigned)__builtin_amdgcn_readfirstlane((int)rdy_v); // (uniform anyway: scalar branch)
               if (rdy == (unsigned)t + 1u) break;
               if (spins > (1u << 24)) {
                 if (lane == 0) __hip_atomic_store(P.err, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -376,13 +414,20 @@ __global__ __launch_bounds__(64 * (1 + PIPE_NL)) void k_trsv_pipe(PipeParams P)
               c0 = c;
             }
             S.W = __builtin_amdgcn_readfirstlane(wk.x);
-            next_kib = __builtin_amdgcn_readfirstlane(wk.y);
+            S.late = PIPE_NC == 1 ? 0u : (unsigned)__builtin_amdgcn_readfirstlane(PIPE_NC == 2 ? wk.z : late2);
+            // this wave's next tile is NC tiles further
+            if (PIPE_NC == 1) next_kib = __builtin_amdgcn_readfirstlane(wk.y);
+            else {
+              unsigned dummy;
+              place(v, __builtin_amdgcn_readfirstlane(wk.y), dummy);
+              next_kib = __builtin_amdgcn_readfirstlane(wk.w);
+            }
             if (lane >= nprod) need = 0;
             if (!__all(have >= need)) { // producers far enough? (normally yes: they run ahead)
               for (unsigned spins = 0;; ++spins) {
                 if (have < need) {
-                  const unsigned long long w = __hip_atomic_load(pword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  if ((unsigned)(w >> 32) == epoch) have = (int)(unsigned)w;
+                  const unsigned long long pw = __hip_atomic_load(pword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  if ((unsigned)(pw >> 32) == epoch) have = max(have, (int)(unsigned)pw);
                 }
                 if (__all(have >= need)) break;
                 if (spins > (1u << 22)) {
@@ -397,96 +442,191 @@ __global__ __launch_bounds__(64 * (1 + PIPE_NL)) void k_trsv_pipe(PipeParams P)
             if (STAMP) st_prog += (unsigned)__builtin_amdgcn_s_memtime() - c0;
             uint32_t goff[PIPE_CHUNK];
 #pragma unroll
-            for (int u = 0; u < PIPE_CHUNK; ++u) goff[u] = pipe_gofs(S.op[u]);
+            for (int u = 0; u < PIPE_CHUNK; ++u) goff[u] = pipe_gofs(op[u]);
             pipe_gather_asm8(rhs, (uint32_t)own, src, goff, S.s0, S.xg);
           };
-          auto finish = [&](int t, PipeStep &S, const double(&xl)[PIPE_CHUNK], const double(&a)[PIPE_CHUNK], double dinv, bool fetched_next) __attribute__((always_inline)) {
-            unsigned c0 = 0;
-            if (STAMP) c0 = (unsigned)__builtin_amdgcn_s_memtime();
-            // behind this step's gathers: the result store of the previous step and, if there is a next step, its
+          // one step: "k4" = number of leading groups of 4 entries that no lane takes from the previous NC - 1 steps
+          auto step = [&](int t, PipeStep &cur, PipeStep &nxt) __attribute__((always_inline)) {
+            asm volatile("" ::: "memory");
+            if (STAMP) st_t = (unsigned)__builtin_amdgcn_s_memtime();
+            double xl[PIPE_CHUNK], p[PIPE_CHUNK], dinv; // p: factor entries, then the products
+            int32_t lofs[PIPE_CHUNK];
+            const unsigned char *ctile = tiles + cur.tpos * 1024; // this step's tile stays resident until it is released below
+            // LDS serves the wave in order: the operand words and ring operands of this step first, then the next tile's
+            // header and operands (fetch), then this step's factor entries
+            {
+              const int4 *idxp = reinterpret_cast<const int4 *>(ctile + 1024 * (1 + PIPE_CHUNK / 2)) + lane;
+#pragma unroll
+              for (int q4 = 0; q4 < (PIPE_CHUNK + 3) / 4; ++q4) {
+                const int4 o = idxp[q4 * 64];
+                if (4 * q4 < PIPE_CHUNK) lofs[4 * q4] = pipe_lofs(o.x);
+                if (4 * q4 + 1 < PIPE_CHUNK) lofs[4 * q4 + 1] = pipe_lofs(o.y);
+                if (4 * q4 + 2 < PIPE_CHUNK) lofs[4 * q4 + 2] = pipe_lofs(o.z);
+                if (4 * q4 + 3 < PIPE_CHUNK) lofs[4 * q4 + 3] = pipe_lofs(o.w);
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < PIPE_CHUNK; ++u) xl[u] = pipe_lds_f64(lofs[u]);
+            asm volatile("" ::: "memory");
+            auto read_entries = [&]() __attribute__((always_inline)) {
+              const double2 *valp = reinterpret_cast<const double2 *>(ctile + 1024) + lane;
+#pragma unroll
+              for (int q2 = 0; q2 < PIPE_CHUNK / 2; ++q2) {
+                const double2 vv = valp[q2 * 64];
+                p[2 * q2] = vv.x;
+                p[2 * q2 + 1] = vv.y;
+              }
+              dinv = reinterpret_cast<const double *>(ctile + 512)[lane];
+            };
+            const bool fetched_next = t + PIPE_NC < nsteps;
+            if (fetched_next) fetch(t + PIPE_NC, nxt, []() {});
+            if (failed) return;
+            if (STAMP) {
+              const unsigned c = (unsigned)__builtin_amdgcn_s_memtime();
+              st_a += c - st_t;
+              st_t = c;
+            }
+            read_entries(); // (behind the fetch: its temporaries and the factor entries need not be live together)
+            // behind this step's gathers: the result store of this wave's previous step and, if there is a next step, its
             // PIPE_CHUNK + 1 gathers => at most that many operations may still be outstanding
             // (the drain for the last step has no register operands: no copies of in-flight registers in front of it)
             if (!fetched_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            pipe_wait_gathers<PIPE_CHUNK + 1>(S.s0, S.xg);
-            double s = S.s0;
+            pipe_wait_gathers<PIPE_CHUNK + 1>(cur.s0, cur.xg);
+            if (LAZY && t >= PIPE_NC) { // ... so that store has completed
+              nstored = (t - w) / PIPE_NC;
+              if (lane == 0) lds_store(&sh_stored[w], (unsigned)nstored);
+            }
+            // Products of the groups of 4 entries that no lane takes from the previous NC - 1 steps; in the other groups p keeps
+            // the factor entry until the ring operands can be read (behind the previous step's signal).  The head of the row
+            // sum up to the first such group is final already.
+            const unsigned late = __builtin_amdgcn_readfirstlane(cur.late);
+            auto group = [&](int g0, bool final_operands) __attribute__((always_inline)) {
 #pragma unroll
-            for (int u = 0; u < PIPE_CHUNK; ++u) s -= a[u] * pipe_or(S.xg[u], xl[u]);
-            if (S.W > PIPE_CHUNK) { // wide rows (rare): the rest of the row from the tile, which is still resident, in chunks
-              const unsigned char *tile = tiles + S.tpos * 1024;
-              const pipe::Geometry G(S.W);
-              constexpr int WCH = 6; // (small chunks: this path must not cost the fast path registers)
-              for (int u0 = PIPE_CHUNK; u0 < S.W; u0 += WCH) {
-                int32_t o[WCH];
-                double av[WCH], g[WCH], l[WCH];
+              for (int u = g0; u < g0 + 4 && u < PIPE_CHUNK; ++u) {
+                if (final_operands) p[u] = p[u] * pipe_or(cur.xg[u], xl[u]);
+              }
+            };
+            group(0, (late & 0x000fu) == 0u);
+            group(4, (late & 0x00f0u) == 0u);
+            group(8, (late & 0x0f00u) == 0u);
+            group(12, (late & 0xf000u) == 0u);
+            const int k4 = late == 0u ? 4 : (__builtin_ctz(late) >> 2); // first group with late operands (4: none)
+            double s = cur.s0;
+            if (k4 >= 1) s = (((s - p[0]) - p[1]) - p[2]) - p[3];
+            if (k4 >= 2) s = (((s - p[4]) - p[5]) - p[6]) - p[7];
+            if (k4 >= 3) s = (((s - p[8]) - p[9]) - p[10]) - p[11];
+            if (k4 >= 4) s = (s - p[12]) - p[13];
+            // rows wider than the register chunk (steps next to the overlap shell): the gathers of the next PIPE_WIDE entries
+            // are issued here (the early ring operands are dead by now) and consumed at the end of the sum; the tile is still resident
+            const int W = __builtin_amdgcn_readfirstlane(cur.W);
+            const unsigned char *wtile = tiles + cur.tpos * 1024;
+            const pipe::Geometry G(W);
+            int32_t eo[PIPE_WIDE];
+            double eg[PIPE_WIDE];
+            if (W > PIPE_CHUNK) {
 #pragma unroll
-                for (int u = 0; u < WCH; ++u) {
-                  o[u] = pipe::PAD_OP;
-                  av[u] = 0.0;
-                  if (u0 + u < S.W) { // wave-uniform
-                    o[u] = *reinterpret_cast<const int32_t *>(tile + G.idx_off(u0 + u, lane));
-                    av[u] = *reinterpret_cast<const double *>(tile + G.val_off(u0 + u, lane));
-                  }
+              for (int u = 0; u < PIPE_WIDE; ++u) {
+                eo[u] = pipe::PAD_OP;
+                if (PIPE_CHUNK + u < W) eo[u] = *reinterpret_cast<const int32_t *>(wtile + G.idx_off(PIPE_CHUNK + u, lane));
+              }
+#pragma unroll
+              for (int u = 0; u < PIPE_WIDE; ++u) {
+                eg[u] = 0.0;
+                if (PIPE_CHUNK + u < W) eg[u] = pipe_ld_sc1_off(src, pipe_gofs(eo[u]));
+              }
+            }
+            // everything above is computed BEFORE the wait below (the compiler would sink it behind the wait otherwise)
+            pipe_pin(s, p);
+            if (STAMP) {
+              const unsigned c = (unsigned)__builtin_amdgcn_s_memtime();
+              st_b += c - st_t;
+              st_t = c;
+            }
+            unsigned c0 = 0;
+            if (PIPE_NC > 1) { // the previous step's results must be in the ring now
+              for (unsigned spins = 0; (unsigned)__builtin_amdgcn_readfirstlane((int)lds_load(&sh_stepdone)) < (unsigned)t; ++spins) {
+                if (spins > (1u << 24)) {
+                  if (lane == 0) __hip_atomic_store(P.err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  failed = true;
+                  return;
                 }
+              }
+              asm volatile("" ::: "memory");
+              if (STAMP) {
+                c0 = (unsigned)__builtin_amdgcn_s_memtime();
+                st_c += c0 - st_t;
+              }
+              auto late_group = [&](int g0) __attribute__((always_inline)) {
+                double x2[4];
 #pragma unroll
-                for (int u = 0; u < WCH; ++u) {
-                  g[u] = 0.0;
-                  if (u0 + u < S.W) g[u] = pipe_ld_sc1_off(src, pipe_gofs(o[u]));
-                  l[u] = pipe_lds_f64(pipe_lofs(o[u]));
+                for (int u = g0; u < g0 + 4 && u < PIPE_CHUNK; ++u) x2[u - g0] = pipe_lds_f64(lofs[u]);
+#pragma unroll
+                for (int u = g0; u < g0 + 4 && u < PIPE_CHUNK; ++u) p[u] = p[u] * pipe_or(cur.xg[u], x2[u - g0]);
+              };
+              if (late & 0x000fu) late_group(0);
+              if (late & 0x00f0u) late_group(4);
+              if (late & 0x0f00u) late_group(8);
+              if (late & 0xf000u) late_group(12);
+            }
+            if (k4 < 1) s = (((s - p[0]) - p[1]) - p[2]) - p[3];
+            if (k4 < 2) s = (((s - p[4]) - p[5]) - p[6]) - p[7];
+            if (k4 < 3) s = (((s - p[8]) - p[9]) - p[10]) - p[11];
+            if (k4 < 4) s = (s - p[12]) - p[13];
+            if (W > PIPE_CHUNK) {
+#pragma unroll
+              for (int u = 0; u < PIPE_WIDE; ++u)
+                if (PIPE_CHUNK + u < W) { // wave-uniform
+                  const double av = *reinterpret_cast<const double *>(wtile + G.val_off(PIPE_CHUNK + u, lane));
+                  s -= av * pipe_or(eg[u], pipe_lds_f64(pipe_lofs(eo[u])));
                 }
-#pragma unroll
-                for (int u = 0; u < WCH; ++u) s -= av[u] * pipe_or(g[u], l[u]);
+              for (int u = PIPE_CHUNK + PIPE_WIDE; u < W; ++u) { // still wider (not seen on the stencils of SURVEY section 8): entry by entry
+                const int32_t o = *reinterpret_cast<const int32_t *>(wtile + G.idx_off(u, lane));
+                const double av = *reinterpret_cast<const double *>(wtile + G.val_off(u, lane));
+                s -= av * pipe_or(pipe_ld_sc1_off(src, pipe_gofs(o)), pipe_lds_f64(pipe_lofs(o)));
               }
             }
             const double out = s * dinv; // (forward sweep: scale 1)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(out) : "memory"); // "out" is complete: every load of this step has returned
-            if (lane == 0) lds_store(&sh_vconsumed, S.vend);             // the tile's ring space goes back to the loaders
             ringd[(t % pipe::RING) * 64 + lane] = out;
-            // the wait above left at most the next step's gathers outstanding; the result store of step t-1 is older than those
-            if (LAZY) publish(t);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(out) : "memory"); // the result is in the ring, every LDS read of this step has returned
+            if (lane == 0) {
+              lds_store(&sh_vconsumed, cur.vend);       // the tile's ring space goes back to the loaders ...
+              lds_store(&sh_stepdone, (unsigned)t + 1u); // ... and the next step may read the ring
+            }
+            if (STAMP && PIPE_NC > 1) {
+              st_t = (unsigned)__builtin_amdgcn_s_memtime();
+              st_sum += st_t - c0;
+            }
             const int64_t mypos = pos_base + (int64_t)t * 64 + lane;
             if (wt) st_sc1(dst + mypos, out);
             else dst[mypos] = out;
             if (!LAZY) {
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-              publish(t + 1);
+              nstored = (t - w) / PIPE_NC + 1;
+              if (lane == 0) lds_store(&sh_stored[w], (unsigned)nstored);
             }
-            if (STAMP) st_sum += (unsigned)__builtin_amdgcn_s_memtime() - c0;
+            // steps 0 .. prog-1 are stored: the first step of each compute wave that is not known to be stored bounds it
+            int prog = w + PIPE_NC * nstored;
+#pragma unroll
+            for (int k = 0; k < PIPE_NC; ++k)
+              if (k != w) prog = min(prog, k + PIPE_NC * (int)lds_load(&sh_stored[k]));
+            publish(prog);
+            if (STAMP) st_d += (unsigned)__builtin_amdgcn_s_memtime() - st_t;
           };
-          auto step = [&](int t, PipeStep &cur, PipeStep &nxt) __attribute__((always_inline)) {
-            asm volatile("" ::: "memory");
-            double xl[PIPE_CHUNK], a[PIPE_CHUNK];
-#pragma unroll
-            for (int u = 0; u < PIPE_CHUNK; ++u) xl[u] = pipe_lds_f64(pipe_lofs(cur.op[u]));
-            const unsigned char *ctile = tiles + cur.tpos * 1024; // this step's tile stays resident until finish() releases it
-            const double2 *valp = reinterpret_cast<const double2 *>(ctile + 1024) + lane;
-#pragma unroll
-            for (int q2 = 0; q2 < PIPE_CHUNK / 2; ++q2) {
-              const double2 vv = valp[q2 * 64];
-              a[2 * q2] = vv.x;
-              a[2 * q2 + 1] = vv.y;
+          if (w < nsteps) {
+            PipeStep SA, SB;
+            fetch(w, SA, []() {});
+            if (failed) return;
+            if (STAMP) st_first = __builtin_amdgcn_s_memrealtime();
+            for (int t = w; t < nsteps; t += 2 * PIPE_NC) {
+              step(t, SA, SB);
+              if (failed) return;
+              if (t + PIPE_NC < nsteps) step(t + PIPE_NC, SB, SA);
+              if (failed) return;
             }
-            const double dinv = reinterpret_cast<const double *>(ctile + 512)[lane];
-            asm volatile("" ::: "memory"); // these reads are issued before the next tile's
-            if (t + 1 < nsteps) fetch(t + 1, nxt);
-            if (failed) return;
-            finish(t, cur, xl, a, dinv, t + 1 < nsteps);
-          };
-          PipeStep SA, SB;
-          fetch(0, SA);
-          if (failed) return;
-          if (STAMP) st_first = __builtin_amdgcn_s_memrealtime();
-          for (int t = 0; t < nsteps; t += 2) {
-            step(t, SA, SB);
-            if (failed) return;
-            if (t + 1 < nsteps) step(t + 1, SB, SA);
-            if (failed) return;
           }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          publish(nsteps);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (lane == 0) __hip_atomic_fetch_add(qbase + (2 + sweep) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (STAMP && lane == 0 && P.stamps) {
-            unsigned long long *o = P.stamps + (size_t)tid * 8;
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every result store of this wave has completed
+          if (STAMP && w == 0 && lane == 0 && P.stamps) {
+            unsigned long long *o = P.stamps + (size_t)tid * 16;
             o[0] = st_start;
             o[1] = st_first;
             o[2] = __builtin_amdgcn_s_memrealtime();
@@ -495,9 +635,18 @@ __global__ __launch_bounds__(64 * (1 + PIPE_NL)) void k_trsv_pipe(PipeParams P)
             o[5] = st_sum;
             o[6] = (unsigned long long)nsteps;
             o[7] = xcc;
+            o[8] = st_a;
+            o[9] = st_b;
+            o[10] = st_c;
+            o[11] = st_d;
           }
         }
-        __syncthreads();
+        __syncthreads(); // all steps are stored (every compute wave has drained)
+        if (threadIdx.x == 0) {
+          publish(nsteps);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_fetch_add(qbase + (2 + sweep) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
   }

@@ -48,16 +48,18 @@ constexpr int FIRST_POS = ZERO_POS + LANES;     // first position of a task
 constexpr int MIN_W = 14;                       // tiles hold at least this many entries per row (the kernel's register chunk)
 inline int32_t ring_op(int step, int lane) { return (int32_t)(((step % RING) * LANES + lane) * 8); }
 constexpr int32_t PAD_OP = RING_Z;
-constexpr int MAXPROD = 52;    // producer tasks per task (header words HDR_REQ0 .. 59)
+constexpr int MAXPROD = 51;    // producer tasks per task (header words HDR_REQ0 .. 58)
+constexpr int MAX_NC = 3;      // the late-operand masks below are provided for up to MAX_NC compute waves per task
 constexpr int HDR_REQ0 = 8;
-constexpr int MAX_W = 40;      // widest triangular row the tile format takes
+constexpr int MAX_W = 26;      // widest triangular row taken (27-point stencil: all neighbours on one side); the kernel's LDS
+                               // tile ring must hold 3 such tiles (21 KiB each) or loaders and compute wave could wait for each other
 
 struct Task { // device-visible descriptor, 256 bytes
   int64_t tile_off;  // byte offset of the first tile in the stream
   int64_t pos_base;  // first position of the task in the position space of its sweep
   int64_t koff_base; // index of the task's nsteps + 1 cumulative tile offsets (KiB, relative to tile_off) in Schedule::koff
   int32_t nsteps, nprod, group, sweep;
-  int32_t W, first_kib; // widest row of the task; size of its first tile in KiB
+  int32_t W, first_kib, second_kib; // widest row of the task; sizes of its first two tiles in KiB
   int32_t prod[MAXPROD]; // global task ids of the producers
 };
 static_assert(sizeof(Task) == 256, "Task layout");
@@ -66,15 +68,17 @@ struct Group {
 };
 
 // Tile layout (bytes): [0,256) header int32[64]: [0] active rows, [1] flags, [2] W = widest row of the step,
-// [3] size of the task's NEXT tile in KiB (0 behind the last one),
+// [3] size of the task's NEXT tile in KiB (0 behind the last one), [5] of the tile after that, [4] / [6]: bit u set =
+// entry u of some lane is a ring operand produced 1 step / 1 or 2 steps earlier (what a compute wave that shares the task
+// with 1 / 2 other waves must read AFTER the previous step has signalled),
 // [HDR_REQ0+p] steps of producer p that must be stored; [256,512) int32[64]: U: position of the row's forward value, L: natural row; [512,1024) double[64]:
 // U: inverse pivot; then idx pieces (1 KiB each: lane l holds int32[4] = operands 4q..4q+3), then value pieces
 // (1 KiB each: lane l holds double[2] = entries 2q, 2q+1).  Operand encoding: see above; the U tile's "own" word is
 // the BYTE offset of the row's forward value.  W is at least MIN_W (narrower rows are padded).  Tiles are sized by the step's own W and packed back to back.
 struct Geometry {
   int W = 0, idx_pieces = 0, val_pieces = 0, tile_bytes = 0;
-  Geometry() = default;
-  PIPE_HD explicit Geometry(int w_) : W(w_ > MIN_W ? w_ : MIN_W), idx_pieces((W + 3) / 4), val_pieces((W + 1) / 2), tile_bytes(1024 * (1 + idx_pieces + val_pieces)) {}
+  constexpr Geometry() = default;
+  PIPE_HD constexpr explicit Geometry(int w_) : W(w_ > MIN_W ? w_ : MIN_W), idx_pieces((W + 3) / 4), val_pieces((W + 1) / 2), tile_bytes(1024 * (1 + idx_pieces + val_pieces)) {}
   // Piece order inside a tile: header | value pieces 0..6 | operand pieces 0..3 | further value pieces | further operand
   // pieces -- the first MIN_W entries of every row sit at offsets that do not depend on W (one batch of LDS reads).
   static constexpr int FIXED_VAL = MIN_W / 2, FIXED_IDX = (MIN_W + 3) / 4, FIXED_KIB = 1 + FIXED_VAL + FIXED_IDX;
@@ -560,6 +564,7 @@ inline bool build(int64_t n, const int64_t *rp, const int32_t *ci, const double 
           }
           S.koff[(size_t)kb + B.tasks[q].nsteps] = k;
           T.first_kib = S.koff[(size_t)kb + 1];
+          T.second_kib = B.tasks[q].nsteps > 1 ? S.koff[(size_t)kb + 2] - S.koff[(size_t)kb + 1] : 0;
           kb += B.tasks[q].nsteps + 1;
           off += (int64_t)k * 1024;
           T.pos_base = pos;
@@ -590,6 +595,7 @@ inline bool build(int64_t n, const int64_t *rp, const int32_t *ci, const double 
         const Task &T = S.tasks[(size_t)tb + q];
         std::vector<int32_t> req(MAXPROD, 0);
         for (int32_t t = 0; t < R.nsteps; ++t) {
+          uint32_t late1 = 0, late2 = 0;
           const Geometry G(R.stepW[t]);
           unsigned char *tile = S.stream.data() + T.tile_off + (int64_t)S.koff[(size_t)T.koff_base + t] * 1024;
           int32_t *hdr = reinterpret_cast<int32_t *>(tile);
@@ -626,6 +632,8 @@ inline bool build(int64_t n, const int64_t *rp, const int32_t *ci, const double 
               if (tj == (int32_t)q && t - sj < RING) {
                 op = ring_op(sj, lj);
                 ++st.entries_local;
+                if (t - sj <= 1) late1 |= 1u << std::min(u, 31);
+                if (t - sj <= 2) late2 |= 1u << std::min(u, 31);
               } else {
                 op = (int32_t)(pos_of(B, tb, j) * 8);
                 if (tj == (int32_t)q) ++st.entries_self_global;
@@ -643,6 +651,9 @@ inline bool build(int64_t n, const int64_t *rp, const int32_t *ci, const double 
           hdr[1] = t + 1 == R.nsteps ? 1 : 0;
           hdr[2] = G.W;
           hdr[3] = t + 1 < R.nsteps ? Geometry(R.stepW[t + 1]).tile_bytes / 1024 : 0;
+          hdr[5] = t + 2 < R.nsteps ? Geometry(R.stepW[t + 2]).tile_bytes / 1024 : 0;
+          hdr[4] = (int32_t)late1;
+          hdr[6] = (int32_t)late2;
           for (int p = 0; p < T.nprod; ++p) hdr[HDR_REQ0 + p] = req[p]; // cumulative: never decreases along the task
         }
       }
@@ -693,6 +704,8 @@ inline std::string emulate(const Schedule &S, int64_t n, const double *d, double
           const Geometry G(hdr[2]);
           if (hdr[3] != (t + 1 < T.nsteps ? S.koff[(size_t)T.koff_base + t + 2] - S.koff[(size_t)T.koff_base + t + 1] : 0)) return "next-tile size mismatch";
           if (t == 0 && T.first_kib != S.koff[(size_t)T.koff_base + 1]) return "first-tile size mismatch";
+          if (t == 0 && T.second_kib != (T.nsteps > 1 ? S.koff[(size_t)T.koff_base + 2] - S.koff[(size_t)T.koff_base + 1] : 0)) return "second-tile size mismatch";
+          if (hdr[5] != (t + 2 < T.nsteps ? S.koff[(size_t)T.koff_base + t + 3] - S.koff[(size_t)T.koff_base + t + 2] : 0)) return "second-next-tile size mismatch";
           if (hdr[2] < MIN_W || G.W > std::max(T.W, MIN_W) || S.koff[(size_t)T.koff_base + t + 1] - S.koff[(size_t)T.koff_base + t] != G.tile_bytes / 1024) return "tile size mismatch";
           const int32_t *own = reinterpret_cast<const int32_t *>(tile + 256);
           const double *s0 = reinterpret_cast<const double *>(tile + 512);
@@ -712,6 +725,14 @@ inline std::string emulate(const Schedule &S, int64_t n, const double *d, double
               double xv;
               if (op < 0 || op % 8) return "malformed operand";
               if (op <= RING_Z) {
+                if (op < RING_Z) { // which step wrote this ring row last?
+                  const int row = op / (LANES * 8);
+                  int back = (t % RING) - row;
+                  if (back <= 0) back += RING;
+                  if (back > t) return "ring operand older than the task";
+                  if (back <= 1 && !((uint32_t)hdr[4] >> std::min(u, 31) & 1u)) return "late mask (1 step) misses an operand";
+                  if (back <= 2 && !((uint32_t)hdr[6] >> std::min(u, 31) & 1u)) return "late mask (2 steps) misses an operand";
+                }
                 xv = ring[(size_t)op / 8];
               } else {
                 const int64_t opos = op / 8;

@@ -47,10 +47,11 @@ for g in sorted(set(meta[:, 0]))[:2]:
         dur = end[m] - first[m]
         print(f"group {g} sweep {sw}: tasks {m.sum()} steps {int(steps[m].sum())} span [{start[m].min():.1f}, {end[m].max():.1f}] us; "
               f"per-step us: median {np.median(dur / steps[m]):.3f} mean {dur.sum() / steps[m].sum():.3f}; "
-              f"cycles/step: tile-wait {st[m, 3].sum() / steps[m].sum():.0f} producer-wait {st[m, 4].sum() / steps[m].sum():.0f} gather+sum {st[m, 5].sum() / steps[m].sum():.0f}")
+              f"cycles/step: tile-wait {st[m, 3].sum() / steps[m].sum():.0f} producer-wait {st[m, 4].sum() / steps[m].sum():.0f} critical {st[m, 5].sum() / steps[m].sum():.0f}; "
+              f"wave-0 segments per step: top->gathers {st[m, 8].sum() / steps[m].sum():.0f} ->early done {st[m, 9].sum() / steps[m].sum():.0f} ->signalled {st[m, 10].sum() / steps[m].sum():.0f} post {st[m, 11].sum() / steps[m].sum():.0f}")
         idx = np.where(m)[0]
         sel = idx[:: max(1, len(idx) // 12)]
         for i in sel:
             print(f"    task {i - idx[0]:4d}: dequeued {start[i]:8.1f} first {first[i]:8.1f} end {end[i]:8.1f} steps {int(steps[i]):4d} "
-                  f"us/step {(end[i] - first[i]) / steps[i]:.3f} tile {st[i, 3] / steps[i]:.0f} prod {st[i, 4] / steps[i]:.0f} sum {st[i, 5] / steps[i]:.0f} cyc/step xcc {int(st[i, 7])}")
+                  f"us/step {(end[i] - first[i]) / steps[i]:.3f} tile {st[i, 3] / steps[i]:.0f} prod {st[i, 4] / steps[i]:.0f} crit {st[i, 5] / steps[i]:.0f} | a {st[i, 8] / steps[i]:.0f} b {st[i, 9] / steps[i]:.0f} c {st[i, 10] / steps[i]:.0f} d {st[i, 11] / steps[i]:.0f} cyc/step xcc {int(st[i, 7])}")
 ctx.close()
