@@ -425,7 +425,7 @@ struct ddm_ilu0 {
   unsigned long long *p_progress = nullptr;
   unsigned *p_queue = nullptr;
   int64_t p_nposL = 0, p_nposU = 0;
-  int p_grid = 0, p_lazy = 1;
+  int p_grid = 0, p_lazy = 0;   // lazy publishing measured slower (4.70 vs 4.48 ms per solve at 216^3)
   pipe::Stats p_stats;
   int64_t p_stream_bytes = 0;
   // slab-ownership engine (mode 7)

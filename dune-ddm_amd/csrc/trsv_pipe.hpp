@@ -329,11 +329,13 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
           const int w = wave;
           const int nprod = T->nprod;
           const int64_t pos_base = T->pos_base;
-          const unsigned long long *pword = P.progress + (size_t)(lane < nprod ? T->prod[lane] : tid) * 16;
+          // lane l watches producers 2l and 2l + 1 (16-bit requirements, two per header word)
+          const unsigned long long *pword0 = P.progress + (size_t)(2 * lane < nprod ? T->prod[2 * lane] : tid) * 16;
+          const unsigned long long *pword1 = P.progress + (size_t)(2 * lane + 1 < nprod ? T->prod[2 * lane + 1] : tid) * 16;
           const double *src = pipe_uniform_ptr(upper ? P.xpos : P.ypos);
           const double *rhs = pipe_uniform_ptr(upper ? P.ypos : P.dperm);
           double *dst = upper ? P.xpos : P.ypos;
-          int have = 0;
+          int have0 = 0, have1 = 0;
           unsigned long long st_start = 0, st_first = 0;
           unsigned st_tile = 0, st_prog = 0, st_sum = 0; // cycles (32 bits are plenty for one task)
           unsigned st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_t = 0; // step top -> gathers issued -> early part done -> previous step signalled; signal -> step end
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
               const unsigned rdy_v = lds_load(&sh_ready[t % PIPE_READY]);
               wk = make_int4(hdr[2], hdr[3], hdr[4], hdr[5]);
               late2 = hdr[6];
-              need = hdr[pipe::HDR_REQ0 + (lane < nprod ? lane : 0)];
+              need = hdr[pipe::HDR_REQ0 + (lane < 56 ? lane : 0)];
               own = reinterpret_cast<const int32_t *>(tile + 256)[lane];
 #pragma unroll
               for (int q4 = 0; q4 < (PIPE_CHUNK + 3) / 4; ++q4) {
@@ -422,14 +424,18 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
               place(v, __builtin_amdgcn_readfirstlane(wk.y), dummy);
               next_kib = __builtin_amdgcn_readfirstlane(wk.w);
             }
-            if (lane >= nprod) need = 0;
-            if (!__all(have >= need)) { // producers far enough? (normally yes: they run ahead)
+            const int need0 = 2 * lane < nprod ? (need & 0xffff) : 0, need1 = 2 * lane + 1 < nprod ? (int)((unsigned)need >> 16) : 0;
+            if (!__all(have0 >= need0 && have1 >= need1)) { // producers far enough? (normally yes: they run ahead)
               for (unsigned spins = 0;; ++spins) {
-                if (have < need) {
-                  const unsigned long long pw = __hip_atomic_load(pword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  if ((unsigned)(pw >> 32) == epoch) have = max(have, (int)(unsigned)pw);
+                if (have0 < need0) {
+                  const unsigned long long pw = __hip_atomic_load(pword0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  if ((unsigned)(pw >> 32) == epoch) have0 = max(have0, (int)(unsigned)pw);
                 }
-                if (__all(have >= need)) break;
+                if (have1 < need1) {
+                  const unsigned long long pw = __hip_atomic_load(pword1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  if ((unsigned)(pw >> 32) == epoch) have1 = max(have1, (int)(unsigned)pw);
+                }
+                if (__all(have0 >= need0 && have1 >= need1)) break;
                 if (spins > (1u << 22)) {
                   if (lane == 0) __hip_atomic_store(P.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                   failed = true;

@@ -48,21 +48,21 @@ constexpr int FIRST_POS = ZERO_POS + LANES;     // first position of a task
 constexpr int MIN_W = 14;                       // tiles hold at least this many entries per row (the kernel's register chunk)
 inline int32_t ring_op(int step, int lane) { return (int32_t)(((step % RING) * LANES + lane) * 8); }
 constexpr int32_t PAD_OP = RING_Z;
-constexpr int MAXPROD = 51;    // producer tasks per task (header words HDR_REQ0 .. 58)
+constexpr int MAXPROD = 112;   // producer tasks per task: two 16-bit step counts per header word HDR_REQ0 .. 63
 constexpr int MAX_NC = 3;      // the late-operand masks below are provided for up to MAX_NC compute waves per task
 constexpr int HDR_REQ0 = 8;
 constexpr int MAX_W = 26;      // widest triangular row taken (27-point stencil: all neighbours on one side); the kernel's LDS
                                // tile ring must hold 3 such tiles (21 KiB each) or loaders and compute wave could wait for each other
 
-struct Task { // device-visible descriptor, 256 bytes
+struct Task { // device-visible descriptor, 512 bytes
   int64_t tile_off;  // byte offset of the first tile in the stream
   int64_t pos_base;  // first position of the task in the position space of its sweep
   int64_t koff_base; // index of the task's nsteps + 1 cumulative tile offsets (KiB, relative to tile_off) in Schedule::koff
   int32_t nsteps, nprod, group, sweep;
-  int32_t W, first_kib, second_kib; // widest row of the task; sizes of its first two tiles in KiB
+  int32_t W, first_kib, second_kib, pad[3]; // widest row of the task; sizes of its first two tiles in KiB
   int32_t prod[MAXPROD]; // global task ids of the producers
 };
-static_assert(sizeof(Task) == 256, "Task layout");
+static_assert(sizeof(Task) == 512, "Task layout");
 struct Group {
   int32_t task0[2], ntask[2]; // [0] forward (L) sweep, [1] backward (U) sweep; tasks in queue order
 };
@@ -71,7 +71,7 @@ struct Group {
 // [3] size of the task's NEXT tile in KiB (0 behind the last one), [5] of the tile after that, [4] / [6]: bit u set =
 // entry u of some lane is a ring operand produced 1 step / 1 or 2 steps earlier (what a compute wave that shares the task
 // with 1 / 2 other waves must read AFTER the previous step has signalled),
-// [HDR_REQ0+p] steps of producer p that must be stored; [256,512) int32[64]: U: position of the row's forward value, L: natural row; [512,1024) double[64]:
+// word HDR_REQ0 + p/2, 16-bit half p%2: steps of producer p that must be stored; [256,512) int32[64]: U: position of the row's forward value, L: natural row; [512,1024) double[64]:
 // U: inverse pivot; then idx pieces (1 KiB each: lane l holds int32[4] = operands 4q..4q+3), then value pieces
 // (1 KiB each: lane l holds double[2] = entries 2q, 2q+1).  Operand encoding: see above; the U tile's "own" word is
 // the BYTE offset of the row's forward value.  W is at least MIN_W (narrower rows are padded).  Tiles are sized by the step's own W and packed back to back.
@@ -89,10 +89,10 @@ struct Geometry {
 };
 
 struct Options {
-  int delta = 16;   // chains are queued by (start level / delta, head row): tasks are blocks of neighbouring chains of one band
+  int delta = 24;   // chains are queued by (start level / delta, head row): tasks are blocks of neighbouring chains of one band
   int vote = 1;     // 1: lanes are re-used by later chains; 0: one chain per lane
   int pack_steps = 64; // steps of a task of dependency-free rows
-  int max_span = 192;  // longest task (steps)
+  int max_span = 256;  // longest task (steps); measured at 216^3: delta 16/32/48 -> 4.59/4.47/4.41 ms per solve, stream 1.78x/1.89x/1.98x
 };
 
 struct Stats {
@@ -533,6 +533,10 @@ inline bool build(int64_t n, const int64_t *rp, const int32_t *ci, const double 
       }
       S.stats.ntasks[sweep] += (int64_t)B.tasks.size();
     }
+  if (S.stats.max_steps > 0xffff) {
+    S.error = "a task has more steps than the 16-bit progress requirements hold";
+    return false;
+  }
   if (npos[0] >= (int64_t)0x0fffffff || npos[1] >= (int64_t)0x0fffffff || ntask >= (int64_t)0x7fffffff) {
     S.error = "position space exceeds 32-bit operands";
     return false;
@@ -654,7 +658,7 @@ inline bool build(int64_t n, const int64_t *rp, const int32_t *ci, const double 
           hdr[5] = t + 2 < R.nsteps ? Geometry(R.stepW[t + 2]).tile_bytes / 1024 : 0;
           hdr[4] = (int32_t)late1;
           hdr[6] = (int32_t)late2;
-          for (int p = 0; p < T.nprod; ++p) hdr[HDR_REQ0 + p] = req[p]; // cumulative: never decreases along the task
+          for (int p = 0; p < T.nprod; ++p) hdr[HDR_REQ0 + p / 2] |= (int32_t)((uint32_t)req[p] << (16 * (p & 1))); // cumulative: never decreases along the task
         }
       }
     }
@@ -710,9 +714,10 @@ inline std::string emulate(const Schedule &S, int64_t n, const double *d, double
           const int32_t *own = reinterpret_cast<const int32_t *>(tile + 256);
           const double *s0 = reinterpret_cast<const double *>(tile + 512);
           for (int p = 0; p < T.nprod; ++p) {
-            if (hdr[HDR_REQ0 + p] < prev_req[p]) return "progress requirement decreases";
-            if (hdr[HDR_REQ0 + p] > S.tasks[(size_t)T.prod[p]].nsteps) return "progress requirement beyond the producer's steps";
-            prev_req[p] = hdr[HDR_REQ0 + p];
+            const int32_t rq = (int32_t)(((uint32_t)hdr[HDR_REQ0 + p / 2] >> (16 * (p & 1))) & 0xffffu);
+            if (rq < prev_req[p]) return "progress requirement decreases";
+            if (rq > S.tasks[(size_t)T.prod[p]].nsteps) return "progress requirement beyond the producer's steps";
+            prev_req[p] = rq;
           }
           double out[LANES];
           for (int l = 0; l < LANES; ++l) {
@@ -745,7 +750,7 @@ inline std::string emulate(const Schedule &S, int64_t n, const double *d, double
                   int p = 0;
                   while (p < T.nprod && T.prod[p] != pt) ++p;
                   if (p == T.nprod) return "operand of a task that is not a declared producer";
-                  if (hdr[HDR_REQ0 + p] < ps + 1) return "progress requirement does not cover an operand";
+                  if (prev_req[p] < ps + 1) return "progress requirement does not cover an operand";
                   if (done[(size_t)pt] < ps + 1) return "producer has not run";
                 }
                 xv = src[(size_t)opos];
