@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--coarse", default="auto", choices=["auto", "geneo", "pou", "none"])
     ap.add_argument("--nev", type=int, default=20)
     ap.add_argument("--no-solve", action="store_true", help="skip the full solve to 1e-10 (iteration count / residual check)")
-    ap.add_argument("--cpu-iters", type=int, default=8, help="CG iterations of the CPU oracle timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-iters", type=int, default=60, help="CG iterations of the CPU oracle timed for cpu_baseline (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=8)
     args = ap.parse_args()
 
@@ -155,7 +155,7 @@ def main():
                  "xcdw": "k_trsv_xcdw", "xcd2": "k_trsv_xcd2<false>"}.get(engine, "k_trsv_pipe (+ k_pipe_permute_in/out)")
         traffic = None
         try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command (profiles/), gfx950-corrected
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_b_pmc_traffic_grid216.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_f_pmc_traffic_grid216_pipe.json" if engine == "pipe" else "r01_b_pmc_traffic_grid216.json")))
             if G == 216 and engine in pmc.get("engine_kernels", {}):
                 traffic = pmc["kernels"][pmc["engine_kernels"][engine]]["hbm_bytes_per_dispatch_corrected"] / world if P == 2 else None
         except Exception:
