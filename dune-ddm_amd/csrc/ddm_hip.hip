@@ -425,6 +425,7 @@ struct ddm_ilu0 {
   unsigned long long *p_progress = nullptr;
   unsigned *p_queue = nullptr;
   int64_t p_nposL = 0, p_nposU = 0;
+  int p_spread = 0;             // placement-independent mode (set when a subdomain has more work per level than one XCD's workgroups take)
   int p_grid = 0, p_lazy = 0;   // lazy publishing measured slower (4.70 vs 4.48 ms per solve at 216^3)
   pipe::Stats p_stats;
   int64_t p_stream_bytes = 0;
@@ -1163,6 +1164,8 @@ static int build_pipe_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
   if (const char *e = std::getenv("DDM_PIPE_SPAN")) opt.max_span = std::atoi(e);
   if (const char *e = std::getenv("DDM_PIPE_REUSE")) opt.vote = std::atoi(e);
   if (const char *e = std::getenv("DDM_PIPE_LAZY")) F->p_lazy = std::atoi(e);
+  int spread_env = -1;
+  if (const char *e = std::getenv("DDM_PIPE_SPREAD")) spread_env = std::atoi(e);
   pipe::Schedule S;
   const int nb = (int)F->h_block_ptr.size() - 1;
   if (!pipe::build(A->nrows, A->h_rp.data(), A->h_ci.data(), F->h_lu.data(), F->h_diag.data(), nb, F->h_block_ptr.data(), opt, S)) {
@@ -1172,6 +1175,9 @@ static int build_pipe_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
   }
   F->ngroups = nb;
   F->p_stats = S.stats;
+  // one XCD hosts 64 workgroups (2 per CU): a subdomain whose sweeps are wider than ~48 wavefronts per level is spread over
+  // all XCDs (write-through hand-overs); measured at 216^3: 1 subdomain 6.9 vs 9.2 ms, 2 subdomains 7.6 vs 8.3 ms
+  F->p_spread = spread_env >= 0 ? spread_env : (nb < 8 && S.stats.max_rows_per_level > 48.0 * 64.0 ? 1 : 0);
   F->p_stream_bytes = (int64_t)S.stream.size();
   F->p_nposL = S.nposL;
   F->p_nposU = S.nposU;
@@ -1207,12 +1213,12 @@ static int build_pipe_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
     const pipe::Stats &st = S.stats;
     std::fprintf(stderr,
                  "[ddm] pipe schedule: %lld rows, tasks %lld+%lld, steps %lld+%lld (lane occupancy %.3f / %.3f), entries %lld: local %.3f self-global %.3f remote %.3f, "
-                 "stream %.1f MB (%.2fx of 12 B/entry), max producers %lld, max steps %lld, regrouped %lld, grid %d\n",
+                 "stream %.1f MB (%.2fx of 12 B/entry), max producers %lld, max steps %lld, regrouped %lld, levels <= %lld, rows/level <= %.0f, spread %d, grid %d\n",
                  (long long)st.rows, (long long)st.ntasks[0], (long long)st.ntasks[1], (long long)st.nsteps[0], (long long)st.nsteps[1],
                  (double)st.rows / (64.0 * std::max<int64_t>(st.nsteps[0], 1)), (double)st.rows / (64.0 * std::max<int64_t>(st.nsteps[1], 1)), (long long)st.entries,
                  (double)st.entries_local / std::max<int64_t>(st.entries, 1), (double)st.entries_self_global / std::max<int64_t>(st.entries, 1),
                  (double)st.entries_remote / std::max<int64_t>(st.entries, 1), S.stream.size() / 1e6, S.stream.size() / (12.0 * std::max<int64_t>(st.entries, 1)),
-                 (long long)st.max_prod, (long long)st.max_steps, (long long)st.regrouped, F->p_grid);
+                 (long long)st.max_prod, (long long)st.max_steps, (long long)st.regrouped, (long long)st.max_levels, st.max_rows_per_level, F->p_spread, F->p_grid);
   }
   F->pipe_state = 1;
   return DDM_OK;
@@ -1235,6 +1241,7 @@ static void enqueue_pipe(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, 
   P.err = F->err;
   P.stamps = stamps;
   P.dbg = dbg;
+  P.spread = F->p_spread;
   P.nposL_bytes = (unsigned)(F->p_nposL * 8);
   P.nposU_bytes = (unsigned)(F->p_nposU * 8);
   hipLaunchKernelGGL(k_pipe_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate, F->p_queue, F->ngroups * 4);

@@ -13,7 +13,7 @@
 // row sum in ascending column order (= the sequential back-solve), one coalesced 512-byte store of the 64 results.
 //
 // Visibility protocol (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"):
-//   * XCD-local mode (>= 8 subdomains, every XCD hosts workgroups): all tasks of a subdomain run on ONE XCD; results
+//   * XCD-local mode (every XCD that owns a subdomain hosts workgroups): all tasks of a subdomain run on ONE XCD; results
 //     are plain stores (they stay in that XCD's L2), every read of another wave's result is an sc1 load (bypasses
 //     the non-coherent L1), the progress word is stored after the result stores have completed;
 //   * placement-independent mode: results and progress words are sc1 (write-through) stores.
@@ -145,6 +145,7 @@ struct PipeParams {
   unsigned long long *stamps;   // diagnostics (nullptr in the product path)
   unsigned long long *dbg;      // diagnostics: 8 words describing the first out-of-range operand (stamped build only)
   unsigned nposL_bytes, nposU_bytes;
+  int spread;                   // != 0: placement-independent mode even if the XCD-local one is possible (few, large subdomains)
 };
 
 __global__ void k_pipe_prologue(XcdState *st, unsigned *queue, int nwords)
@@ -227,10 +228,13 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
   const unsigned xcc = sh_xcc;
   const unsigned epoch = __hip_atomic_load(&st->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned tk = lane < 8 ? __hip_atomic_load(&st->tickets[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
-  const bool local_ok = P.ngroups >= 8 && __all(tk >= 1u); // every XCD hosts workgroups: subdomain g lives on XCD g % 8
+  // XCD-local mode: subdomain g lives on XCD g % 8 -- possible when every XCD that owns a subdomain hosts workgroups (with
+  // fewer than 8 subdomains the other XCDs idle: one subdomain has work for ~30 waves at a time, and same-XCD L2 hand-overs
+  // are what keeps a step short)
+  const bool local_ok = !P.spread && __all(lane >= min(P.ngroups, 8) || tk >= 1u);
   const bool wt = !local_ok;
   const int gfirst = local_ok ? (int)xcc : (int)(sh_gt % (unsigned)P.ngroups);
-  const int gcount = local_ok ? (P.ngroups - (int)xcc + 7) / 8 : P.ngroups;
+  const int gcount = local_ok ? ((int)xcc < P.ngroups ? (P.ngroups - (int)xcc + 7) / 8 : 0) : P.ngroups;
 
   for (int gi = 0; gi < gcount; ++gi) {
     const int g = local_ok ? gfirst + 8 * gi : (gfirst + gi) % P.ngroups;

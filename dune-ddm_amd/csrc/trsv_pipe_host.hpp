@@ -99,6 +99,8 @@ struct Stats {
   int64_t ntasks[2] = {0, 0}, nsteps[2] = {0, 0};
   int64_t rows = 0, entries = 0, entries_local = 0, entries_self_global = 0, entries_remote = 0;
   int64_t max_prod = 0, max_steps = 0, regrouped = 0, nchains[2] = {0, 0};
+  int64_t max_levels = 0;           // deepest sweep of any subdomain
+  double max_rows_per_level = 0.0;  // largest average parallelism of a sweep (rows / levels)
 };
 
 struct Schedule {
@@ -128,6 +130,7 @@ struct BlockSweep { // tasks of one block and one sweep, block-local numbering
   int64_t nchains = 0;
   bool cyclic = false, too_many_prod = false;
   int dissolve_rounds = 0;
+  int32_t nlev = 0; // dependency levels of the sweep
 };
 
 // deps(i, f): calls f(j) for every dependency j of block-local row i in ascending column order
@@ -272,6 +275,7 @@ static void build_block_sweep(int64_t nb, bool upper, const Deps &deps, const Op
     ++B.dissolve_rounds;
   }
   B.nchains = nc;
+  for (int64_t i = 0; i < nb; ++i) B.nlev = std::max(B.nlev, lev[i] + 1);
   // components: members, key, condensation in-degrees
   std::vector<int64_t> mptr(ncomp + 1, 0);
   for (int64_t c = 0; c < nc; ++c)
@@ -510,6 +514,8 @@ inline bool build(int64_t n, const int64_t *rp, const int32_t *ci, const double 
       }
       S.stats.regrouped += regrouped[(size_t)b * 2 + sweep];
       S.stats.nchains[sweep] += B.nchains;
+      S.stats.max_levels = std::max<int64_t>(S.stats.max_levels, B.nlev);
+      if (B.nlev > 0) S.stats.max_rows_per_level = std::max(S.stats.max_rows_per_level, (double)(block_ptr[b + 1] - block_ptr[b]) / B.nlev);
     }
   // global numbering: tasks (group-major, L then U), positions per sweep, tile offsets
   S.groups.resize(nblocks);

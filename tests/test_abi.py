@@ -47,3 +47,27 @@ def test_product_never_touches_the_oracle():
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)
                 assert "liboracle" not in src
+
+
+def test_pipe_kernel_has_no_spills():
+    """The pipe engine's compute wave keeps gathers in flight behind the compiler's back (inline asm, explicit waits):
+    a register spill (scratch or AGPR) of such a register would be silent.  The product builds must have none."""
+    import re
+    import subprocess
+    src = os.path.join(ROOT, "dune-ddm_amd", "csrc", "ddm_hip.hip")
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--cuda-device-only",
+                          "-c", "-o", os.devnull, src, "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    blocks = re.split(r"remark: Function Name: ", out.stderr)
+    seen = 0
+    for b in blocks:
+        if not b.startswith("_ZN3ddm11k_trsv_pipe"):
+            continue
+        name = b.split()[0]
+        vals = {k: int(v) for k, v in re.findall(r"(ScratchSize \[bytes/lane\]|AGPRs|VGPRs|VGPRs Spill|SGPRs Spill): (\d+)", b)}
+        if "Lb1EEE" in name.split("k_trsv_pipe")[1][:12] and name.endswith("Lb1EEEvNS_10PipeParamsE"):
+            continue                                            # the stamped diagnostic build is not a product path
+        seen += 1
+        assert vals["ScratchSize [bytes/lane]"] == 0 and vals["AGPRs"] == 0 and vals["VGPRs Spill"] == 0, (name, vals)
+        assert vals["VGPRs"] <= 256, (name, vals)              # two workgroups of three waves per CU
+    assert seen >= 2
