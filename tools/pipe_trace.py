@@ -54,4 +54,5 @@ for g in sorted(set(meta[:, 0]))[:2]:
         for i in sel:
             print(f"    task {i - idx[0]:4d}: dequeued {start[i]:8.1f} first {first[i]:8.1f} end {end[i]:8.1f} steps {int(steps[i]):4d} "
                   f"us/step {(end[i] - first[i]) / steps[i]:.3f} tile {st[i, 3] / steps[i]:.0f} prod {st[i, 4] / steps[i]:.0f} crit {st[i, 5] / steps[i]:.0f} | a {st[i, 8] / steps[i]:.0f} b {st[i, 9] / steps[i]:.0f} c {st[i, 10] / steps[i]:.0f} d {st[i, 11] / steps[i]:.0f} cyc/step xcc {int(st[i, 7])}")
+np.savez(os.path.join(ROOT, 'gpurun_out', f'pipe_trace{N}.npz'), st=st, meta=meta)
 ctx.close()
