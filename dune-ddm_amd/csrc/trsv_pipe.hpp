@@ -40,6 +40,8 @@ struct PipeStep { // registers of one step, filled NC steps ahead of their use (
                   // again from the tile when the step is computed: two sets of them would not fit the register budget)
   double xg[PIPE_CHUNK];
   double s0;
+  unsigned long long pw0, pw1; // progress words of the two producers this lane watches, loaded with the gathers (non-blocking)
+  int polled;                  // (uniform) pw0 / pw1 hold a poll
   int W;
   unsigned late;       // entries whose ring operand may come from one of the NC - 1 steps before this one
   unsigned tpos, vend; // tile position in the LDS ring (KiB), virtual ring offset behind the tile
@@ -111,6 +113,16 @@ __device__ __forceinline__ void pipe_gather_asm8(const double *rhs_uniform, uint
                : "v"(off[7]), "v"(off[8]), "v"(off[9]), "v"(off[10]), "v"(off[11]), "v"(off[12]), "v"(off[13]), "s"(src_uniform)
                : "memory");
 }
+// non-blocking poll of two progress words per lane, part of the same in-flight group as the gathers
+__device__ __forceinline__ void pipe_poll_asm(const unsigned long long *p0, const unsigned long long *p1, unsigned long long &w0, unsigned long long &w1)
+{
+  asm volatile("global_load_dwordx2 %0, %2, off sc1\n\t"
+               "global_load_dwordx2 %1, %3, off sc1"
+               : "=&v"(w0), "=&v"(w1)
+               : "v"(p0), "v"(p1)
+               : "memory");
+}
+constexpr int PIPE_INFLIGHT = PIPE_CHUNK + 3; // loads per step issued ahead: right-hand side, PIPE_CHUNK operands, two progress words
 template <int N>
 __device__ __forceinline__ void pipe_wait_gathers(double &s0, double (&x)[PIPE_CHUNK])
 {
@@ -429,6 +441,10 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
               next_kib = __builtin_amdgcn_readfirstlane(wk.w);
             }
             const int need0 = 2 * lane < nprod ? (need & 0xffff) : 0, need1 = 2 * lane + 1 < nprod ? (int)((unsigned)need >> 16) : 0;
+            if (S.polled) { // the poll this stage issued two steps ago has long returned (finish() of that step waited for it)
+              if ((unsigned)(S.pw0 >> 32) == epoch) have0 = max(have0, (int)(unsigned)S.pw0);
+              if ((unsigned)(S.pw1 >> 32) == epoch) have1 = max(have1, (int)(unsigned)S.pw1);
+            }
             if (!__all(have0 >= need0 && have1 >= need1)) { // producers far enough? (normally yes: they run ahead)
               for (unsigned spins = 0;; ++spins) {
                 if (have0 < need0) {
@@ -454,6 +470,8 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
 #pragma unroll
             for (int u = 0; u < PIPE_CHUNK; ++u) goff[u] = pipe_gofs(op[u]);
             pipe_gather_asm8(rhs, (uint32_t)own, src, goff, S.s0, S.xg);
+            pipe_poll_asm(pword0, pword1, S.pw0, S.pw1);
+            S.polled = 1;
           };
           // one step: "k4" = number of leading groups of 4 entries that no lane takes from the previous NC - 1 steps
           auto step = [&](int t, PipeStep &cur, PipeStep &nxt) __attribute__((always_inline)) {
@@ -498,10 +516,11 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             }
             read_entries(); // (behind the fetch: its temporaries and the factor entries need not be live together)
             // behind this step's gathers: the result store of this wave's previous step and, if there is a next step, its
-            // PIPE_CHUNK + 1 gathers => at most that many operations may still be outstanding
+            // PIPE_INFLIGHT loads => at most that many operations may still be outstanding
             // (the drain for the last step has no register operands: no copies of in-flight registers in front of it)
             if (!fetched_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            pipe_wait_gathers<PIPE_CHUNK + 1>(cur.s0, cur.xg);
+            pipe_wait_gathers<PIPE_INFLIGHT>(cur.s0, cur.xg);
+            asm volatile("" : "+v"(cur.pw0), "+v"(cur.pw1)); // (valid from here on)
             if (LAZY && t >= PIPE_NC) { // ... so that store has completed
               nstored = (t - w) / PIPE_NC;
               if (lane == 0) lds_store(&sh_stored[w], (unsigned)nstored);
@@ -624,6 +643,8 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
           };
           if (w < nsteps) {
             PipeStep SA, SB;
+            SA.polled = 0;
+            SB.polled = 0;
             fetch(w, SA, []() {});
             if (failed) return;
             if (STAMP) st_first = __builtin_amdgcn_s_memrealtime();

@@ -82,3 +82,26 @@ def test_pipe_stress_many_solves_uneven(ddm, monkeypatch):
         ref = _oracle_solve(M, bp, ref)
     assert np.array_equal(a.cpu().numpy(), ref)
     ctx.close()
+
+
+def test_pipe_falls_back_for_wide_rows(ddm, monkeypatch):
+    """rows wider than the tile format (here a dense-ish band matrix): the pipe builder declines, the object silently uses the
+    loader engine and the result is still the oracle's"""
+    import torch
+    monkeypatch.setenv("DDM_TRSV_MODE", "pipe")
+    n = 600
+    rng = np.random.default_rng(2)
+    B = sp.diags([rng.standard_normal(n - abs(k)) for k in range(-40, 41)], list(range(-40, 41)), format="csr")
+    M = sp.csr_matrix(B + B.T + sp.eye(n) * 200.0)
+    M.sort_indices()
+    bp = np.array([0, n], dtype=np.int64)
+    ctx = ddm.torch_context(0)
+    F = ddm.Ilu0(ctx, ddm.CsrMatrix(ctx, M), bp)
+    d = rng.standard_normal(n)
+    x = torch.zeros(n, dtype=torch.float64, device="cuda")
+    F.solve(torch.as_tensor(d).cuda(), x)
+    ctx.sync()
+    assert F.status() == 0
+    xo = _oracle_solve(M, bp, d)
+    assert np.max(np.abs(x.cpu().numpy() - xo)) <= 1e-12 * np.max(np.abs(xo))
+    ctx.close()
