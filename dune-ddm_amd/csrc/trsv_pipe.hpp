@@ -30,15 +30,16 @@ constexpr int PIPE_DEPTH = 3;       // tiles a loader keeps in flight
 constexpr int PIPE_RING_KIB = 64;   // LDS byte ring of tiles per workgroup: one workgroup per CU.  2 NC tiles (the current and the
                                     // prefetched step of every compute wave) + one in flight must fit, or loaders and compute waves
                                     // would wait for each other: 5 tiles of the widest row the builder accepts (pipe::MAX_W)
-constexpr int PIPE_WIDE = 6;        // further entries of a wide row handled with one gather latency
+constexpr int PIPE_WIDE = 12;       // further entries of a wide row handled with one gather latency
 constexpr int PIPE_READY = 32;      // ready words (tiles in flight < 32: the smallest tile is 3 KiB)
 constexpr int PIPE_CHUNK = pipe::MIN_W; // entries of a row held in registers; every tile has at least that many (padded), wider rows take the rest from the tile
 constexpr int PIPE_RINGAREA = (pipe::RING_BYTES + 4 * (PIPE_READY + 16) + 1023) / 1024 * 1024; // result ring + control words
 constexpr size_t PIPE_LDS_BYTES = (size_t)PIPE_RINGAREA + (size_t)PIPE_RING_KIB * 1024; // dynamic part
 
-struct PipeStep { // registers of one step, filled NC steps ahead of their use (operand words and factor entries are read
-                  // again from the tile when the step is computed: two sets of them would not fit the register budget)
+struct PipeStep { // registers of one step, filled NC steps ahead of their use (the factor entries are read
+                  // from the tile when the step is computed: two sets of them would not fit the register budget)
   double xg[PIPE_CHUNK];
+  uint32_t lofs[PIPE_CHUNK];   // LDS ring addresses of the operands (the zero row for operands that are gathered)
   double s0;
   unsigned long long pw0, pw1; // progress words of the two producers this lane watches, loaded with the gathers (non-blocking)
   int polled;                  // (uniform) pw0 / pw1 hold a poll
@@ -468,7 +469,10 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             if (STAMP) st_prog += (unsigned)__builtin_amdgcn_s_memtime() - c0;
             uint32_t goff[PIPE_CHUNK];
 #pragma unroll
-            for (int u = 0; u < PIPE_CHUNK; ++u) goff[u] = pipe_gofs(op[u]);
+            for (int u = 0; u < PIPE_CHUNK; ++u) {
+              goff[u] = pipe_gofs(op[u]);
+              S.lofs[u] = pipe_lofs(op[u]);
+            }
             pipe_gather_asm8(rhs, (uint32_t)own, src, goff, S.s0, S.xg);
             pipe_poll_asm(pword0, pword1, S.pw0, S.pw1);
             S.polled = 1;
@@ -478,23 +482,11 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             asm volatile("" ::: "memory");
             if (STAMP) st_t = (unsigned)__builtin_amdgcn_s_memtime();
             double xl[PIPE_CHUNK], p[PIPE_CHUNK], dinv; // p: factor entries, then the products
-            int32_t lofs[PIPE_CHUNK];
             const unsigned char *ctile = tiles + cur.tpos * 1024; // this step's tile stays resident until it is released below
-            // LDS serves the wave in order: the operand words and ring operands of this step first, then the next tile's
-            // header and operands (fetch), then this step's factor entries
-            {
-              const int4 *idxp = reinterpret_cast<const int4 *>(ctile + 1024 * (1 + PIPE_CHUNK / 2)) + lane;
+            // LDS serves the wave in order: the ring operands of this step first, then the next tile's header and operands
+            // (fetch), then this step's factor entries
 #pragma unroll
-              for (int q4 = 0; q4 < (PIPE_CHUNK + 3) / 4; ++q4) {
-                const int4 o = idxp[q4 * 64];
-                if (4 * q4 < PIPE_CHUNK) lofs[4 * q4] = pipe_lofs(o.x);
-                if (4 * q4 + 1 < PIPE_CHUNK) lofs[4 * q4 + 1] = pipe_lofs(o.y);
-                if (4 * q4 + 2 < PIPE_CHUNK) lofs[4 * q4 + 2] = pipe_lofs(o.z);
-                if (4 * q4 + 3 < PIPE_CHUNK) lofs[4 * q4 + 3] = pipe_lofs(o.w);
-              }
-            }
-#pragma unroll
-            for (int u = 0; u < PIPE_CHUNK; ++u) xl[u] = pipe_lds_f64(lofs[u]);
+            for (int u = 0; u < PIPE_CHUNK; ++u) xl[u] = pipe_lds_f64(cur.lofs[u]);
             asm volatile("" ::: "memory");
             auto read_entries = [&]() __attribute__((always_inline)) {
               const double2 *valp = reinterpret_cast<const double2 *>(ctile + 1024) + lane;
@@ -539,14 +531,9 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             group(4, (late & 0x00f0u) == 0u);
             group(8, (late & 0x0f00u) == 0u);
             group(12, (late & 0xf000u) == 0u);
-            const int k4 = late == 0u ? 4 : (__builtin_ctz(late) >> 2); // first group with late operands (4: none)
-            double s = cur.s0;
-            if (k4 >= 1) s = (((s - p[0]) - p[1]) - p[2]) - p[3];
-            if (k4 >= 2) s = (((s - p[4]) - p[5]) - p[6]) - p[7];
-            if (k4 >= 3) s = (((s - p[8]) - p[9]) - p[10]) - p[11];
-            if (k4 >= 4) s = (s - p[12]) - p[13];
             // rows wider than the register chunk (steps next to the overlap shell): the gathers of the next PIPE_WIDE entries
-            // are issued here (the early ring operands are dead by now) and consumed at the end of the sum; the tile is still resident
+            // are issued here (the ring operands and gathered values of the first PIPE_CHUNK entries are dead by now: no extra registers) and
+            // consumed behind the row sum of those entries; the tile is still resident
             const int W = __builtin_amdgcn_readfirstlane(cur.W);
             const unsigned char *wtile = tiles + cur.tpos * 1024;
             const pipe::Geometry G(W);
@@ -564,6 +551,12 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
                 if (PIPE_CHUNK + u < W) eg[u] = pipe_ld_sc1_off(src, pipe_gofs(eo[u]));
               }
             }
+            const int k4 = late == 0u ? 4 : (__builtin_ctz(late) >> 2); // first group with late operands (4: none)
+            double s = cur.s0;
+            if (k4 >= 1) s = (((s - p[0]) - p[1]) - p[2]) - p[3];
+            if (k4 >= 2) s = (((s - p[4]) - p[5]) - p[6]) - p[7];
+            if (k4 >= 3) s = (((s - p[8]) - p[9]) - p[10]) - p[11];
+            if (k4 >= 4) s = (s - p[12]) - p[13];
             // everything above is computed BEFORE the wait below (the compiler would sink it behind the wait otherwise)
             pipe_pin(s, p);
             if (STAMP) {
@@ -588,7 +581,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
               auto late_group = [&](int g0) __attribute__((always_inline)) {
                 double x2[4];
 #pragma unroll
-                for (int u = g0; u < g0 + 4 && u < PIPE_CHUNK; ++u) x2[u - g0] = pipe_lds_f64(lofs[u]);
+                for (int u = g0; u < g0 + 4 && u < PIPE_CHUNK; ++u) x2[u - g0] = pipe_lds_f64(cur.lofs[u]);
 #pragma unroll
                 for (int u = g0; u < g0 + 4 && u < PIPE_CHUNK; ++u) p[u] = p[u] * pipe_or(cur.xg[u], x2[u - g0]);
               };
