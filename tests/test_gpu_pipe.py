@@ -32,15 +32,15 @@ def _oracle_solve(M, bp, d):
     return xo
 
 
-@pytest.mark.parametrize("lazy", ["1", "0"])
-@pytest.mark.parametrize("N,P", [((26, 24, 22), (2, 2, 2)),      # 8 subdomains: XCD-local mode
-                                 ((20, 18, 16), (2, 1, 1)),      # 2 subdomains: placement-independent mode (write-through)
+@pytest.mark.parametrize("spread", ["0", "1"])                  # XCD-local hand-overs / subdomains spread over all XCDs (write-through)
+@pytest.mark.parametrize("N,P", [((26, 24, 22), (2, 2, 2)),      # 8 subdomains
+                                 ((20, 18, 16), (2, 1, 1)),      # 2 subdomains
                                  ((9, 8, 7), (1, 1, 1))])
-def test_pipe_solve_bit_exact(ddm, N, P, lazy, monkeypatch):
+def test_pipe_solve_bit_exact(ddm, N, P, spread, monkeypatch):
     import torch
     assert torch.cuda.is_available()
     monkeypatch.setenv("DDM_TRSV_MODE", "pipe")
-    monkeypatch.setenv("DDM_PIPE_LAZY", lazy)
+    monkeypatch.setenv("DDM_PIPE_SPREAD", spread)
     M, bp = _blocks(ddm, N, P)
     ctx = ddm.torch_context(0)
     A = ddm.CsrMatrix(ctx, M)
