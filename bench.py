@@ -104,8 +104,10 @@ def main():
 
     # ---- full solve: iteration count and final residual (validity of the configuration) --------
     solve_info = None
+    gpu_hist = None
     if not args.no_solve:
         res, hist, x = tl.solve(reduction=1e-10, maxit=1000, history=True)
+        gpu_hist = np.asarray(hist, dtype=float)
         solve_info = {"iterations": int(res.iterations), "converged": bool(res.converged), "reduction": float(res.reduction),
                       "solve_s": float(res.elapsed_s)}
         log(rank, f"full solve: {res.iterations} iterations, ||r||/||r0|| = {res.reduction:.3e}, {res.elapsed_s:.3f} s")
@@ -184,6 +186,14 @@ def main():
         cpu = {"value": it_cpu / t_cpu, "unit": "iterations/s", "cores": threads, "kind": "port",
                "sample": f"{it_cpu} CG iterations of the same {G}^3 / {P ** 3}-subdomain problem (setup excluded), one host thread per subdomain"}
         log(rank, f"cpu_baseline: {it_cpu} iterations in {t_cpu:.1f} s on {threads} threads")
+        # full-size parity: the oracle's residual norms of these iterations against the HIP solve above (same problem, same start)
+        ho = getattr(oracle_time_iterations, "last_history", None)
+        if gpu_hist is not None and ho is not None and len(gpu_hist) >= len(ho):
+            dev = np.abs(gpu_hist[:len(ho)] - ho) / ho
+            cpu["parity_first_iterations"] = {"iterations": int(len(ho) - 1), "max_rel_dev_residual_norm": float(dev.max()),
+                                              "tolerance": "1e-8 * ||r_k|| + 1e-12 * ||r_0|| (DESIGN.md section 6)",
+                                              "ok": bool(np.all(np.abs(gpu_hist[:len(ho)] - ho) <= 1e-8 * ho + 1e-12 * ho[0]))}
+            log(rank, f"full-size parity vs oracle over {len(ho) - 1} iterations: max rel. deviation of ||r_k|| = {dev.max():.2e}")
 
     if rank == 0:
         out = {

@@ -27,7 +27,7 @@ namespace ddm {
 constexpr int PIPE_NC = 1;          // compute waves per workgroup (steps of a task alternate between them)
 constexpr int PIPE_NL = 2;          // loader waves per workgroup
 constexpr int PIPE_DEPTH = 3;       // tiles a loader keeps in flight
-constexpr int PIPE_RING_KIB = 64;   // LDS byte ring of tiles per workgroup: one workgroup per CU.  2 NC tiles (the current and the
+constexpr int PIPE_RING_KIB = 64;   // LDS byte ring of tiles per workgroup (two workgroups per CU).  2 NC tiles (the current and the
                                     // prefetched step of every compute wave) + one in flight must fit, or loaders and compute waves
                                     // would wait for each other: 5 tiles of the widest row the builder accepts (pipe::MAX_W)
 constexpr int PIPE_WIDE = 12;       // further entries of a wide row handled with one gather latency
@@ -483,11 +483,12 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             if (STAMP) st_t = (unsigned)__builtin_amdgcn_s_memtime();
             double xl[PIPE_CHUNK], p[PIPE_CHUNK], dinv; // p: factor entries, then the products
             const unsigned char *ctile = tiles + cur.tpos * 1024; // this step's tile stays resident until it is released below
-            // LDS serves the wave in order: the ring operands of this step first, then the next tile's header and operands
-            // (fetch), then this step's factor entries
+            // LDS serves the wave in order: the next tile's header and operand words first (fetch waits for them at once, so they
+            // must not queue behind anything), then the ring operands of this step, then this step's factor entries
+            auto read_ring = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int u = 0; u < PIPE_CHUNK; ++u) xl[u] = pipe_lds_f64(cur.lofs[u]);
-            asm volatile("" ::: "memory");
+              for (int u = 0; u < PIPE_CHUNK; ++u) xl[u] = pipe_lds_f64(cur.lofs[u]);
+            };
             auto read_entries = [&]() __attribute__((always_inline)) {
               const double2 *valp = reinterpret_cast<const double2 *>(ctile + 1024) + lane;
 #pragma unroll
@@ -499,7 +500,8 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
               dinv = reinterpret_cast<const double *>(ctile + 512)[lane];
             };
             const bool fetched_next = t + PIPE_NC < nsteps;
-            if (fetched_next) fetch(t + PIPE_NC, nxt, []() {});
+            if (fetched_next) fetch(t + PIPE_NC, nxt, read_ring);
+            else read_ring();
             if (failed) return;
             if (STAMP) {
               const unsigned c = (unsigned)__builtin_amdgcn_s_memtime();

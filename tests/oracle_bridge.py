@@ -54,4 +54,5 @@ def oracle_time_iterations(dec, iters, **kw):
     b = [sd.b.copy() for sd in dec.subs]
     t0 = time.perf_counter()
     it, conv, hist = ao.cg_solve(op, sp_, prec, x, b, 0.0, iters)
+    oracle_time_iterations.last_history = np.asarray(hist, dtype=float)   # ||r_0|| .. ||r_iters|| (full-size parity check in bench.py)
     return time.perf_counter() - t0, it
