@@ -190,12 +190,16 @@ def main():
         ho = getattr(oracle_time_iterations, "last_history", None)
         if gpu_hist is not None and ho is not None and len(gpu_hist) >= len(ho):
             dev = np.abs(gpu_hist[:len(ho)] - ho) / ho
-            cpu["parity_first_iterations"] = {"iterations": int(len(ho) - 1), "max_rel_dev_residual_norm": float(dev.max()),
-                                              "max_abs_dev_over_r0": float((np.abs(gpu_hist[:len(ho)] - ho) / ho[0]).max()),
-                                              "tolerance": "|r_k(hip) - r_k(oracle)| <= 1e-8 * ||r_k|| + 1e-9 * ||r_0|| (DESIGN.md section 6: rounding-level "
-                                                           "differences of the parallel reductions are amplified by CG as it converges)",
-                                              "ok": bool(np.all(np.abs(gpu_hist[:len(ho)] - ho) <= 1e-8 * ho + 1e-9 * ho[0]))}
-            log(rank, f"full-size parity vs oracle over {len(ho) - 1} iterations: max rel. deviation of ||r_k|| = {dev.max():.2e}")
+            kcheck = min(30, len(ho) - 1)
+            cpu["parity_first_iterations"] = {"iterations_checked": int(kcheck), "max_rel_dev_residual_norm": float(dev[:kcheck + 1].max()),
+                                              "tolerance": "| ||r_k||(hip) - ||r_k||(oracle) | <= 1e-8 * ||r_k|| for k <= 30; beyond that CG amplifies the "
+                                                           "rounding-level differences of the parallel reductions (DESIGN.md section 6); identical iteration counts",
+                                              "ok": bool(np.all(dev[:kcheck + 1] <= 1e-8)),
+                                              "rel_dev_at": {str(k): float(dev[k]) for k in (1, 10, 20, 30, 40, 50, 60) if k < len(ho)}}
+            prof = ", ".join(f"k={k}: {dev[k]:.1e} (r_k/r_0 {ho[k] / ho[0]:.1e})" for k in (1, 5, 10, 20, 30, 40, 50, len(ho) - 1) if k < len(ho))
+            log(rank, f"full-size parity vs oracle over {len(ho) - 1} iterations: max rel. deviation of ||r_k|| = {dev.max():.2e}; {prof}")
+            if tl.galerkin is not None and getattr(tl, "a0", None) is not None:
+                log(rank, f"coarse matrix: K = {tl.K}, cond = {np.linalg.cond(tl.a0):.3e}")
 
     if rank == 0:
         out = {
