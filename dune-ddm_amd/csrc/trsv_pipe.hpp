@@ -385,6 +385,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
           }
           bool failed = false;
           int nstored = 0; // own steps whose result store has completed
+          bool publish_pending = false; // (eager mode) the previous step's store has been issued but not yet drained and published
           auto fetch = [&](int t, PipeStep &S, auto &&after_issue) __attribute__((always_inline)) {
             unsigned pos;
             place(v, next_kib, pos);
@@ -477,6 +478,14 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             pipe_poll_asm(pword0, pword1, S.pw0, S.pw1);
             S.polled = 1;
           };
+          // steps 0 .. prog-1 are stored: the first step of each compute wave that is not known to be stored bounds it
+          auto publish_progress = [&]() __attribute__((always_inline)) {
+            int prog = w + PIPE_NC * nstored;
+#pragma unroll
+            for (int k = 0; k < PIPE_NC; ++k)
+              if (k != w) prog = min(prog, k + PIPE_NC * (int)lds_load(&sh_stored[k]));
+            publish(prog);
+          };
           // one step: "k4" = number of leading groups of 4 entries that no lane takes from the previous NC - 1 steps
           auto step = [&](int t, PipeStep &cur, PipeStep &nxt) __attribute__((always_inline)) {
             asm volatile("" ::: "memory");
@@ -488,6 +497,13 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             auto read_ring = [&]() __attribute__((always_inline)) {
 #pragma unroll
               for (int u = 0; u < PIPE_CHUNK; ++u) xl[u] = pipe_lds_f64(cur.lofs[u]);
+              if (!LAZY && publish_pending) { // the store of the previous step has had these instructions' time to complete
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                nstored = (t - w) / PIPE_NC;
+                if (lane == 0) lds_store(&sh_stored[w], (unsigned)nstored);
+                publish_progress();
+                publish_pending = false;
+              }
             };
             auto read_entries = [&]() __attribute__((always_inline)) {
               const double2 *valp = reinterpret_cast<const double2 *>(ctile + 1024) + lane;
@@ -623,17 +639,8 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             const int64_t mypos = pos_base + (int64_t)t * 64 + lane;
             if (wt) st_sc1(dst + mypos, out);
             else dst[mypos] = out;
-            if (!LAZY) {
-              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-              nstored = (t - w) / PIPE_NC + 1;
-              if (lane == 0) lds_store(&sh_stored[w], (unsigned)nstored);
-            }
-            // steps 0 .. prog-1 are stored: the first step of each compute wave that is not known to be stored bounds it
-            int prog = w + PIPE_NC * nstored;
-#pragma unroll
-            for (int k = 0; k < PIPE_NC; ++k)
-              if (k != w) prog = min(prog, k + PIPE_NC * (int)lds_load(&sh_stored[k]));
-            publish(prog);
+            if (!LAZY) publish_pending = true; // drained and published at the top of the next step, behind its first LDS reads
+            else publish_progress();
             if (STAMP) st_d += (unsigned)__builtin_amdgcn_s_memtime() - st_t;
           };
           if (w < nsteps) {
