@@ -355,6 +355,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
           int have0 = 0, have1 = 0;
           unsigned long long st_start = 0, st_first = 0;
           unsigned st_tile = 0, st_prog = 0, st_sum = 0; // cycles (32 bits are plenty for one task)
+          unsigned st_nblock = 0, st_cblock = 0; // steps behind the first one that had to poll their producers, cycles spent there
           unsigned st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_t = 0; // step top -> gathers issued -> early part done -> previous step signalled; signal -> step end
           if (STAMP) st_start = __builtin_amdgcn_s_memrealtime();
           if (upper) { // the forward sweep of this subdomain must be complete (its results are this sweep's right-hand side)
@@ -448,6 +449,8 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
               if ((unsigned)(S.pw1 >> 32) == epoch) have1 = max(have1, (int)(unsigned)S.pw1);
             }
             if (!__all(have0 >= need0 && have1 >= need1)) { // producers far enough? (normally yes: they run ahead)
+              unsigned cb = 0;
+              if (STAMP) cb = (unsigned)__builtin_amdgcn_s_memtime();
               for (unsigned spins = 0;; ++spins) {
                 if (have0 < need0) {
                   const unsigned long long pw = __hip_atomic_load(pword0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -466,6 +469,10 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
                 __builtin_amdgcn_s_sleep(1);
               }
               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+              if (STAMP && t > w) {
+                st_nblock += 1;
+                st_cblock += (unsigned)__builtin_amdgcn_s_memtime() - cb;
+              }
             }
             if (STAMP) st_prog += (unsigned)__builtin_amdgcn_s_memtime() - c0;
             uint32_t goff[PIPE_CHUNK];
@@ -672,6 +679,8 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             o[9] = st_b;
             o[10] = st_c;
             o[11] = st_d;
+            o[12] = st_nblock;
+            o[13] = st_cblock;
           }
         }
         __syncthreads(); // all steps are stored (every compute wave has drained)

@@ -48,7 +48,7 @@ for g in sorted(set(meta[:, 0]))[:2]:
         print(f"group {g} sweep {sw}: tasks {m.sum()} steps {int(steps[m].sum())} span [{start[m].min():.1f}, {end[m].max():.1f}] us; "
               f"per-step us: median {np.median(dur / steps[m]):.3f} mean {dur.sum() / steps[m].sum():.3f}; "
               f"cycles/step: tile-wait {st[m, 3].sum() / steps[m].sum():.0f} producer-wait {st[m, 4].sum() / steps[m].sum():.0f} critical {st[m, 5].sum() / steps[m].sum():.0f}; "
-              f"wave-0 segments per step: top->gathers {st[m, 8].sum() / steps[m].sum():.0f} ->early done {st[m, 9].sum() / steps[m].sum():.0f} ->signalled {st[m, 10].sum() / steps[m].sum():.0f} post {st[m, 11].sum() / steps[m].sum():.0f}")
+              f"wave-0 segments per step: top->gathers {st[m, 8].sum() / steps[m].sum():.0f} ->early done {st[m, 9].sum() / steps[m].sum():.0f} ->signalled {st[m, 10].sum() / steps[m].sum():.0f} post {st[m, 11].sum() / steps[m].sum():.0f}; steps (behind the first) that polled producers: {st[m, 12].sum() / steps[m].sum():.2%}, {st[m, 13].sum() / np.maximum(st[m, 12].sum(), 1):.0f} cycles each")
         idx = np.where(m)[0]
         sel = idx[:: max(1, len(idx) // 12)]
         for i in sel:
