@@ -1224,7 +1224,7 @@ static int build_pipe_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
   return DDM_OK;
 }
 
-static void enqueue_pipe(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, unsigned long long *stamps, unsigned long long *dbg = nullptr)
+static void enqueue_pipe(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, unsigned long long *stamps)
 {
   PipeParams P;
   P.ngroups = F->ngroups;
@@ -1240,10 +1240,7 @@ static void enqueue_pipe(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, 
   P.st = F->xstate;
   P.err = F->err;
   P.stamps = stamps;
-  P.dbg = dbg;
   P.spread = F->p_spread;
-  P.nposL_bytes = (unsigned)(F->p_nposL * 8);
-  P.nposU_bytes = (unsigned)(F->p_nposU * 8);
   hipLaunchKernelGGL(k_pipe_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate, F->p_queue, F->ngroups * 4);
   hipLaunchKernelGGL(k_pipe_permute_in, dim3(grid_for(F->p_nposL)), dim3(WG), 0, ctx->stream, F->p_nposL, F->p_rowL, d, F->p_dperm);
   if (stamps) hipLaunchKernelGGL((k_trsv_pipe<true, true>), dim3(F->p_grid), dim3(64 * (PIPE_NC + PIPE_NL)), PIPE_LDS_BYTES, ctx->stream, P);
@@ -1323,13 +1320,8 @@ extern "C" int ddm_ilu0_pipe_trace(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, d
   unsigned long long *st = nullptr;
   HIPCHECK(ctx, hipMalloc((void **)&st, sizeof(unsigned long long) * 16 * (size_t)(nt + 1)));
   HIPCHECK(ctx, hipMemsetAsync(st, 0, sizeof(unsigned long long) * 16 * (size_t)(nt + 1), ctx->stream));
-  enqueue_pipe(ctx, F, d, x, st, st + 16 * nt);
+  enqueue_pipe(ctx, F, d, x, st);
   int rc = ddm_memcpy_d2h(ctx, out_host, st, (int64_t)sizeof(unsigned long long) * 16 * nt);
-  unsigned long long dbg[8] = {0};
-  if (!rc) rc = ddm_memcpy_d2h(ctx, dbg, st + 16 * nt, (int64_t)sizeof(dbg));
-  if (!rc && dbg[0])
-    std::fprintf(stderr, "[ddm] pipe trace: %llu out-of-range operands; first: task %llu step %llu lane %llu own %llu entry %lld op %llu tile-pos %llu W %llu (limits L %lld U %lld bytes)\n", dbg[0],
-                 dbg[1], dbg[2], dbg[3], dbg[4], (long long)dbg[5], dbg[6], dbg[7] >> 32, dbg[7] & 0xffffffffull, (long long)F->p_nposL * 8, (long long)F->p_nposU * 8);
   if (!rc && meta_host) {
     std::vector<pipe::Task> tasks((size_t)nt);
     rc = ddm_memcpy_d2h(ctx, tasks.data(), F->p_tasks, (int64_t)sizeof(pipe::Task) * nt);

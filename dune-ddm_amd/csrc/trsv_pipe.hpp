@@ -3,22 +3,24 @@
 // One workgroup = PIPE_NC compute waves + PIPE_NL loader waves; two workgroups per CU.  Workgroups pull tasks (64
 // chains walked level by level) from a per-(subdomain, sweep) queue in topological order.  The loader waves stream the
 // task's tiles HBM -> LDS with LDS-DMA (global_load_lds_dwordx4, 1 KiB per instruction) into a byte ring, far ahead of
-// the compute waves.  A lone wave issues one instruction every ~4 cycles and a step is ~300 instructions, so the steps
-// of a task ALTERNATE between the compute waves: wave w takes steps w, w + NC, ...; everything of its step that does
-// not depend on the previous step (tile reads, progress check, remote gathers, ring operands older than NC steps, the
-// products and the head of the row sum) runs while the other wave finishes the previous step; only the operands
-// flagged in the tile's late mask are read after the previous step has signalled (one LDS word).
-// Per step: operands of the own task from the LDS result ring, operands of other tasks by sc1
-// gathers from the position arrays (guarded by the producers' progress words, which are normally far ahead), the
-// row sum in ascending column order (= the sequential back-solve), one coalesced 512-byte store of the 64 results.
+// the compute wave.
+// Per step of the compute wave: operands of the own task from the LDS result ring, operands of other tasks by sc1
+// gathers from the position arrays (guarded by the producers' progress words, which are normally ahead), the row sum in
+// ascending column order (= the sequential back-solve), one coalesced 512-byte store of the 64 results.  The wave is
+// software-pipelined by hand: header and operand words of the NEXT tile, the progress check, the next step's 15 gathers
+// and a non-blocking poll of the producers' progress words are issued before the row sums of the current step.
+// PIPE_NC = 2 (built, bit-exact, not faster -- DESIGN.md section 3) lets two compute waves alternate the steps of a task:
+// wave w takes steps w, w + NC, ...; only the operands flagged in the tile's late mask are read after the previous
+// step has signalled (one LDS word).
 //
 // Visibility protocol (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"):
 //   * XCD-local mode (every XCD that owns a subdomain hosts workgroups): all tasks of a subdomain run on ONE XCD; results
 //     are plain stores (they stay in that XCD's L2), every read of another wave's result is an sc1 load (bypasses
 //     the non-coherent L1), the progress word is stored after the result stores have completed;
-//   * placement-independent mode: results and progress words are sc1 (write-through) stores.
-//   * "completed": vmcnt retires in issue order, so once a load issued after a store has returned, the store has
-//     completed; PIPE_LAZY publishes on that basis, otherwise the wave drains (s_waitcnt vmcnt(0)) before publishing.
+//   * placement-independent ("spread") mode: results and progress words are sc1 (write-through) stores;
+//   * "completed": the wave drains its stores (s_waitcnt vmcnt(0)) at the top of the next step, behind that step's first
+//     LDS reads, and then publishes; LAZY = true instead relies on vmcnt retiring in issue order (once a load issued after
+//     a store has returned, the store has completed) and publishes one step later without a drain (measured slower).
 #pragma once
 #include "trsv_pipe_host.hpp"
 
@@ -156,8 +158,6 @@ struct PipeParams {
   XcdState *st;
   unsigned *err;
   unsigned long long *stamps;   // diagnostics (nullptr in the product path)
-  unsigned long long *dbg;      // diagnostics: 8 words describing the first out-of-range operand (stamped build only)
-  unsigned nposL_bytes, nposU_bytes;
   int spread;                   // != 0: placement-independent mode even if the XCD-local one is possible (few, large subdomains)
 };
 
