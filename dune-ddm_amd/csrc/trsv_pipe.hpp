@@ -126,6 +126,33 @@ __device__ __forceinline__ void pipe_poll_asm(const unsigned long long *p0, cons
                : "memory");
 }
 constexpr int PIPE_INFLIGHT = PIPE_CHUNK + 3; // loads per step issued ahead: right-hand side, PIPE_CHUNK operands, two progress words
+// the PIPE_WIDE further operands of a wide row, issued in front of the next step's gathers (same in-flight rules)
+__device__ __forceinline__ void pipe_gather_asm_wide(const double *src_uniform, const uint32_t (&off)[PIPE_WIDE], double (&x)[PIPE_WIDE])
+{
+  static_assert(PIPE_WIDE == 12, "operand lists below");
+  asm volatile("s_nop 4\n\t"
+               "global_load_dwordx2 %0, %12, %24 sc1\n\t"
+               "global_load_dwordx2 %1, %13, %24 sc1\n\t"
+               "global_load_dwordx2 %2, %14, %24 sc1\n\t"
+               "global_load_dwordx2 %3, %15, %24 sc1\n\t"
+               "global_load_dwordx2 %4, %16, %24 sc1\n\t"
+               "global_load_dwordx2 %5, %17, %24 sc1\n\t"
+               "global_load_dwordx2 %6, %18, %24 sc1\n\t"
+               "global_load_dwordx2 %7, %19, %24 sc1\n\t"
+               "global_load_dwordx2 %8, %20, %24 sc1\n\t"
+               "global_load_dwordx2 %9, %21, %24 sc1\n\t"
+               "global_load_dwordx2 %10, %22, %24 sc1\n\t"
+               "global_load_dwordx2 %11, %23, %24 sc1"
+               : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]), "=&v"(x[8]), "=&v"(x[9]), "=&v"(x[10]),
+                 "=&v"(x[11])
+               : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "v"(off[7]), "v"(off[8]), "v"(off[9]), "v"(off[10]),
+                 "v"(off[11]), "s"(src_uniform)
+               : "memory");
+}
+__device__ __forceinline__ void pipe_pin_wide(double (&x)[PIPE_WIDE])
+{
+  asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11])::"memory");
+}
 template <int N>
 __device__ __forceinline__ void pipe_wait_gathers(double &s0, double (&x)[PIPE_CHUNK])
 {
@@ -501,6 +528,21 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             const unsigned char *ctile = tiles + cur.tpos * 1024; // this step's tile stays resident until it is released below
             // LDS serves the wave in order: the next tile's header and operand words first (fetch waits for them at once, so they
             // must not queue behind anything), then the ring operands of this step, then this step's factor entries
+            // rows wider than the register chunk (steps next to the overlap shell): their further operand words are read first
+            // of all, the gathers of those PIPE_WIDE operands are issued in front of the next step's gathers (so the explicit
+            // wait below covers them) and consumed behind the row sum of the first PIPE_CHUNK entries
+            const int W = __builtin_amdgcn_readfirstlane(cur.W);
+            const unsigned char *wtile = ctile;
+            const pipe::Geometry G(W);
+            uint32_t ego[PIPE_WIDE];
+            double eg[PIPE_WIDE];
+            if (W > PIPE_CHUNK) {
+#pragma unroll
+              for (int u = 0; u < PIPE_WIDE; ++u) {
+                ego[u] = pipe_gofs(pipe::PAD_OP);
+                if (PIPE_CHUNK + u < W) ego[u] = pipe_gofs(*reinterpret_cast<const int32_t *>(wtile + G.idx_off(PIPE_CHUNK + u, lane)));
+              }
+            }
             auto read_ring = [&]() __attribute__((always_inline)) {
 #pragma unroll
               for (int u = 0; u < PIPE_CHUNK; ++u) xl[u] = pipe_lds_f64(cur.lofs[u]);
@@ -511,6 +553,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
                 publish_progress();
                 publish_pending = false;
               }
+              if (W > PIPE_CHUNK) pipe_gather_asm_wide(src, ego, eg); // (behind the drain above, in front of the next step's gathers)
             };
             auto read_entries = [&]() __attribute__((always_inline)) {
               const double2 *valp = reinterpret_cast<const double2 *>(ctile + 1024) + lane;
@@ -538,6 +581,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             if (!fetched_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             pipe_wait_gathers<PIPE_INFLIGHT>(cur.s0, cur.xg);
             asm volatile("" : "+v"(cur.pw0), "+v"(cur.pw1)); // (valid from here on)
+            if (W > PIPE_CHUNK) pipe_pin_wide(eg);            // (older than the gathers the wait left in flight: valid too)
             if (LAZY && t >= PIPE_NC) { // ... so that store has completed
               nstored = (t - w) / PIPE_NC;
               if (lane == 0) lds_store(&sh_stored[w], (unsigned)nstored);
@@ -556,26 +600,6 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             group(4, (late & 0x00f0u) == 0u);
             group(8, (late & 0x0f00u) == 0u);
             group(12, (late & 0xf000u) == 0u);
-            // rows wider than the register chunk (steps next to the overlap shell): the gathers of the next PIPE_WIDE entries
-            // are issued here (the ring operands and gathered values of the first PIPE_CHUNK entries are dead by now: no extra registers) and
-            // consumed behind the row sum of those entries; the tile is still resident
-            const int W = __builtin_amdgcn_readfirstlane(cur.W);
-            const unsigned char *wtile = tiles + cur.tpos * 1024;
-            const pipe::Geometry G(W);
-            int32_t eo[PIPE_WIDE];
-            double eg[PIPE_WIDE];
-            if (W > PIPE_CHUNK) {
-#pragma unroll
-              for (int u = 0; u < PIPE_WIDE; ++u) {
-                eo[u] = pipe::PAD_OP;
-                if (PIPE_CHUNK + u < W) eo[u] = *reinterpret_cast<const int32_t *>(wtile + G.idx_off(PIPE_CHUNK + u, lane));
-              }
-#pragma unroll
-              for (int u = 0; u < PIPE_WIDE; ++u) {
-                eg[u] = 0.0;
-                if (PIPE_CHUNK + u < W) eg[u] = pipe_ld_sc1_off(src, pipe_gofs(eo[u]));
-              }
-            }
             const int k4 = late == 0u ? 4 : (__builtin_ctz(late) >> 2); // first group with late operands (4: none)
             double s = cur.s0;
             if (k4 >= 1) s = (((s - p[0]) - p[1]) - p[2]) - p[3];
@@ -624,7 +648,8 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
               for (int u = 0; u < PIPE_WIDE; ++u)
                 if (PIPE_CHUNK + u < W) { // wave-uniform
                   const double av = *reinterpret_cast<const double *>(wtile + G.val_off(PIPE_CHUNK + u, lane));
-                  s -= av * pipe_or(eg[u], pipe_lds_f64(pipe_lofs(eo[u])));
+                  const int32_t o = *reinterpret_cast<const int32_t *>(wtile + G.idx_off(PIPE_CHUNK + u, lane));
+                  s -= av * pipe_or(eg[u], pipe_lds_f64(pipe_lofs(o)));
                 }
               for (int u = PIPE_CHUNK + PIPE_WIDE; u < W; ++u) { // still wider (not seen on the stencils of SURVEY section 8): entry by entry
                 const int32_t o = *reinterpret_cast<const int32_t *>(wtile + G.idx_off(u, lane));
