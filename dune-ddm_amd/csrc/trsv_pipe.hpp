@@ -414,7 +414,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
           bool failed = false;
           int nstored = 0; // own steps whose result store has completed
           bool publish_pending = false; // (eager mode) the previous step's store has been issued but not yet drained and published
-          auto fetch = [&](int t, PipeStep &S, auto &&after_issue) __attribute__((always_inline)) {
+          auto fetch = [&](int t, PipeStep &S, PipeStep *prev, auto &&after_issue) __attribute__((always_inline)) {
             unsigned pos;
             place(v, next_kib, pos);
             S.tpos = pos;
@@ -431,6 +431,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             int4 wk; // hdr[2..5]: W, size of tile t+1, late mask (1 step), size of tile t+2
             int late2;
             int32_t op[PIPE_CHUNK];
+            bool drained = false; // the caller's hook has waited for every outstanding load: the previous stage's poll is valid
             for (unsigned spins = 0;; ++spins) {
               asm volatile("" ::: "memory");
               const unsigned rdy_v = lds_load(&sh_ready[t % PIPE_READY]);
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
                 if (4 * q4 + 2 < PIPE_CHUNK) op[4 * q4 + 2] = o.z;
                 if (4 * q4 + 3 < PIPE_CHUNK) op[4 * q4 + 3] = o.w;
               }
-              if (spins == 0) after_issue(); // further LDS reads of the caller, queued behind the batch
+              if (spins == 0) drained = after_issue(); // further LDS reads of the caller, queued behind the batch
               const unsigned rdy = (unsigned)__builtin_amdgcn_readfirstlane((int)rdy_v); // (uniform anyway: scalar branch)
               if (rdy == (unsigned)t + 1u) break;
               if (spins > (1u << 24)) {
@@ -474,6 +475,11 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             if (S.polled) { // the poll this stage issued two steps ago has long returned (finish() of that step waited for it)
               if ((unsigned)(S.pw0 >> 32) == epoch) have0 = max(have0, (int)(unsigned)S.pw0);
               if ((unsigned)(S.pw1 >> 32) == epoch) have1 = max(have1, (int)(unsigned)S.pw1);
+            }
+            if (prev != nullptr && drained) { // ... and the one issued a step ago has returned too: one step fresher
+              asm volatile("" : "+v"(prev->pw0), "+v"(prev->pw1));
+              if ((unsigned)(prev->pw0 >> 32) == epoch) have0 = max(have0, (int)(unsigned)prev->pw0);
+              if ((unsigned)(prev->pw1 >> 32) == epoch) have1 = max(have1, (int)(unsigned)prev->pw1);
             }
             if (!__all(have0 >= need0 && have1 >= need1)) { // producers far enough? (normally yes: they run ahead)
               unsigned cb = 0;
@@ -543,10 +549,12 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
                 if (PIPE_CHUNK + u < W) ego[u] = pipe_gofs(*reinterpret_cast<const int32_t *>(wtile + G.idx_off(PIPE_CHUNK + u, lane)));
               }
             }
-            auto read_ring = [&]() __attribute__((always_inline)) {
+            auto read_ring = [&]() __attribute__((always_inline)) -> bool {
+              bool drained = false;
 #pragma unroll
               for (int u = 0; u < PIPE_CHUNK; ++u) xl[u] = pipe_lds_f64(cur.lofs[u]);
-              if (!LAZY && publish_pending) { // the store of the previous step has had these instructions' time to complete
+              if (!LAZY && publish_pending) {
+                drained = true; // the store of the previous step has had these instructions' time to complete
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 nstored = (t - w) / PIPE_NC;
                 if (lane == 0) lds_store(&sh_stored[w], (unsigned)nstored);
@@ -554,6 +562,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
                 publish_pending = false;
               }
               if (W > PIPE_CHUNK) pipe_gather_asm_wide(src, ego, eg); // (behind the drain above, in front of the next step's gathers)
+              return drained;
             };
             auto read_entries = [&]() __attribute__((always_inline)) {
               const double2 *valp = reinterpret_cast<const double2 *>(ctile + 1024) + lane;
@@ -566,7 +575,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
               dinv = reinterpret_cast<const double *>(ctile + 512)[lane];
             };
             const bool fetched_next = t + PIPE_NC < nsteps;
-            if (fetched_next) fetch(t + PIPE_NC, nxt, read_ring);
+            if (fetched_next) fetch(t + PIPE_NC, nxt, &cur, read_ring);
             else read_ring();
             if (failed) return;
             if (STAMP) {
@@ -679,7 +688,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             PipeStep SA, SB;
             SA.polled = 0;
             SB.polled = 0;
-            fetch(w, SA, []() {});
+            fetch(w, SA, nullptr, []() { return false; });
             if (failed) return;
             if (STAMP) st_first = __builtin_amdgcn_s_memrealtime();
             for (int t = w; t < nsteps; t += 2 * PIPE_NC) {

@@ -25,9 +25,13 @@ extern "C" int pipe_test_build_and_emulate(int64_t n, const int64_t *rp, const i
   if (const char *f = std::getenv("PIPE_DEBUG_TASKS")) { // per task: group sweep W nsteps active-rows nprod
     FILE *fp = std::fopen(f, "w");
     for (const pipe::Task &T : S.tasks) {
-      int64_t active = 0;
-      for (int t = 0; t < T.nsteps; ++t) active += *reinterpret_cast<const int32_t *>(S.stream.data() + T.tile_off + (int64_t)S.koff[(size_t)T.koff_base + t] * 1024);
-      std::fprintf(fp, "%d %d %d %d %lld %d\n", T.group, T.sweep, T.W, T.nsteps, (long long)active, T.nprod);
+      int64_t active = 0, wide = 0;
+      for (int t = 0; t < T.nsteps; ++t) {
+        const int32_t *hdr = reinterpret_cast<const int32_t *>(S.stream.data() + T.tile_off + (int64_t)S.koff[(size_t)T.koff_base + t] * 1024);
+        active += hdr[0];
+        wide += hdr[2] > pipe::MIN_W;
+      }
+      std::fprintf(fp, "%d %d %d %d %lld %d %lld\n", T.group, T.sweep, T.W, T.nsteps, (long long)active, T.nprod, (long long)wide);
     }
     std::fclose(fp);
   }
