@@ -426,7 +426,7 @@ struct ddm_ilu0 {
   unsigned *p_queue = nullptr;
   int64_t p_nposL = 0, p_nposU = 0;
   int p_spread = 0;             // placement-independent mode (set when a subdomain has more work per level than one XCD's workgroups take)
-  int p_grid = 0, p_lazy = 0;   // lazy publishing measured slower (4.70 vs 4.48 ms per solve at 216^3)
+  int p_grid = 0;
   pipe::Stats p_stats;
   int64_t p_stream_bytes = 0;
   // slab-ownership engine (mode 7)
@@ -1163,7 +1163,6 @@ static int build_pipe_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
   if (const char *e = std::getenv("DDM_PIPE_DELTA")) opt.delta = std::atoi(e);
   if (const char *e = std::getenv("DDM_PIPE_SPAN")) opt.max_span = std::atoi(e);
   if (const char *e = std::getenv("DDM_PIPE_REUSE")) opt.vote = std::atoi(e);
-  if (const char *e = std::getenv("DDM_PIPE_LAZY")) F->p_lazy = std::atoi(e);
   int spread_env = -1;
   if (const char *e = std::getenv("DDM_PIPE_SPREAD")) spread_env = std::atoi(e);
   pipe::Schedule S;
@@ -1201,11 +1200,10 @@ static int build_pipe_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
     HIPCHECK(ctx, hipMalloc((void **)&F->xstate, sizeof(XcdState)));
     HIPCHECK(ctx, hipMemset(F->xstate, 0, sizeof(XcdState)));
   }
-  HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_pipe<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS_BYTES));
-  HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_pipe<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS_BYTES));
-  HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_pipe<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS_BYTES));
+  HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_pipe<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS_BYTES));
+  HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_pipe<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS_BYTES));
   int per_cu = 0;
-  HIPCHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_trsv_pipe<true, false>, 64 * (PIPE_NC + PIPE_NL), PIPE_LDS_BYTES));
+  HIPCHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_trsv_pipe<false>, 64 * (PIPE_NC + PIPE_NL), PIPE_LDS_BYTES));
   per_cu = std::max(1, std::min(per_cu, 2));
   if (const char *e = std::getenv("DDM_PIPE_WG_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(e)));
   F->p_grid = per_cu * (ctx->num_cu / 8 * 8);
@@ -1243,9 +1241,8 @@ static void enqueue_pipe(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, 
   P.spread = F->p_spread;
   hipLaunchKernelGGL(k_pipe_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate, F->p_queue, F->ngroups * 4);
   hipLaunchKernelGGL(k_pipe_permute_in, dim3(grid_for(F->p_nposL)), dim3(WG), 0, ctx->stream, F->p_nposL, F->p_rowL, d, F->p_dperm);
-  if (stamps) hipLaunchKernelGGL((k_trsv_pipe<true, true>), dim3(F->p_grid), dim3(64 * (PIPE_NC + PIPE_NL)), PIPE_LDS_BYTES, ctx->stream, P);
-  else if (F->p_lazy) hipLaunchKernelGGL((k_trsv_pipe<true, false>), dim3(F->p_grid), dim3(64 * (PIPE_NC + PIPE_NL)), PIPE_LDS_BYTES, ctx->stream, P);
-  else hipLaunchKernelGGL((k_trsv_pipe<false, false>), dim3(F->p_grid), dim3(64 * (PIPE_NC + PIPE_NL)), PIPE_LDS_BYTES, ctx->stream, P);
+  if (stamps) hipLaunchKernelGGL((k_trsv_pipe<true>), dim3(F->p_grid), dim3(64 * (PIPE_NC + PIPE_NL)), PIPE_LDS_BYTES, ctx->stream, P);
+  else hipLaunchKernelGGL((k_trsv_pipe<false>), dim3(F->p_grid), dim3(64 * (PIPE_NC + PIPE_NL)), PIPE_LDS_BYTES, ctx->stream, P);
   hipLaunchKernelGGL(k_pipe_permute_out, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, F->p_posU, F->p_xpos, x);
 }
 

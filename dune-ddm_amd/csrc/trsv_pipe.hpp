@@ -19,8 +19,10 @@
 //     the non-coherent L1), the progress word is stored after the result stores have completed;
 //   * placement-independent ("spread") mode: results and progress words are sc1 (write-through) stores;
 //   * "completed": the wave drains its stores (s_waitcnt vmcnt(0)) at the top of the next step, behind that step's first
-//     LDS reads, and then publishes; LAZY = true instead relies on vmcnt retiring in issue order (once a load issued after
-//     a store has returned, the store has completed) and publishes one step later without a drain (measured slower).
+//     LDS reads, and then publishes.  (Publishing a step later without a drain - vmcnt retires in issue order, so a
+//     returned younger load vouches for the store - was measured slower.)  The non-blocking poll of the producers' progress
+//     words is issued together with the result store, so the same drain makes it valid: the producer check of the next
+//     prefetch sees progress that is one L2 round trip old.
 #pragma once
 #include "trsv_pipe_host.hpp"
 
@@ -43,8 +45,6 @@ struct PipeStep { // registers of one step, filled NC steps ahead of their use (
   double xg[PIPE_CHUNK];
   uint32_t lofs[PIPE_CHUNK];   // LDS ring addresses of the operands (the zero row for operands that are gathered)
   double s0;
-  unsigned long long pw0, pw1; // progress words of the two producers this lane watches, loaded with the gathers (non-blocking)
-  int polled;                  // (uniform) pw0 / pw1 hold a poll
   int W;
   unsigned late;       // entries whose ring operand may come from one of the NC - 1 steps before this one
   unsigned tpos, vend; // tile position in the LDS ring (KiB), virtual ring offset behind the tile
@@ -116,7 +116,7 @@ __device__ __forceinline__ void pipe_gather_asm8(const double *rhs_uniform, uint
                : "v"(off[7]), "v"(off[8]), "v"(off[9]), "v"(off[10]), "v"(off[11]), "v"(off[12]), "v"(off[13]), "s"(src_uniform)
                : "memory");
 }
-// non-blocking poll of two progress words per lane, part of the same in-flight group as the gathers
+// non-blocking poll of two progress words per lane (issued in front of a step's result store, valid behind the next drain)
 __device__ __forceinline__ void pipe_poll_asm(const unsigned long long *p0, const unsigned long long *p1, unsigned long long &w0, unsigned long long &w1)
 {
   asm volatile("global_load_dwordx2 %0, %2, off sc1\n\t"
@@ -125,7 +125,7 @@ __device__ __forceinline__ void pipe_poll_asm(const unsigned long long *p0, cons
                : "v"(p0), "v"(p1)
                : "memory");
 }
-constexpr int PIPE_INFLIGHT = PIPE_CHUNK + 3; // loads per step issued ahead: right-hand side, PIPE_CHUNK operands, two progress words
+constexpr int PIPE_INFLIGHT = PIPE_CHUNK + 1; // loads per step issued ahead: right-hand side, PIPE_CHUNK operands
 // the PIPE_WIDE further operands of a wide row, issued in front of the next step's gathers (same in-flight rules)
 __device__ __forceinline__ void pipe_gather_asm_wide(const double *src_uniform, const uint32_t (&off)[PIPE_WIDE], double (&x)[PIPE_WIDE])
 {
@@ -218,7 +218,7 @@ __device__ __forceinline__ void pipe_glds16(const unsigned char *gsrc, unsigned 
 
 // STAMP (diagnostic build only): per task 8 words -- start / first step / end (s_memrealtime, 100 MHz), cycles of compute
 // wave 0 waiting for tiles / for producers / between the previous step's signal and its own (s_memtime), steps, XCC id
-template <bool LAZY, bool STAMP>
+template <bool STAMP>
 __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipeParams P)
 {
   static_assert(PIPE_NC >= 1 && PIPE_NC <= pipe::MAX_NC, "late masks exist for up to MAX_NC compute waves");
@@ -413,8 +413,9 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
           }
           bool failed = false;
           int nstored = 0; // own steps whose result store has completed
-          bool publish_pending = false; // (eager mode) the previous step's store has been issued but not yet drained and published
-          auto fetch = [&](int t, PipeStep &S, PipeStep *prev, auto &&after_issue) __attribute__((always_inline)) {
+          bool publish_pending = false; // the previous step's store (and the poll in front of it) has been issued but not yet drained and published
+          unsigned long long pw0 = 0, pw1 = 0; // progress words of the two producers this lane watches (non-blocking poll)
+          auto fetch = [&](int t, PipeStep &S, auto &&after_issue) __attribute__((always_inline)) {
             unsigned pos;
             place(v, next_kib, pos);
             S.tpos = pos;
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             int4 wk; // hdr[2..5]: W, size of tile t+1, late mask (1 step), size of tile t+2
             int late2;
             int32_t op[PIPE_CHUNK];
-            bool drained = false; // the caller's hook has waited for every outstanding load: the previous stage's poll is valid
+            bool drained = false; // the caller's hook has waited for every outstanding load: the poll issued with the last store is valid
             for (unsigned spins = 0;; ++spins) {
               asm volatile("" ::: "memory");
               const unsigned rdy_v = lds_load(&sh_ready[t % PIPE_READY]);
@@ -472,14 +473,10 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
               next_kib = __builtin_amdgcn_readfirstlane(wk.w);
             }
             const int need0 = 2 * lane < nprod ? (need & 0xffff) : 0, need1 = 2 * lane + 1 < nprod ? (int)((unsigned)need >> 16) : 0;
-            if (S.polled) { // the poll this stage issued two steps ago has long returned (finish() of that step waited for it)
-              if ((unsigned)(S.pw0 >> 32) == epoch) have0 = max(have0, (int)(unsigned)S.pw0);
-              if ((unsigned)(S.pw1 >> 32) == epoch) have1 = max(have1, (int)(unsigned)S.pw1);
-            }
-            if (prev != nullptr && drained) { // ... and the one issued a step ago has returned too: one step fresher
-              asm volatile("" : "+v"(prev->pw0), "+v"(prev->pw1));
-              if ((unsigned)(prev->pw0 >> 32) == epoch) have0 = max(have0, (int)(unsigned)prev->pw0);
-              if ((unsigned)(prev->pw1 >> 32) == epoch) have1 = max(have1, (int)(unsigned)prev->pw1);
+            if (drained) { // (only a drain follows a poll)
+              asm volatile("" : "+v"(pw0), "+v"(pw1));
+              if ((unsigned)(pw0 >> 32) == epoch) have0 = max(have0, (int)(unsigned)pw0);
+              if ((unsigned)(pw1 >> 32) == epoch) have1 = max(have1, (int)(unsigned)pw1);
             }
             if (!__all(have0 >= need0 && have1 >= need1)) { // producers far enough? (normally yes: they run ahead)
               unsigned cb = 0;
@@ -515,8 +512,6 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
               S.lofs[u] = pipe_lofs(op[u]);
             }
             pipe_gather_asm8(rhs, (uint32_t)own, src, goff, S.s0, S.xg);
-            pipe_poll_asm(pword0, pword1, S.pw0, S.pw1);
-            S.polled = 1;
           };
           // steps 0 .. prog-1 are stored: the first step of each compute wave that is not known to be stored bounds it
           auto publish_progress = [&]() __attribute__((always_inline)) {
@@ -553,7 +548,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
               bool drained = false;
 #pragma unroll
               for (int u = 0; u < PIPE_CHUNK; ++u) xl[u] = pipe_lds_f64(cur.lofs[u]);
-              if (!LAZY && publish_pending) {
+              if (publish_pending) {
                 drained = true; // the store of the previous step has had these instructions' time to complete
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 nstored = (t - w) / PIPE_NC;
@@ -575,7 +570,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
               dinv = reinterpret_cast<const double *>(ctile + 512)[lane];
             };
             const bool fetched_next = t + PIPE_NC < nsteps;
-            if (fetched_next) fetch(t + PIPE_NC, nxt, &cur, read_ring);
+            if (fetched_next) fetch(t + PIPE_NC, nxt, read_ring);
             else read_ring();
             if (failed) return;
             if (STAMP) {
@@ -589,12 +584,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             // (the drain for the last step has no register operands: no copies of in-flight registers in front of it)
             if (!fetched_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             pipe_wait_gathers<PIPE_INFLIGHT>(cur.s0, cur.xg);
-            asm volatile("" : "+v"(cur.pw0), "+v"(cur.pw1)); // (valid from here on)
             if (W > PIPE_CHUNK) pipe_pin_wide(eg);            // (older than the gathers the wait left in flight: valid too)
-            if (LAZY && t >= PIPE_NC) { // ... so that store has completed
-              nstored = (t - w) / PIPE_NC;
-              if (lane == 0) lds_store(&sh_stored[w], (unsigned)nstored);
-            }
             // Products of the groups of 4 entries that no lane takes from the previous NC - 1 steps; in the other groups p keeps
             // the factor entry until the ring operands can be read (behind the previous step's signal).  The head of the row
             // sum up to the first such group is final already.
@@ -678,17 +668,15 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
               st_sum += st_t - c0;
             }
             const int64_t mypos = pos_base + (int64_t)t * 64 + lane;
+            pipe_poll_asm(pword0, pword1, pw0, pw1); // (as late as possible: the drain of the next step is the first to need it)
             if (wt) st_sc1(dst + mypos, out);
             else dst[mypos] = out;
-            if (!LAZY) publish_pending = true; // drained and published at the top of the next step, behind its first LDS reads
-            else publish_progress();
+            publish_pending = true; // drained and published at the top of the next step, behind its first LDS reads
             if (STAMP) st_d += (unsigned)__builtin_amdgcn_s_memtime() - st_t;
           };
           if (w < nsteps) {
             PipeStep SA, SB;
-            SA.polled = 0;
-            SB.polled = 0;
-            fetch(w, SA, nullptr, []() { return false; });
+            fetch(w, SA, []() { return false; });
             if (failed) return;
             if (STAMP) st_first = __builtin_amdgcn_s_memrealtime();
             for (int t = w; t < nsteps; t += 2 * PIPE_NC) {
