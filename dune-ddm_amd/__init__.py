@@ -256,10 +256,10 @@ class Ilu0:
         return out
 
     def pipe_trace(self, d, x):
-        """diagnostic: (stamps[ntasks, 8] uint64, meta[ntasks, 2] int32 = group, sweep) of one pipe-engine solve"""
+        """diagnostic: (stamps[ntasks, 272] uint64, meta[ntasks, 2] int32 = group, sweep) of one pipe-engine solve"""
         nt = ctypes.c_int64()
         self.ctx.check(self.ctx.lib.ddm_ilu0_pipe_trace(self.ctx.h, self.h, None, None, None, None, 0, ctypes.byref(nt)))
-        out = np.zeros((nt.value, 16), dtype=np.uint64)
+        out = np.zeros((nt.value, 272), dtype=np.uint64)
         meta = np.zeros((nt.value, 2), dtype=np.int32)
         self.ctx.check(self.ctx.lib.ddm_ilu0_pipe_trace(self.ctx.h, self.h, _ptr(d), _ptr(x), _hp(out), _hp(meta), nt.value, ctypes.byref(nt)))
         return out, meta

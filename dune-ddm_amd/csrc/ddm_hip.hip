@@ -1315,10 +1315,10 @@ extern "C" int ddm_ilu0_pipe_trace(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, d
   if (!out_host) return DDM_OK;
   if (capacity_tasks < nt || !d || !x || d == x) return fail(ctx, DDM_EINVAL, "ddm_ilu0_pipe_trace: bad arguments");
   unsigned long long *st = nullptr;
-  HIPCHECK(ctx, hipMalloc((void **)&st, sizeof(unsigned long long) * 16 * (size_t)(nt + 1)));
-  HIPCHECK(ctx, hipMemsetAsync(st, 0, sizeof(unsigned long long) * 16 * (size_t)(nt + 1), ctx->stream));
+  HIPCHECK(ctx, hipMalloc((void **)&st, sizeof(unsigned long long) * PIPE_STAMP_WORDS * (size_t)(nt + 1)));
+  HIPCHECK(ctx, hipMemsetAsync(st, 0, sizeof(unsigned long long) * PIPE_STAMP_WORDS * (size_t)(nt + 1), ctx->stream));
   enqueue_pipe(ctx, F, d, x, st);
-  int rc = ddm_memcpy_d2h(ctx, out_host, st, (int64_t)sizeof(unsigned long long) * 16 * nt);
+  int rc = ddm_memcpy_d2h(ctx, out_host, st, (int64_t)sizeof(unsigned long long) * PIPE_STAMP_WORDS * nt);
   if (!rc && meta_host) {
     std::vector<pipe::Task> tasks((size_t)nt);
     rc = ddm_memcpy_d2h(ctx, tasks.data(), F->p_tasks, (int64_t)sizeof(pipe::Task) * nt);

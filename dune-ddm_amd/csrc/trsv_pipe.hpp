@@ -34,6 +34,7 @@ constexpr int PIPE_DEPTH = 3;       // tiles a loader keeps in flight
 constexpr int PIPE_RING_KIB = 64;   // LDS byte ring of tiles per workgroup (two workgroups per CU).  2 NC tiles (the current and the
                                     // prefetched step of every compute wave) + one in flight must fit, or loaders and compute waves
                                     // would wait for each other: 5 tiles of the widest row the builder accepts (pipe::MAX_W)
+constexpr int PIPE_STAMP_WORDS = 16 + 256; // stamped build: words per task (16 sums, then the time of every step's result store)
 constexpr int PIPE_WIDE = 12;       // further entries of a wide row handled with one gather latency
 constexpr int PIPE_READY = 32;      // ready words (tiles in flight < 32: the smallest tile is 3 KiB)
 constexpr int PIPE_CHUNK = pipe::MIN_W; // entries of a row held in registers; every tile has at least that many (padded), wider rows take the rest from the tile
@@ -672,6 +673,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             if (wt) st_sc1(dst + mypos, out);
             else dst[mypos] = out;
             publish_pending = true; // drained and published at the top of the next step, behind its first LDS reads
+            if (STAMP && w == 0 && lane == 0 && P.stamps && t < PIPE_STAMP_WORDS - 16) P.stamps[(size_t)tid * PIPE_STAMP_WORDS + 16 + t] = __builtin_amdgcn_s_memrealtime();
             if (STAMP) st_d += (unsigned)__builtin_amdgcn_s_memtime() - st_t;
           };
           if (w < nsteps) {
@@ -688,7 +690,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every result store of this wave has completed
           if (STAMP && w == 0 && lane == 0 && P.stamps) {
-            unsigned long long *o = P.stamps + (size_t)tid * 16;
+            unsigned long long *o = P.stamps + (size_t)tid * PIPE_STAMP_WORDS;
             o[0] = st_start;
             o[1] = st_first;
             o[2] = __builtin_amdgcn_s_memrealtime();

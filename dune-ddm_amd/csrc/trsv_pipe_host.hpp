@@ -59,7 +59,8 @@ struct Task { // device-visible descriptor, 512 bytes
   int64_t pos_base;  // first position of the task in the position space of its sweep
   int64_t koff_base; // index of the task's nsteps + 1 cumulative tile offsets (KiB, relative to tile_off) in Schedule::koff
   int32_t nsteps, nprod, group, sweep;
-  int32_t W, first_kib, second_kib, pad[3]; // widest row of the task; sizes of its first two tiles in KiB
+  int32_t W, first_kib, second_kib; // widest row of the task; sizes of its first two tiles in KiB
+  int32_t start_level, pad[2];      // dependency level of the task's first step (diagnostics)
   int32_t prod[MAXPROD]; // global task ids of the producers
 };
 static_assert(sizeof(Task) == 512, "Task layout");
@@ -566,6 +567,7 @@ inline bool build(int64_t n, const int64_t *rp, const int32_t *ci, const double 
           std::memset(&T, 0, sizeof(Task));
           T.tile_off = off;
           T.W = B.tasks[q].W;
+          T.start_level = B.tasks[q].start0;
           T.koff_base = kb;
           int32_t k = 0;
           for (int32_t t = 0; t < B.tasks[q].nsteps; ++t) {

@@ -99,9 +99,10 @@ int64_t ddm_ilu0_num_levels(const ddm_ilu0 *F, int upper);
 int ddm_ilu0_status(ddm_ctx *ctx, const ddm_ilu0 *F, int *status);
 /* diagnostic: one solve with in-kernel cycle stamps of one compute wave */
 int ddm_ilu0_debug_stamps(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, unsigned long long *out6_host);
-/* diagnostic: one solve with the stamped build of the pipe engine's kernel (DDM_TRSV_MODE=pipe, the default); per task 16
- * words: start / first step / end (100 MHz ticks), cycles waiting for tiles / for producer tasks / in the signalled section,
- * steps, XCC id, four segment sums of the compute wave's step (csrc/trsv_pipe.hpp); meta_host (optional) receives group and
+/* diagnostic: one solve with the stamped build of the pipe engine's kernel (DDM_TRSV_MODE=pipe, the default); per task 272
+ * words, the first 16: start / first step / end (100 MHz ticks), cycles waiting for tiles / for producer tasks / in the signalled section,
+ * steps, XCC id, four segment sums of the compute wave's step (csrc/trsv_pipe.hpp), then the time of each of the first 256
+ * steps' result stores; meta_host (optional) receives group and
  * sweep per task.  out_host == NULL queries *ntasks. */
 int ddm_ilu0_pipe_trace(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, unsigned long long *out_host, int32_t *meta_host,
                         int64_t capacity_tasks, int64_t *ntasks);

@@ -31,9 +31,35 @@ extern "C" int pipe_test_build_and_emulate(int64_t n, const int64_t *rp, const i
         active += hdr[0];
         wide += hdr[2] > pipe::MIN_W;
       }
-      std::fprintf(fp, "%d %d %d %d %lld %d %lld\n", T.group, T.sweep, T.W, T.nsteps, (long long)active, T.nprod, (long long)wide);
+      std::fprintf(fp, "%d %d %d %d %lld %d %lld %d", T.group, T.sweep, T.W, T.nsteps, (long long)active, T.nprod, (long long)wide, T.start_level);
+      if (std::getenv("PIPE_DEBUG_NEEDS")) { // producers with the steps of each that the first / the middle / the last step of the task requires
+        for (int j = 0; j < T.nprod; ++j) {
+          std::fprintf(fp, " %d", T.prod[j]);
+          for (int t : {0, T.nsteps / 2, T.nsteps - 1}) {
+            const uint32_t *hdr = reinterpret_cast<const uint32_t *>(S.stream.data() + T.tile_off + (int64_t)S.koff[(size_t)T.koff_base + t] * 1024);
+            std::fprintf(fp, ":%u", (hdr[pipe::HDR_REQ0 + j / 2] >> (16 * (j & 1))) & 0xffffu);
+          }
+        }
+      }
+      std::fprintf(fp, "\n");
     }
     std::fclose(fp);
+    if (const char *nf = std::getenv("PIPE_DEBUG_NEEDS_BIN")) { // per task: nprod, nsteps, producer ids, then per step the steps required of each producer
+      FILE *fb = std::fopen(nf, "wb");
+      for (const pipe::Task &T : S.tasks) {
+        std::fwrite(&T.nprod, 4, 1, fb);
+        std::fwrite(&T.nsteps, 4, 1, fb);
+        std::fwrite(T.prod, 4, (size_t)T.nprod, fb);
+        for (int t = 0; t < T.nsteps; ++t) {
+          const uint32_t *hdr = reinterpret_cast<const uint32_t *>(S.stream.data() + T.tile_off + (int64_t)S.koff[(size_t)T.koff_base + t] * 1024);
+          for (int j = 0; j < T.nprod; ++j) {
+            const uint16_t rq = (uint16_t)((hdr[pipe::HDR_REQ0 + j / 2] >> (16 * (j & 1))) & 0xffffu);
+            std::fwrite(&rq, 2, 1, fb);
+          }
+        }
+      }
+      std::fclose(fb);
+    }
   }
   const std::string e = pipe::emulate(S, n, d, x);
   if (!e.empty()) {
