@@ -127,32 +127,25 @@ __device__ __forceinline__ void pipe_poll_asm(const unsigned long long *p0, cons
                : "memory");
 }
 constexpr int PIPE_INFLIGHT = PIPE_CHUNK + 1; // loads per step issued ahead: right-hand side, PIPE_CHUNK operands
-// the PIPE_WIDE further operands of a wide row, issued in front of the next step's gathers (same in-flight rules)
-__device__ __forceinline__ void pipe_gather_asm_wide(const double *src_uniform, const uint32_t (&off)[PIPE_WIDE], double (&x)[PIPE_WIDE])
+// PIPE_WIDE / 2 further operands of a wide row, issued in front of the next step's gathers (same in-flight rules)
+constexpr int PIPE_WHALF = PIPE_WIDE / 2;
+__device__ __forceinline__ void pipe_gather_asm_wide(const double *src_uniform, const uint32_t (&off)[PIPE_WHALF], double (&x)[PIPE_WHALF])
 {
-  static_assert(PIPE_WIDE == 12, "operand lists below");
+  static_assert(PIPE_WHALF == 6, "operand lists below");
   asm volatile("s_nop 4\n\t"
-               "global_load_dwordx2 %0, %12, %24 sc1\n\t"
-               "global_load_dwordx2 %1, %13, %24 sc1\n\t"
-               "global_load_dwordx2 %2, %14, %24 sc1\n\t"
-               "global_load_dwordx2 %3, %15, %24 sc1\n\t"
-               "global_load_dwordx2 %4, %16, %24 sc1\n\t"
-               "global_load_dwordx2 %5, %17, %24 sc1\n\t"
-               "global_load_dwordx2 %6, %18, %24 sc1\n\t"
-               "global_load_dwordx2 %7, %19, %24 sc1\n\t"
-               "global_load_dwordx2 %8, %20, %24 sc1\n\t"
-               "global_load_dwordx2 %9, %21, %24 sc1\n\t"
-               "global_load_dwordx2 %10, %22, %24 sc1\n\t"
-               "global_load_dwordx2 %11, %23, %24 sc1"
-               : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]), "=&v"(x[8]), "=&v"(x[9]), "=&v"(x[10]),
-                 "=&v"(x[11])
-               : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "v"(off[7]), "v"(off[8]), "v"(off[9]), "v"(off[10]),
-                 "v"(off[11]), "s"(src_uniform)
+               "global_load_dwordx2 %0, %6, %12 sc1\n\t"
+               "global_load_dwordx2 %1, %7, %12 sc1\n\t"
+               "global_load_dwordx2 %2, %8, %12 sc1\n\t"
+               "global_load_dwordx2 %3, %9, %12 sc1\n\t"
+               "global_load_dwordx2 %4, %10, %12 sc1\n\t"
+               "global_load_dwordx2 %5, %11, %12 sc1"
+               : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5])
+               : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "s"(src_uniform)
                : "memory");
 }
-__device__ __forceinline__ void pipe_pin_wide(double (&x)[PIPE_WIDE])
+__device__ __forceinline__ void pipe_pin_wide(double (&x)[PIPE_WHALF])
 {
-  asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11])::"memory");
+  asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5])::"memory");
 }
 template <int N>
 __device__ __forceinline__ void pipe_wait_gathers(double &s0, double (&x)[PIPE_CHUNK])
@@ -483,13 +476,12 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
               unsigned cb = 0;
               if (STAMP) cb = (unsigned)__builtin_amdgcn_s_memtime();
               for (unsigned spins = 0;; ++spins) {
-                if (have0 < need0) {
-                  const unsigned long long pw = __hip_atomic_load(pword0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  if ((unsigned)(pw >> 32) == epoch) have0 = max(have0, (int)(unsigned)pw);
-                }
-                if (have1 < need1) {
-                  const unsigned long long pw = __hip_atomic_load(pword1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  if ((unsigned)(pw >> 32) == epoch) have1 = max(have1, (int)(unsigned)pw);
+                { // both words of every lane in one round trip
+                  unsigned long long q0, q1;
+                  pipe_poll_asm(pword0, pword1, q0, q1);
+                  asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0), "+v"(q1)::"memory");
+                  if ((unsigned)(q0 >> 32) == epoch) have0 = max(have0, (int)(unsigned)q0);
+                  if ((unsigned)(q1 >> 32) == epoch) have1 = max(have1, (int)(unsigned)q1);
                 }
                 if (__all(have0 >= need0 && have1 >= need1)) break;
                 if (spins > (1u << 22)) {
@@ -536,13 +528,34 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             const int W = __builtin_amdgcn_readfirstlane(cur.W);
             const unsigned char *wtile = ctile;
             const pipe::Geometry G(W);
-            uint32_t ego[PIPE_WIDE];
-            double eg[PIPE_WIDE];
-            if (W > PIPE_CHUNK) {
+            // (two halves of PIPE_WHALF entries; the operand words of a half are one batch of LDS reads: pieces that the tile
+            // does not have are read from its last piece instead and masked)
+            auto wide_ops = [&](int u0, int32_t (&o)[PIPE_WHALF]) __attribute__((always_inline)) {
+              const int q0 = u0 >> 2, last = G.idx_pieces - 1;
+              const int4 a = *reinterpret_cast<const int4 *>(wtile + 1024 * G.idx_piece(min(q0, last)) + lane * 16);
+              const int4 b = *reinterpret_cast<const int4 *>(wtile + 1024 * G.idx_piece(min(q0 + 1, last)) + lane * 16);
+              // u0 = 14: entries 14, 15 | 16 .. 19;  u0 = 20: entries 20 .. 23 | 24, 25
+              if ((u0 & 3) == 2) {
+                o[0] = a.z, o[1] = a.w, o[2] = b.x, o[3] = b.y, o[4] = b.z, o[5] = b.w;
+              } else {
+                o[0] = a.x, o[1] = a.y, o[2] = a.z, o[3] = a.w, o[4] = b.x, o[5] = b.y;
+              }
 #pragma unroll
-              for (int u = 0; u < PIPE_WIDE; ++u) {
-                ego[u] = pipe_gofs(pipe::PAD_OP);
-                if (PIPE_CHUNK + u < W) ego[u] = pipe_gofs(*reinterpret_cast<const int32_t *>(wtile + G.idx_off(PIPE_CHUNK + u, lane)));
+              for (int k = 0; k < PIPE_WHALF; ++k)
+                if (u0 + k >= W) o[k] = pipe::PAD_OP; // (wave-uniform)
+            };
+            static_assert(PIPE_CHUNK == 14 && PIPE_WHALF == 6, "piece arithmetic of wide_ops");
+            uint32_t ego0[PIPE_WHALF], ego1[PIPE_WHALF];
+            double eg0[PIPE_WHALF], eg1[PIPE_WHALF];
+            if (W > PIPE_CHUNK) {
+              int32_t o[PIPE_WHALF];
+              wide_ops(PIPE_CHUNK, o);
+#pragma unroll
+              for (int k = 0; k < PIPE_WHALF; ++k) ego0[k] = pipe_gofs(o[k]);
+              if (W > PIPE_CHUNK + PIPE_WHALF) {
+                wide_ops(PIPE_CHUNK + PIPE_WHALF, o);
+#pragma unroll
+                for (int k = 0; k < PIPE_WHALF; ++k) ego1[k] = pipe_gofs(o[k]);
               }
             }
             auto read_ring = [&]() __attribute__((always_inline)) -> bool {
@@ -557,7 +570,8 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
                 publish_progress();
                 publish_pending = false;
               }
-              if (W > PIPE_CHUNK) pipe_gather_asm_wide(src, ego, eg); // (behind the drain above, in front of the next step's gathers)
+              if (W > PIPE_CHUNK) pipe_gather_asm_wide(src, ego0, eg0); // (behind the drain above, in front of the next step's gathers)
+              if (W > PIPE_CHUNK + PIPE_WHALF) pipe_gather_asm_wide(src, ego1, eg1);
               return drained;
             };
             auto read_entries = [&]() __attribute__((always_inline)) {
@@ -585,7 +599,8 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             // (the drain for the last step has no register operands: no copies of in-flight registers in front of it)
             if (!fetched_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             pipe_wait_gathers<PIPE_INFLIGHT>(cur.s0, cur.xg);
-            if (W > PIPE_CHUNK) pipe_pin_wide(eg);            // (older than the gathers the wait left in flight: valid too)
+            if (W > PIPE_CHUNK) pipe_pin_wide(eg0); // (older than the gathers the wait left in flight: valid too)
+            if (W > PIPE_CHUNK + PIPE_WHALF) pipe_pin_wide(eg1);
             // Products of the groups of 4 entries that no lane takes from the previous NC - 1 steps; in the other groups p keeps
             // the factor entry until the ring operands can be read (behind the previous step's signal).  The head of the row
             // sum up to the first such group is final already.
@@ -644,13 +659,26 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             if (k4 < 3) s = (((s - p[8]) - p[9]) - p[10]) - p[11];
             if (k4 < 4) s = (s - p[12]) - p[13];
             if (W > PIPE_CHUNK) {
+              // a half: operand words and factor entries in one batch of LDS reads, then the ring operands, then the row sum
+              auto wide_half = [&](int u0, const double (&eg)[PIPE_WHALF]) __attribute__((always_inline)) {
+                int32_t o[PIPE_WHALF];
+                wide_ops(u0, o);
+                const int lastv = G.val_pieces - 1;
+                double av[PIPE_WHALF], xr[PIPE_WHALF];
 #pragma unroll
-              for (int u = 0; u < PIPE_WIDE; ++u)
-                if (PIPE_CHUNK + u < W) { // wave-uniform
-                  const double av = *reinterpret_cast<const double *>(wtile + G.val_off(PIPE_CHUNK + u, lane));
-                  const int32_t o = *reinterpret_cast<const int32_t *>(wtile + G.idx_off(PIPE_CHUNK + u, lane));
-                  s -= av * pipe_or(eg[u], pipe_lds_f64(pipe_lofs(o)));
+                for (int k = 0; k < PIPE_WHALF / 2; ++k) {
+                  const double2 vv = *reinterpret_cast<const double2 *>(wtile + 1024 * G.val_piece(min((u0 >> 1) + k, lastv)) + lane * 16);
+                  av[2 * k] = vv.x;
+                  av[2 * k + 1] = vv.y;
                 }
+#pragma unroll
+                for (int k = 0; k < PIPE_WHALF; ++k) xr[k] = pipe_lds_f64(pipe_lofs(o[k]));
+#pragma unroll
+                for (int k = 0; k < PIPE_WHALF; ++k)
+                  if (u0 + k < W) s -= av[k] * pipe_or(eg[k], xr[k]); // (wave-uniform)
+              };
+              wide_half(PIPE_CHUNK, eg0);
+              if (W > PIPE_CHUNK + PIPE_WHALF) wide_half(PIPE_CHUNK + PIPE_WHALF, eg1);
               for (int u = PIPE_CHUNK + PIPE_WIDE; u < W; ++u) { // still wider (not seen on the stencils of SURVEY section 8): entry by entry
                 const int32_t o = *reinterpret_cast<const int32_t *>(wtile + G.idx_off(u, lane));
                 const double av = *reinterpret_cast<const double *>(wtile + G.val_off(u, lane));
