@@ -49,6 +49,7 @@ struct PipeStep { // registers of one step, filled NC steps ahead of their use (
   int W;
   unsigned late;       // entries whose ring operand may come from one of the NC - 1 steps before this one
   unsigned tpos, vend; // tile position in the LDS ring (KiB), virtual ring offset behind the tile
+  int deferred;        // (uniform) the producers were not far enough when the step was prefetched: its gathers are issued by fetch_late()
 };
 __device__ __forceinline__ double pipe_ld_sc1_off(const double *base, uint32_t byte_off)
 {
@@ -409,7 +410,45 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
           int nstored = 0; // own steps whose result store has completed
           bool publish_pending = false; // the previous step's store (and the poll in front of it) has been issued but not yet drained and published
           unsigned long long pw0 = 0, pw1 = 0; // progress words of the two producers this lane watches (non-blocking poll)
-          auto fetch = [&](int t, PipeStep &S, auto &&after_issue) __attribute__((always_inline)) {
+          // waits (polling) until the producers have stored what the lanes need
+          auto block_on_producers = [&](int t, int need0, int need1, auto &&on_first_drain) __attribute__((always_inline)) {
+            unsigned cb = 0;
+            if (STAMP) cb = (unsigned)__builtin_amdgcn_s_memtime();
+            for (unsigned spins = 0;; ++spins) {
+              { // both words of every lane in one round trip
+                unsigned long long q0, q1;
+                pipe_poll_asm(pword0, pword1, q0, q1);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0), "+v"(q1)::"memory");
+                if ((unsigned)(q0 >> 32) == epoch) have0 = max(have0, (int)(unsigned)q0);
+                if ((unsigned)(q1 >> 32) == epoch) have1 = max(have1, (int)(unsigned)q1);
+              }
+              if (spins == 0) on_first_drain();
+              if (__all(have0 >= need0 && have1 >= need1)) break;
+              if (spins > (1u << 22)) {
+                if (lane == 0) __hip_atomic_store(P.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                failed = true;
+                return;
+              }
+              __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (STAMP && t > w) {
+              st_nblock += 1;
+              st_cblock += (unsigned)__builtin_amdgcn_s_memtime() - cb;
+            }
+          };
+          auto issue_gathers = [&](PipeStep &S, const int32_t (&op)[PIPE_CHUNK], int own) __attribute__((always_inline)) {
+            uint32_t goff[PIPE_CHUNK];
+#pragma unroll
+            for (int u = 0; u < PIPE_CHUNK; ++u) {
+              goff[u] = pipe_gofs(op[u]);
+              S.lofs[u] = pipe_lofs(op[u]);
+            }
+            pipe_gather_asm8(rhs, (uint32_t)own, src, goff, S.s0, S.xg);
+          };
+          // may_defer: when the producers are not far enough, do not wait here (the caller still has the current step to compute):
+          // S.deferred is set and fetch_late() finishes the job
+          auto fetch = [&](int t, PipeStep &S, bool may_defer, auto &&after_issue) __attribute__((always_inline)) {
             unsigned pos;
             place(v, next_kib, pos);
             S.tpos = pos;
@@ -472,39 +511,20 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
               if ((unsigned)(pw0 >> 32) == epoch) have0 = max(have0, (int)(unsigned)pw0);
               if ((unsigned)(pw1 >> 32) == epoch) have1 = max(have1, (int)(unsigned)pw1);
             }
+            S.deferred = 0;
             if (!__all(have0 >= need0 && have1 >= need1)) { // producers far enough? (normally yes: they run ahead)
-              unsigned cb = 0;
-              if (STAMP) cb = (unsigned)__builtin_amdgcn_s_memtime();
-              for (unsigned spins = 0;; ++spins) {
-                { // both words of every lane in one round trip
-                  unsigned long long q0, q1;
-                  pipe_poll_asm(pword0, pword1, q0, q1);
-                  asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0), "+v"(q1)::"memory");
-                  if ((unsigned)(q0 >> 32) == epoch) have0 = max(have0, (int)(unsigned)q0);
-                  if ((unsigned)(q1 >> 32) == epoch) have1 = max(have1, (int)(unsigned)q1);
-                }
-                if (__all(have0 >= need0 && have1 >= need1)) break;
-                if (spins > (1u << 22)) {
-                  if (lane == 0) __hip_atomic_store(P.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  failed = true;
-                  return;
-                }
-                __builtin_amdgcn_s_sleep(1);
+              if (may_defer) {
+                S.deferred = 1;
+#pragma unroll
+                for (int u = 0; u < PIPE_CHUNK; ++u) S.lofs[u] = pipe_lofs(op[u]); // (the ring operands are read at the top of the step)
+                if (STAMP) st_prog += (unsigned)__builtin_amdgcn_s_memtime() - c0;
+                return;
               }
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-              if (STAMP && t > w) {
-                st_nblock += 1;
-                st_cblock += (unsigned)__builtin_amdgcn_s_memtime() - cb;
-              }
+              block_on_producers(t, need0, need1, []() {});
+              if (failed) return;
             }
             if (STAMP) st_prog += (unsigned)__builtin_amdgcn_s_memtime() - c0;
-            uint32_t goff[PIPE_CHUNK];
-#pragma unroll
-            for (int u = 0; u < PIPE_CHUNK; ++u) {
-              goff[u] = pipe_gofs(op[u]);
-              S.lofs[u] = pipe_lofs(op[u]);
-            }
-            pipe_gather_asm8(rhs, (uint32_t)own, src, goff, S.s0, S.xg);
+            issue_gathers(S, op, own);
           };
           // steps 0 .. prog-1 are stored: the first step of each compute wave that is not known to be stored bounds it
           auto publish_progress = [&]() __attribute__((always_inline)) {
@@ -513,6 +533,28 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             for (int k = 0; k < PIPE_NC; ++k)
               if (k != w) prog = min(prog, k + PIPE_NC * (int)lds_load(&sh_stored[k]));
             publish(prog);
+          };
+          // second half of a deferred fetch(), behind the caller's own step: the operand words again (the tile is resident), the
+          // wait for the producers, the gathers.  The first poll's drain also covers the caller's result store: published there.
+          auto fetch_late = [&](int t, PipeStep &S, auto &&on_first_drain) __attribute__((always_inline)) {
+            const unsigned char *tile = tiles + S.tpos * 1024;
+            const int4 *idxp = reinterpret_cast<const int4 *>(tile + 1024 * (1 + PIPE_CHUNK / 2)) + lane;
+            const int need = reinterpret_cast<const int32_t *>(tile)[pipe::HDR_REQ0 + (lane < 56 ? lane : 0)];
+            const int own = reinterpret_cast<const int32_t *>(tile + 256)[lane];
+            int32_t op[PIPE_CHUNK];
+#pragma unroll
+            for (int q4 = 0; q4 < (PIPE_CHUNK + 3) / 4; ++q4) {
+              const int4 o = idxp[q4 * 64];
+              if (4 * q4 < PIPE_CHUNK) op[4 * q4] = o.x;
+              if (4 * q4 + 1 < PIPE_CHUNK) op[4 * q4 + 1] = o.y;
+              if (4 * q4 + 2 < PIPE_CHUNK) op[4 * q4 + 2] = o.z;
+              if (4 * q4 + 3 < PIPE_CHUNK) op[4 * q4 + 3] = o.w;
+            }
+            const int need0 = 2 * lane < nprod ? (need & 0xffff) : 0, need1 = 2 * lane + 1 < nprod ? (int)((unsigned)need >> 16) : 0;
+            block_on_producers(t, need0, need1, on_first_drain);
+            if (failed) return;
+            issue_gathers(S, op, own);
+            S.deferred = 0;
           };
           // one step: "k4" = number of leading groups of 4 entries that no lane takes from the previous NC - 1 steps
           auto step = [&](int t, PipeStep &cur, PipeStep &nxt) __attribute__((always_inline)) {
@@ -585,7 +627,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
               dinv = reinterpret_cast<const double *>(ctile + 512)[lane];
             };
             const bool fetched_next = t + PIPE_NC < nsteps;
-            if (fetched_next) fetch(t + PIPE_NC, nxt, read_ring);
+            if (fetched_next) fetch(t + PIPE_NC, nxt, true, read_ring);
             else read_ring();
             if (failed) return;
             if (STAMP) {
@@ -597,7 +639,8 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             // behind this step's gathers: the result store of this wave's previous step and, if there is a next step, its
             // PIPE_INFLIGHT loads => at most that many operations may still be outstanding
             // (the drain for the last step has no register operands: no copies of in-flight registers in front of it)
-            if (!fetched_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const bool deferred_next = fetched_next && __builtin_amdgcn_readfirstlane(nxt.deferred) != 0; // (no gathers of the next step in flight)
+            if (!fetched_next || deferred_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             pipe_wait_gathers<PIPE_INFLIGHT>(cur.s0, cur.xg);
             if (W > PIPE_CHUNK) pipe_pin_wide(eg0); // (older than the gathers the wait left in flight: valid too)
             if (W > PIPE_CHUNK + PIPE_WHALF) pipe_pin_wide(eg1);
@@ -701,12 +744,21 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             if (wt) st_sc1(dst + mypos, out);
             else dst[mypos] = out;
             publish_pending = true; // drained and published at the top of the next step, behind its first LDS reads
+            if (deferred_next) { // the next step's producers were not far enough at the top of this step: now is the time to wait for them
+              fetch_late(t + PIPE_NC, nxt, [&]() {
+                nstored = (t - w) / PIPE_NC + 1; // (the drain behind the first poll has completed this step's store)
+                if (lane == 0) lds_store(&sh_stored[w], (unsigned)nstored);
+                publish_progress();
+                publish_pending = false;
+              });
+              if (failed) return;
+            }
             if (STAMP && w == 0 && lane == 0 && P.stamps && t < PIPE_STAMP_WORDS - 16) P.stamps[(size_t)tid * PIPE_STAMP_WORDS + 16 + t] = __builtin_amdgcn_s_memrealtime();
             if (STAMP) st_d += (unsigned)__builtin_amdgcn_s_memtime() - st_t;
           };
           if (w < nsteps) {
             PipeStep SA, SB;
-            fetch(w, SA, []() { return false; });
+            fetch(w, SA, false, []() { return false; });
             if (failed) return;
             if (STAMP) st_first = __builtin_amdgcn_s_memrealtime();
             for (int t = w; t < nsteps; t += 2 * PIPE_NC) {
