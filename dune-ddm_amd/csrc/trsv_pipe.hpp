@@ -227,6 +227,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
   unsigned *sh_ready = ctl;                    // [PIPE_READY] tile t is in LDS when sh_ready[t % PIPE_READY] == t + 1
   unsigned &sh_vconsumed = ctl[PIPE_READY];    // virtual ring offset (KiB) behind the last tile that is no longer needed
   unsigned &sh_xcc = ctl[PIPE_READY + 1], &sh_gt = ctl[PIPE_READY + 2], &sh_fail = ctl[PIPE_READY + 3], &sh_q = ctl[PIPE_READY + 4];
+  unsigned &sh_xt = ctl[PIPE_READY + 6];       // this workgroup's arrival number on its XCD
   unsigned &sh_stepdone = ctl[PIPE_READY + 5]; // steps of the task whose results are in the LDS ring
   unsigned *sh_stored = ctl + PIPE_READY + 8;  // [PIPE_NC] own steps of compute wave w whose global stores have completed
   unsigned char *tiles = smem + PIPE_RINGAREA; // byte ring of tiles
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
   if (threadIdx.x == 0) {
     const unsigned xcc = hw_xcc_id();
     sh_xcc = xcc;
-    __hip_atomic_fetch_add(&st->tickets[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh_xt = __hip_atomic_fetch_add(&st->tickets[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     sh_gt = __hip_atomic_fetch_add(&st->global_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(&st->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned fail_ = 0;
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
   __syncthreads();
   if (sh_fail) return;
   const unsigned xcc = sh_xcc;
+  const unsigned xt = sh_xt;
   const unsigned epoch = __hip_atomic_load(&st->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned tk = lane < 8 ? __hip_atomic_load(&st->tickets[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
   // XCD-local mode: subdomain g lives on XCD g % 8 -- possible when every XCD that owns a subdomain hosts workgroups (with
@@ -272,7 +274,9 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
   const int gcount = local_ok ? ((int)xcc < P.ngroups ? (P.ngroups - (int)xcc + 7) / 8 : 0) : P.ngroups;
 
   for (int gi = 0; gi < gcount; ++gi) {
-    const int g = local_ok ? gfirst + 8 * gi : (gfirst + gi) % P.ngroups;
+    // an XCD that owns several subdomains works on all of them at once: its workgroups start on different ones (each sweep is
+    // latency-bound and keeps only some tens of workgroups busy) and move on to the others as their queues run dry
+    const int g = local_ok ? gfirst + 8 * (int)((gi + xt) % (unsigned)gcount) : (gfirst + gi) % P.ngroups;
     const pipe::Group *Gp = P.groups + g;
     const int ntaskL = Gp->ntask[0];
     unsigned *qbase = P.queue + (size_t)g * 4 * 32;

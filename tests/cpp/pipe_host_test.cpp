@@ -25,13 +25,22 @@ extern "C" int pipe_test_build_and_emulate(int64_t n, const int64_t *rp, const i
   if (const char *f = std::getenv("PIPE_DEBUG_TASKS")) { // per task: group sweep W nsteps active-rows nprod
     FILE *fp = std::fopen(f, "w");
     for (const pipe::Task &T : S.tasks) {
-      int64_t active = 0, wide = 0;
+      int64_t active = 0, wide = 0, remote_slots = 0;
       for (int t = 0; t < T.nsteps; ++t) {
         const int32_t *hdr = reinterpret_cast<const int32_t *>(S.stream.data() + T.tile_off + (int64_t)S.koff[(size_t)T.koff_base + t] * 1024);
         active += hdr[0];
         wide += hdr[2] > pipe::MIN_W;
+        { // slots of the first MIN_W entries that hold a gathered operand in some lane
+          const pipe::Geometry G(hdr[2]);
+          const unsigned char *tile = reinterpret_cast<const unsigned char *>(hdr);
+          for (int u = 0; u < pipe::MIN_W; ++u) {
+            bool any = false;
+            for (int l = 0; l < pipe::LANES; ++l) any |= *reinterpret_cast<const int32_t *>(tile + G.idx_off(u, l)) > pipe::RING_Z;
+            remote_slots += any;
+          }
+        }
       }
-      std::fprintf(fp, "%d %d %d %d %lld %d %lld %d", T.group, T.sweep, T.W, T.nsteps, (long long)active, T.nprod, (long long)wide, T.start_level);
+      std::fprintf(fp, "%d %d %d %d %lld %d %lld %d %lld", T.group, T.sweep, T.W, T.nsteps, (long long)active, T.nprod, (long long)wide, T.start_level, (long long)remote_slots);
       if (std::getenv("PIPE_DEBUG_NEEDS")) { // producers with the steps of each that the first / the middle / the last step of the task requires
         for (int j = 0; j < T.nprod; ++j) {
           std::fprintf(fp, " %d", T.prod[j]);

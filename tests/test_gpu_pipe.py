@@ -35,6 +35,7 @@ def _oracle_solve(M, bp, d):
 @pytest.mark.parametrize("spread", ["0", "1"])                  # XCD-local hand-overs / subdomains spread over all XCDs (write-through)
 @pytest.mark.parametrize("N,P", [((26, 24, 22), (2, 2, 2)),      # 8 subdomains
                                  ((20, 18, 16), (2, 1, 1)),      # 2 subdomains
+                                 ((24, 21, 16), (3, 3, 2)),      # 18 subdomains: XCDs own two or three of them and work on them at once
                                  ((9, 8, 7), (1, 1, 1))])
 def test_pipe_solve_bit_exact(ddm, N, P, spread, monkeypatch):
     import torch
