@@ -64,17 +64,38 @@ __global__ __launch_bounds__(WG) void k_spmv_stream(const int64_t *__restrict__ 
     if (threadIdx.x == 0) y[r0] = ACC ? y[r0] + alpha * s : s;
     return;
   }
+  // all loads of a thread are issued before the first one is needed: indices past the block's end are clamped (loaded, not
+  // stored) instead of branched around, so that nothing serialises the SPMV_NNZ / WG independent load -> gather chains
+  constexpr int U = SPMV_NNZ / WG;
+  const int last = (int)nz - 1;
+  if (last >= 0) {
+    int32_t c[U];
+    double v[U], xv[U];
 #pragma unroll
-  for (int u = 0; u < SPMV_NNZ / WG; ++u) {
-    const int k = threadIdx.x + u * WG;
-    if (k < nz) prod[k] = va[z0 + k] * x[ci[z0 + k]];
+    for (int u = 0; u < U; ++u) c[u] = ci[z0 + min((int)threadIdx.x + u * WG, last)];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = va[z0 + min((int)threadIdx.x + u * WG, last)];
+#pragma unroll
+    for (int u = 0; u < U; ++u) xv[u] = x[c[u]];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = threadIdx.x + u * WG;
+      if (k <= last) prod[k] = v[u] * xv[u];
+    }
   }
   __syncthreads();
   const int r = r0 + threadIdx.x;
   if (r < r1) {
     const int k0 = (int)(rp[r] - z0), k1 = (int)(rp[r + 1] - z0);
     double s = 0.0;
-    for (int k = k0; k < k1; ++k) s += prod[k];
+    for (int kb = k0; kb < k1; kb += 8) { // eight LDS reads in flight, summed in column order
+      double q[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q[j] = prod[min(kb + j, k1 - 1)];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (kb + j < k1) s += q[j];
+    }
     y[r] = ACC ? y[r] + alpha * s : s;
   }
 }
