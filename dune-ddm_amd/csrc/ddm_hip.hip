@@ -563,6 +563,7 @@ static void free_schedule(TriSchedule &S)
   (void)hipFree(S.d_desc);
 }
 
+static int build_pipe_schedule(ddm_ctx *ctx, ddm_ilu0 *F);
 extern "C" int ddm_ilu0_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, ddm_ilu0 **out)
 {
   if (!ctx || !A || !out || nblocks < 1 || !block_ptr) return fail(ctx, DDM_EINVAL, "ddm_ilu0_create: bad arguments");
@@ -606,6 +607,7 @@ extern "C" int ddm_ilu0_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, 
         hipMemset(F->err, 0, 128) != hipSuccess)
       rc = fail(ctx, DDM_EHIP, "ILU(0): counter allocation failed");
   }
+  if (!rc && F->mode == 8 && F->n > 0) rc = build_pipe_schedule(ctx, F); // part of the setup, not of the first solve (not applicable: pipe_state < 0, see ddm_ilu0_solve)
   if (rc) {
     ddm_ilu0_destroy(F);
     return rc;
