@@ -157,7 +157,7 @@ def main():
                  "xcdw": "k_trsv_xcdw", "xcd2": "k_trsv_xcd2<false>"}.get(engine, "k_trsv_pipe (+ k_pipe_permute_in/out)")
         traffic = None
         try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command (profiles/), gfx950-corrected
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_g_pmc_traffic_grid216_pipe.json" if engine == "pipe" else "r01_b_pmc_traffic_grid216.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_h_pmc_traffic_grid216_pipe.json" if engine == "pipe" else "r01_b_pmc_traffic_grid216.json")))
             if G == 216 and engine in pmc.get("engine_kernels", {}):
                 traffic = pmc["kernels"][pmc["engine_kernels"][engine]]["hbm_bytes_per_dispatch_corrected"] / world if P == 2 else None
         except Exception:

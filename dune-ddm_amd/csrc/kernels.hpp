@@ -1776,7 +1776,18 @@ __global__ __launch_bounds__(WG) void k_coarse_restrict_partial(int kmax, int64_
   for (int j = w; j < kmax; j += 4) {
     const double *bj = basis + (int64_t)j * ld;
     double s = 0.0;
-    for (int64_t r = c.r0 + lane; r < c.r1; r += 64) s += bj[r] * d[r];
+    // (eight loads of each stream in flight per lane; the products are added in the same order as one by one)
+    int64_t r = c.r0 + lane;
+    for (; r + 7 * 64 < c.r1; r += 8 * 64) {
+      double bv[8], dv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) bv[u] = __builtin_nontemporal_load(bj + r + u * 64);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) dv[u] = d[r + u * 64];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += bv[u] * dv[u];
+    }
+    for (; r < c.r1; r += 64) s += bj[r] * d[r];
     s = wave_sum(s);
     if (lane == 0) partial[(int64_t)blockIdx.x * kmax + j] = s;
   }
@@ -1825,7 +1836,15 @@ __global__ __launch_bounds__(WG) void k_coarse_prolong(int kmax, int64_t ld, con
   __syncthreads();
   for (int64_t r = c.r0 + threadIdx.x; r < c.r1; r += WG) {
     double s = 0.0;
-    for (int j = 0; j < kmax; ++j) s += cj[j] * basis[(int64_t)j * ld + r];
+    int j = 0;
+    for (; j + 8 <= kmax; j += 8) { // (eight basis vectors in flight, added in order)
+      double bv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) bv[u] = __builtin_nontemporal_load(basis + (int64_t)(j + u) * ld + r);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += cj[j + u] * bv[u];
+    }
+    for (; j < kmax; ++j) s += cj[j] * basis[(int64_t)j * ld + r];
     xov[r] = s;
   }
 }

@@ -1,6 +1,11 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out
-timeout -k 10 500 python -m pytest tests/test_gpu_pipe.py -x -q > gpurun_out/try_tests.log 2>&1 || { tail -30 gpurun_out/try_tests.log; exit 1; }
-tail -2 gpurun_out/try_tests.log
-timeout -k 10 300 python tools/trsv_engines_bench.py 216 2 2 2 pipe 10 2>&1 | grep engine | tee gpurun_out/try_bench.log
+python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1 || { tail -30 gpurun_out/gpu_tests.log; exit 1; }
+tail -2 gpurun_out/gpu_tests.log
+python bench.py --cpu-iters 0 > gpurun_out/bench_try.json 2> gpurun_out/bench_try.log || { tail -30 gpurun_out/bench_try.log; exit 1; }
+python - <<'PY'
+import json
+d=json.load(open("gpurun_out/bench_try.json"))
+print("it/s", round(d["value"],2), "ms/step", round(d["ms_per_step"],3), d["solve"], d["iteration_traffic"]["phase_ms_per_iteration"])
+PY
