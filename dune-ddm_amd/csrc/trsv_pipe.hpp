@@ -7,8 +7,10 @@
 // Per step of the compute wave: operands of the own task from the LDS result ring, operands of other tasks by sc1
 // gathers from the position arrays (guarded by the producers' progress words, which are normally ahead), the row sum in
 // ascending column order (= the sequential back-solve), one coalesced 512-byte store of the 64 results.  The wave is
-// software-pipelined by hand: header and operand words of the NEXT tile, the progress check, the next step's 15 gathers
-// and a non-blocking poll of the producers' progress words are issued before the row sums of the current step.
+// software-pipelined by hand: header and operand words of the NEXT tile, the progress check and the next step's 15 gathers
+// are issued before the row sums of the current step.  A check that fails there is DEFERRED: the wave computes the current
+// step first (it has the operands), then waits for the producers and issues the gathers (fetch_late) -- a consumer that
+// runs right behind its producer does not idle with work at hand.
 // PIPE_NC = 2 (built, bit-exact, not faster -- DESIGN.md section 3) lets two compute waves alternate the steps of a task:
 // wave w takes steps w, w + NC, ...; only the operands flagged in the tile's late mask are read after the previous
 // step has signalled (one LDS word).
