@@ -82,3 +82,12 @@ for k in range(40):
     print(f"task {i:3d} step {t:3d} store {own[t]:8.2f} dur {own[t]-prev[t]:5.2f} | latest producer task {p} step {s} stored {tstep[p][s]:8.2f} lag {own[t]-tstep[p][s]:5.2f}")
     if own[t]-tstep[p][s] < (own[t]-prev[t])+0.3: i,t=p,s
     else: t-=1
+print("---- largest hand-overs on the critical path of each sweep: (consumer task, step) <- (producer task, step): us")
+for sw in (0, 1):
+    ids = [i for i in range(nt) if sweep[i] == sw]
+    last = max(ids, key=lambda i: tstep[i][steps[i] - 1])
+    h, n, th, tn, path = backtrace(last, steps[last] - 1)
+    big = sorted(path, key=lambda q: -q[4])[:12]
+    print(f"sweep {sw}:", [(int(a), int(b), int(c), int(d), round(float(e), 1)) for (a, b, c, d, e) in big])
+    hc = np.array([q[4] for q in path])
+    print(f"   hand-over cost percentiles 10/50/90: {np.percentile(hc, [10, 50, 90]).round(2)}; sum of those above 6 us: {hc[hc > 6].sum():.0f} us in {int((hc > 6).sum())} hops")
