@@ -1834,18 +1834,28 @@ __global__ __launch_bounds__(WG) void k_coarse_prolong(int kmax, int64_t ld, con
     cj[threadIdx.x] = gi >= 0 ? x0[gi] : 0.0;
   }
   __syncthreads();
-  for (int64_t r = c.r0 + threadIdx.x; r < c.r1; r += WG) {
-    double s = 0.0;
+  // two rows per thread and trip, four basis vectors of each in flight (added in order; kmax is usually a multiple of 4)
+  for (int64_t r = c.r0 + threadIdx.x; r < c.r1; r += 2 * WG) {
+    const int64_t r2 = r + WG < c.r1 ? r + WG : r; // (the second row of the last trip may not exist: computed twice, stored once)
+    double s = 0.0, s2 = 0.0;
     int j = 0;
-    for (; j + 8 <= kmax; j += 8) { // (eight basis vectors in flight, added in order)
-      double bv[8];
+    for (; j + 4 <= kmax; j += 4) {
+      double bv[4], bw[4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) bv[u] = __builtin_nontemporal_load(basis + (int64_t)(j + u) * ld + r);
+      for (int u = 0; u < 4; ++u) bv[u] = __builtin_nontemporal_load(basis + (int64_t)(j + u) * ld + r);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s += cj[j + u] * bv[u];
+      for (int u = 0; u < 4; ++u) bw[u] = __builtin_nontemporal_load(basis + (int64_t)(j + u) * ld + r2);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += cj[j + u] * bv[u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s2 += cj[j + u] * bw[u];
     }
-    for (; j < kmax; ++j) s += cj[j] * basis[(int64_t)j * ld + r];
+    for (; j < kmax; ++j) {
+      s += cj[j] * basis[(int64_t)j * ld + r];
+      s2 += cj[j] * basis[(int64_t)j * ld + r2];
+    }
     xov[r] = s;
+    if (r2 != r) xov[r2] = s2;
   }
 }
 
