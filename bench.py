@@ -153,8 +153,7 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         engine = os.environ.get("DDM_TRSV_MODE", "pipe")
         kname = {"levels": "k_trsv_lower_level + k_trsv_upper_level + k_trsv_small_levels (one launch per level, HIP graph)",
-                 "persistent": "k_trsv_persistent", "syncfree": "k_trsv_syncfree", "xcd": "k_trsv_xcd", "xcd3": "k_trsv_xcd2<true>",
-                 "xcdw": "k_trsv_xcdw", "xcd2": "k_trsv_xcd2<false>"}.get(engine, "k_trsv_pipe (+ k_pipe_permute_in/out)")
+                 "xcd2": "k_trsv_xcd2"}.get(engine, "k_trsv_pipe (+ k_pipe_permute_in/out)")
         traffic = None
         try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command (profiles/), gfx950-corrected
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_h_pmc_traffic_grid216_pipe.json" if engine == "pipe" else "r01_b_pmc_traffic_grid216.json")))

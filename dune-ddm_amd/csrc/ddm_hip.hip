@@ -65,7 +65,7 @@ static int fail(ddm_ctx *ctx, int code, const char *fmt, ...)
   } while (0)
 
 // single-launch triangular solves need every workgroup resident: one workgroup per CU at most
-static inline int persistent_grid(const ddm_ctx *ctx) { return std::max(8, std::min(TRSV_P_GRID, ctx->num_cu) / 8 * 8); }
+static inline int persistent_grid(const ddm_ctx *ctx) { return std::max(8, std::min(256, ctx->num_cu) / 8 * 8); }
 
 static inline int grid_for(int64_t n, int per_block = WG, int cap = 2048)
 {
@@ -398,9 +398,8 @@ struct TriSchedule { // one triangular factor, level by level in sliced ELL
 
 struct ddm_ilu0 {
   int64_t n = 0, nnz = 0;
-  int mode = 8;                 // 8 = pipe (default; falls back to 4 when not applicable), 4 = XCD-local + loader wave, 3 = XCD-local single wave, 5 = dataflow, 6 = LDS-staged windows, 1 = single launch + level counters, 2 = data-driven, 0 = launch per level
-  double *ywork = nullptr;      // forward-solve result of the data-driven kernel
-  // XCD-local engine (mode 3): per-block (subdomain) level schedules, built on first use
+  int mode = 8;                 // 8 = pipe (default; falls back to 4 when not applicable), 4 = xcd2 (XCD-local + loader waves), 0 = one launch per level
+  // xcd2 engine (mode 4): per-block (subdomain) level schedules, built on first use
   std::vector<int64_t> h_diag, h_block_ptr;
   const ddm_csr *A = nullptr;
   bool xcd_built = false;
@@ -429,28 +428,6 @@ struct ddm_ilu0 {
   int p_grid = 0;
   pipe::Stats p_stats;
   int64_t p_stream_bytes = 0;
-  // slab-ownership engine (mode 7)
-  bool slab_built = false;
-  SlabGroup *sg = nullptr;
-  int64_t *s_wave_ptr = nullptr, *s_lpos = nullptr;
-  SlabStep *s_steps = nullptr;
-  int32_t *s_rows = nullptr, *s_cols = nullptr;
-  double *s_vals = nullptr, *s_dinv = nullptr, *s_dperm = nullptr;
-  unsigned *s_progress = nullptr;
-  int64_t s_npos = 0;
-  // windowed level-permuted engine (mode 6)
-  int w_state = 0;              // 0 not built, 1 built, -1 not applicable (rows wider than a tile)
-  GroupDesc *wg = nullptr;
-  WLevel *wlev = nullptr;
-  WChunk *wchunk = nullptr;
-  int64_t *wflag_off = nullptr, *wlpos = nullptr, *wupos = nullptr;
-  int32_t *wrows = nullptr, *widx = nullptr, *wown = nullptr;
-  double *wvals = nullptr, *wdinv = nullptr, *wdperm = nullptr, *wxp = nullptr;
-  unsigned *wflags = nullptr;
-  int64_t wnpos = 0;
-  double w_direct_frac = 0.0;
-  unsigned *cnt = nullptr;      // per-level sharded arrival counters, zeroed before every solve; last word block = error flag
-  size_t cnt_bytes = 0;
   unsigned *err = nullptr;
   std::vector<double> h_lu; // factor values in the pattern of A
   TriSchedule L, U;
@@ -596,17 +573,11 @@ extern "C" int ddm_ilu0_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, 
     }
   int rc = build_schedule(ctx, A, F->h_lu, diag, false, F->L);
   if (!rc) rc = build_schedule(ctx, A, F->h_lu, diag, true, F->U);
-  if (const char *m = std::getenv("DDM_TRSV_MODE")) F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "syncfree") ? 2 : (!std::strcmp(m, "persistent") ? 1 : (!std::strcmp(m, "xcd") ? 3 : (!std::strcmp(m, "xcd3") ? 5 : (!std::strcmp(m, "xcdw") ? 6 : (!std::strcmp(m, "slab") ? 7 : (!std::strcmp(m, "xcd2") ? 4 : 8)))))));
+  if (const char *m = std::getenv("DDM_TRSV_MODE")) F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "xcd2") ? 4 : 8);
   F->A = A;
   F->h_diag = diag;
   F->h_block_ptr.assign(block_ptr, block_ptr + nblocks + 1);
-  if (!rc && hipMalloc((void **)&F->ywork, sizeof(double) * (size_t)std::max<int64_t>(F->n, 1)) != hipSuccess) rc = fail(ctx, DDM_EHIP, "ILU(0): allocation failed");
-  if (!rc) {
-    F->cnt_bytes = sizeof(unsigned) * (size_t)(F->L.nlev + F->U.nlev) * TRSV_P_SHARDS * TRSV_P_STRIDE;
-    if (hipMalloc((void **)&F->cnt, F->cnt_bytes + 128) != hipSuccess || hipMalloc((void **)&F->err, 128) != hipSuccess ||
-        hipMemset(F->err, 0, 128) != hipSuccess)
-      rc = fail(ctx, DDM_EHIP, "ILU(0): counter allocation failed");
-  }
+  if (!rc && (hipMalloc((void **)&F->err, 128) != hipSuccess || hipMemset(F->err, 0, 128) != hipSuccess)) rc = fail(ctx, DDM_EHIP, "ILU(0): allocation failed");
   if (!rc && F->mode == 8 && F->n > 0) rc = build_pipe_schedule(ctx, F); // part of the setup, not of the first solve (not applicable: pipe_state < 0, see ddm_ilu0_solve)
   if (rc) {
     ddm_ilu0_destroy(F);
@@ -619,9 +590,7 @@ extern "C" void ddm_ilu0_destroy(ddm_ilu0 *F)
 {
   if (!F) return;
   if (F->graph) (void)hipGraphExecDestroy(F->graph);
-  (void)hipFree(F->cnt);
   (void)hipFree(F->err);
-  (void)hipFree(F->ywork);
   (void)hipFree(F->xg);
   (void)hipFree(F->xdesc);
   (void)hipFree(F->xflag_off);
@@ -644,30 +613,6 @@ extern "C" void ddm_ilu0_destroy(ddm_ilu0 *F)
   (void)hipFree(F->p_xpos);
   (void)hipFree(F->p_progress);
   (void)hipFree(F->p_queue);
-  (void)hipFree(F->sg);
-  (void)hipFree(F->s_wave_ptr);
-  (void)hipFree(F->s_lpos);
-  (void)hipFree(F->s_steps);
-  (void)hipFree(F->s_rows);
-  (void)hipFree(F->s_cols);
-  (void)hipFree(F->s_vals);
-  (void)hipFree(F->s_dinv);
-  (void)hipFree(F->s_dperm);
-  (void)hipFree(F->s_progress);
-  (void)hipFree(F->wg);
-  (void)hipFree(F->wlev);
-  (void)hipFree(F->wchunk);
-  (void)hipFree(F->wflag_off);
-  (void)hipFree(F->wlpos);
-  (void)hipFree(F->wupos);
-  (void)hipFree(F->wrows);
-  (void)hipFree(F->widx);
-  (void)hipFree(F->wown);
-  (void)hipFree(F->wvals);
-  (void)hipFree(F->wdinv);
-  (void)hipFree(F->wdperm);
-  (void)hipFree(F->wxp);
-  (void)hipFree(F->wflags);
   free_schedule(F->L);
   free_schedule(F->U);
   delete F;
@@ -796,363 +741,8 @@ static int build_xcd_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
     DDMCHECK(upload(ctx, lpos.data(), (int64_t)lpos.size(), &F->xlpos));
   }
   HIPCHECK(ctx, hipMalloc((void **)&F->xdperm, sizeof(double) * (size_t)std::max<int64_t>(F->xnrows, 1)));
-  HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_xcd2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TrsvLds)));
-  HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_xcd2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TrsvLds)));
+  HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_xcd2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TrsvLds)));
   F->xcd_built = true;
-  return DDM_OK;
-}
-
-// Level-permuted schedule with dependency windows (engine "xcdw").  Position space: for every block its
-// L-level-sorted rows, then its U-level-sorted rows (2 n positions).  Per 64-row chunk the dependency
-// positions are merged into runs (gap <= 8), cut into pieces of <= 64; chunks that need more than
-// TRSV_W_MAXPIECE pieces fall back to direct gathers.  Blocks are processed by separate host threads.
-static int build_xcdw_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
-{
-  const ddm_csr *A = F->A;
-  const int64_t *rp = A->h_rp.data();
-  const int32_t *ci = A->h_ci.data();
-  const std::vector<double> &lu = F->h_lu;
-  const std::vector<int64_t> &diag = F->h_diag;
-  const int nb = (int)F->h_block_ptr.size() - 1;
-  const int64_t n = A->nrows;
-  (void)n;
-  struct Block {
-    std::vector<WLevel> lev;
-    std::vector<WChunk> chunk;
-    std::vector<int32_t> rows, idx, own;
-    std::vector<double> vals, dinv;
-    int nlevL = 0, nlevU = 0;
-    int64_t direct = 0;
-  };
-  std::vector<Block> blocks(nb);
-  std::vector<int64_t> pos_base(nb + 1, 0);
-  for (int b = 0; b < nb; ++b) pos_base[b + 1] = pos_base[b] + 2 * (F->h_block_ptr[b + 1] - F->h_block_ptr[b]);
-  auto work = [&](int b) {
-    Block &B = blocks[b];
-    const int64_t r0 = F->h_block_ptr[b], r1 = F->h_block_ptr[b + 1], nbk = r1 - r0;
-    std::vector<int32_t> level(nbk);
-    std::vector<int64_t> posL(nbk), posU(nbk);
-    B.rows.resize(2 * nbk);
-    B.dinv.assign(2 * nbk, 0.0);
-    B.own.assign(2 * nbk, 0);
-    for (int pass = 0; pass < 2; ++pass) {
-      const bool upper = pass == 1;
-      int32_t maxlev = -1;
-      if (!upper)
-        for (int64_t i = r0; i < r1; ++i) {
-          int32_t l = 0;
-          for (int64_t k = rp[i]; k < diag[i]; ++k) l = std::max(l, level[ci[k] - r0] + 1);
-          level[i - r0] = l;
-          maxlev = std::max(maxlev, l);
-        }
-      else
-        for (int64_t i = r1 - 1; i >= r0; --i) {
-          int32_t l = 0;
-          for (int64_t k = diag[i] + 1; k < rp[i + 1]; ++k) l = std::max(l, level[ci[k] - r0] + 1);
-          level[i - r0] = l;
-          maxlev = std::max(maxlev, l);
-        }
-      const int64_t nlev = (int64_t)maxlev + 1;
-      (upper ? B.nlevU : B.nlevL) = (int)nlev;
-      std::vector<int64_t> lptr(nlev + 1, 0);
-      for (int64_t i = 0; i < nbk; ++i) lptr[level[i] + 1]++;
-      for (int64_t l = 0; l < nlev; ++l) lptr[l + 1] += lptr[l];
-      const int64_t pbase = pos_base[b] + (upper ? nbk : 0); // absolute position of the first row of this pass
-      std::vector<int64_t> &pos = upper ? posU : posL;
-      {
-        std::vector<int64_t> fill(lptr.begin(), lptr.end() - 1);
-        for (int64_t i = 0; i < nbk; ++i) {
-          const int64_t p = fill[level[i]]++;
-          pos[i] = pbase + p;
-          B.rows[(upper ? nbk : 0) + p] = (int32_t)(r0 + i);
-        }
-      }
-      for (int64_t l = 0; l < nlev; ++l) {
-        const int64_t m = lptr[l + 1] - lptr[l];
-        int w = 0;
-        for (int64_t r = 0; r < m; ++r) {
-          const int64_t i = B.rows[(upper ? nbk : 0) + lptr[l] + r];
-          w = std::max(w, upper ? (int)(rp[i + 1] - diag[i] - 1) : (int)(diag[i] - rp[i]));
-        }
-        const int64_t ent = (int64_t)B.idx.size();
-        B.lev.push_back(WLevel{(int32_t)m, (int32_t)w, pbase + lptr[l], ent, (int64_t)B.chunk.size()});
-        B.idx.resize(ent + m * (int64_t)w);
-        B.vals.resize(ent + m * (int64_t)w);
-        std::vector<int64_t> dep;
-        for (int64_t c0 = 0; c0 < m; c0 += 64) {
-          const int64_t c1 = std::min<int64_t>(c0 + 64, m);
-          // dependency positions of the chunk
-          dep.clear();
-          for (int64_t r = c0; r < c1; ++r) {
-            const int64_t i = B.rows[(upper ? nbk : 0) + lptr[l] + r];
-            const int64_t k0 = upper ? diag[i] + 1 : rp[i], k1 = upper ? rp[i + 1] : diag[i];
-            for (int64_t p = k0; p < k1; ++p) dep.push_back(pos[ci[p] - r0]);
-          }
-          std::sort(dep.begin(), dep.end());
-          dep.erase(std::unique(dep.begin(), dep.end()), dep.end());
-          WChunk ch;
-          std::memset(&ch, 0, sizeof ch);
-          // runs with gaps <= 8, cut into pieces of <= 64 positions
-          std::vector<std::pair<int64_t, int64_t>> pieces; // (lo, len)
-          bool fits = true;
-          for (size_t a = 0; a < dep.size();) {
-            size_t e = a;
-            while (e + 1 < dep.size() && dep[e + 1] - dep[e] <= 8) ++e;
-            for (int64_t lo = dep[a]; lo <= dep[e]; lo += 64) pieces.emplace_back(lo, std::min<int64_t>(64, dep[e] - lo + 1));
-            a = e + 1;
-            if ((int)pieces.size() > TRSV_W_MAXPIECE) {
-              fits = false;
-              break;
-            }
-          }
-          if (fits && !pieces.empty()) {
-            int off = 0;
-            ch.npiece = (int32_t)pieces.size();
-            for (size_t q = 0; q < pieces.size(); ++q) {
-              ch.lo[q] = (int32_t)pieces[q].first;
-              ch.len[q] = (uint8_t)pieces[q].second;
-              ch.off[q] = (uint16_t)off;
-              off += (int)pieces[q].second;
-            }
-            ch.staged = off;
-          } else if (!pieces.empty() || !fits) {
-            ch.npiece = 0;
-            B.direct += 1;
-          }
-          // entries: staging index (or position)
-          for (int64_t r = c0; r < c1; ++r) {
-            const int64_t i = B.rows[(upper ? nbk : 0) + lptr[l] + r];
-            const int64_t k0 = upper ? diag[i] + 1 : rp[i], k1 = upper ? rp[i + 1] : diag[i];
-            int k = 0;
-            int32_t first = 0;
-            const int32_t first_pos = k1 > k0 ? (int32_t)pos[ci[k0] - r0] : 0;
-            for (int64_t p = k0; p < k1; ++p, ++k) {
-              const int64_t dp = pos[ci[p] - r0];
-              int32_t code = (int32_t)dp;
-              if (ch.npiece > 0 && k < TRSV_UNROLL) { // entries beyond the first tile are gathered by position
-                int q = (int)(std::upper_bound(pieces.begin(), pieces.end(), std::make_pair(dp, (int64_t)INT64_MAX)) - pieces.begin()) - 1;
-                code = (int32_t)(ch.off[q] + (dp - pieces[q].first));
-              }
-              if (k == 0) first = code;
-              B.idx[ent + (int64_t)k * m + r] = code;
-              B.vals[ent + (int64_t)k * m + r] = lu[p];
-            }
-            for (; k < w; ++k) {
-              B.idx[ent + (int64_t)k * m + r] = k < TRSV_UNROLL ? first : first_pos;
-              B.vals[ent + (int64_t)k * m + r] = 0.0;
-            }
-            if (upper) {
-              B.dinv[nbk + lptr[l] + r] = lu[diag[i]];
-              B.own[nbk + lptr[l] + r] = (int32_t)posL[i - r0];
-            }
-          }
-          B.chunk.push_back(ch);
-        }
-      }
-    }
-  };
-  {
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const int nthreads = (int)std::min<int64_t>(nb, hw);
-    std::vector<std::thread> th;
-    for (int t = 0; t < nthreads; ++t)
-      th.emplace_back([&, t]() {
-        for (int b = t; b < nb; b += nthreads) work(b);
-      });
-    for (auto &t : th) t.join();
-  }
-  if (pos_base[nb] >= ((int64_t)1 << 31)) { // positions are stored as int32
-    F->w_state = -1;
-    return DDM_OK;
-  }
-  // concatenate the blocks
-  std::vector<GroupDesc> groups(nb);
-  std::vector<WLevel> lev;
-  std::vector<WChunk> chunk;
-  std::vector<int64_t> flag_off(nb), lpos, upos;
-  std::vector<int32_t> rows, idx, own;
-  std::vector<double> vals, dinv;
-  int64_t nflag = 0, ndirect = 0;
-  for (int b = 0; b < nb; ++b) {
-    Block &B = blocks[b];
-    const int64_t nbk = F->h_block_ptr[b + 1] - F->h_block_ptr[b];
-    groups[b] = GroupDesc{B.nlevL, B.nlevU, (int64_t)lev.size()};
-    flag_off[b] = nflag;
-    nflag += (int64_t)(B.nlevL + B.nlevU) * TRSV_X_MAXW;
-    const int64_t ent0 = (int64_t)idx.size(), ch0 = (int64_t)chunk.size();
-    for (auto L : B.lev) {
-      L.ent_off += ent0;
-      L.chunk_off += ch0;
-      lev.push_back(L);
-    }
-    chunk.insert(chunk.end(), B.chunk.begin(), B.chunk.end());
-    rows.insert(rows.end(), B.rows.begin(), B.rows.end());
-    idx.insert(idx.end(), B.idx.begin(), B.idx.end());
-    own.insert(own.end(), B.own.begin(), B.own.end());
-    vals.insert(vals.end(), B.vals.begin(), B.vals.end());
-    dinv.insert(dinv.end(), B.dinv.begin(), B.dinv.end());
-    for (int64_t p = 0; p < nbk; ++p) {
-      lpos.push_back(pos_base[b] + p);
-      upos.push_back(pos_base[b] + nbk + p);
-    }
-    ndirect += B.direct;
-    B = Block();
-  }
-  F->w_direct_frac = chunk.empty() ? 0.0 : (double)ndirect / (double)chunk.size();
-  F->ngroups = nb;
-  F->wnpos = pos_base[nb];
-  DDMCHECK(upload(ctx, groups.data(), (int64_t)groups.size(), &F->wg));
-  DDMCHECK(upload(ctx, lev.data(), (int64_t)lev.size(), &F->wlev));
-  DDMCHECK(upload(ctx, chunk.data(), (int64_t)chunk.size(), &F->wchunk));
-  DDMCHECK(upload(ctx, flag_off.data(), (int64_t)flag_off.size(), &F->wflag_off));
-  DDMCHECK(upload(ctx, lpos.data(), (int64_t)lpos.size(), &F->wlpos));
-  DDMCHECK(upload(ctx, upos.data(), (int64_t)upos.size(), &F->wupos));
-  DDMCHECK(upload(ctx, rows.data(), (int64_t)rows.size(), &F->wrows));
-  DDMCHECK(upload(ctx, idx.data(), (int64_t)idx.size(), &F->widx));
-  DDMCHECK(upload(ctx, own.data(), (int64_t)own.size(), &F->wown));
-  DDMCHECK(upload(ctx, vals.data(), (int64_t)vals.size(), &F->wvals));
-  DDMCHECK(upload(ctx, dinv.data(), (int64_t)dinv.size(), &F->wdinv));
-  HIPCHECK(ctx, hipMalloc((void **)&F->wdperm, sizeof(double) * (size_t)std::max<int64_t>(F->wnpos, 1)));
-  HIPCHECK(ctx, hipMalloc((void **)&F->wxp, sizeof(double) * (size_t)std::max<int64_t>(F->wnpos, 1)));
-  HIPCHECK(ctx, hipMemset(F->wxp, 0, sizeof(double) * (size_t)std::max<int64_t>(F->wnpos, 1)));
-  HIPCHECK(ctx, hipMalloc((void **)&F->wflags, sizeof(unsigned) * (size_t)std::max<int64_t>(nflag, 1)));
-  HIPCHECK(ctx, hipMemset(F->wflags, 0, sizeof(unsigned) * (size_t)std::max<int64_t>(nflag, 1)));
-  if (!F->xstate) {
-    HIPCHECK(ctx, hipMalloc((void **)&F->xstate, sizeof(XcdState)));
-    HIPCHECK(ctx, hipMemset(F->xstate, 0, sizeof(XcdState)));
-  }
-  HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_xcdw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WLds)));
-  F->w_state = 1;
-  return DDM_OK;
-}
-
-// Slab-ownership schedule (engine "slab"): every block is cut into SLAB_W contiguous row ranges; for each
-// range and sweep the rows are sorted by dependency level and stored step by step (one step = the rows of
-// one level inside one slab) in sliced ELL with natural row indices as columns.
-static int build_slab_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
-{
-  const ddm_csr *A = F->A;
-  const int64_t *rp = A->h_rp.data();
-  const int32_t *ci = A->h_ci.data();
-  const std::vector<double> &lu = F->h_lu;
-  const std::vector<int64_t> &diag = F->h_diag;
-  const int nb = (int)F->h_block_ptr.size() - 1;
-  std::vector<SlabGroup> groups(nb);
-  std::vector<int64_t> wave_ptr, lpos;
-  std::vector<SlabStep> steps;
-  std::vector<int32_t> rows, cols;
-  std::vector<double> vals, dinv;
-  rows.reserve(2 * (size_t)A->nrows);
-  cols.reserve((size_t)A->nnz);
-  vals.reserve((size_t)A->nnz);
-  std::vector<int32_t> level(A->nrows);
-  int64_t nprog = 0;
-  for (int b = 0; b < nb; ++b) {
-    const int64_t r0 = F->h_block_ptr[b], r1 = F->h_block_ptr[b + 1], nbk = r1 - r0;
-    // slab size = the reach of the dependencies in natural order (lower / upper bandwidth): a row then depends only on
-    // its own and the adjacent slab; slabs are dealt round-robin to the SLAB_W waves, so that the rows of one
-    // dependency level are spread over all waves
-    int64_t bw = 64;
-    for (int64_t i = r0; i < r1; ++i) {
-      if (diag[i] > rp[i]) bw = std::max<int64_t>(bw, i - ci[rp[i]]);
-      if (rp[i + 1] - 1 > diag[i]) bw = std::max<int64_t>(bw, ci[rp[i + 1] - 1] - i);
-    }
-    const int64_t slab = std::min<int64_t>(std::max<int64_t>((nbk + SLAB_W - 1) / SLAB_W / 8, std::min(bw, (nbk + SLAB_W - 1) / SLAB_W)), nbk);
-    auto owner = [&](int64_t i) { return (int)(((i - r0) / slab) % SLAB_W); };
-    groups[b].step_ptr = (int64_t)wave_ptr.size();
-    groups[b].prog_off = nprog;
-    nprog += 2 * SLAB_W * 32;
-    for (int sweep = 0; sweep < 2; ++sweep) {
-      const bool upper = sweep == 1;
-      int32_t maxlev = -1;
-      if (!upper)
-        for (int64_t i = r0; i < r1; ++i) {
-          int32_t l = 0;
-          for (int64_t k = rp[i]; k < diag[i]; ++k) l = std::max(l, level[ci[k]] + 1);
-          level[i] = l;
-          maxlev = std::max(maxlev, l);
-        }
-      else
-        for (int64_t i = r1 - 1; i >= r0; --i) {
-          int32_t l = 0;
-          for (int64_t k = diag[i] + 1; k < rp[i + 1]; ++k) l = std::max(l, level[ci[k]] + 1);
-          level[i] = l;
-          maxlev = std::max(maxlev, l);
-        }
-      const int32_t nlev = maxlev + 1;
-      (upper ? groups[b].nlevU : groups[b].nlevL) = nlev;
-      for (int k = 0; k < SLAB_W; ++k) {
-        wave_ptr.push_back((int64_t)steps.size());
-        std::vector<int32_t> order;
-        for (int64_t a = r0 + k * slab; a < r1; a += (int64_t)SLAB_W * slab)
-          for (int64_t i = a; i < std::min(a + slab, r1); ++i) order.push_back((int32_t)i);
-        if (order.empty()) continue;
-        std::stable_sort(order.begin(), order.end(), [&](int32_t p, int32_t q) { return level[p] < level[q]; });
-        size_t first_step = steps.size();
-        for (size_t q0 = 0; q0 < order.size();) {
-          size_t q1 = q0;
-          while (q1 < order.size() && level[order[q1]] == level[order[q0]]) ++q1;
-          const int64_t m = (int64_t)(q1 - q0);
-          int w = 0;
-          for (size_t q = q0; q < q1; ++q) {
-            const int64_t i = order[q];
-            w = std::max(w, upper ? (int)(rp[i + 1] - diag[i] - 1) : (int)(diag[i] - rp[i]));
-          }
-          const int64_t pos = (int64_t)rows.size(), ent = (int64_t)cols.size();
-          uint32_t mask = 0;
-          for (size_t q = q0; q < q1; ++q) {
-            const int64_t i = order[q];
-            const int64_t k0 = upper ? diag[i] + 1 : rp[i], k1 = upper ? rp[i + 1] : diag[i];
-            for (int64_t p = k0; p < k1; ++p) {
-              const int ow = owner(ci[p]);
-              if (ow != k) mask |= 1u << ow;
-            }
-          }
-          steps.push_back(SlabStep{level[order[q0]], (int32_t)m, (int32_t)w, nlev, pos, ent, mask, 0u});
-          cols.resize(ent + m * (int64_t)w);
-          vals.resize(ent + m * (int64_t)w);
-          for (size_t q = q0; q < q1; ++q) {
-            const int64_t i = order[q], r = (int64_t)(q - q0);
-            rows.push_back((int32_t)i);
-            dinv.push_back(upper ? lu[diag[i]] : 0.0);
-            if (!upper) lpos.push_back(pos + r);
-            const int64_t k0 = upper ? diag[i] + 1 : rp[i], k1 = upper ? rp[i + 1] : diag[i];
-            int k = 0;
-            for (int64_t p = k0; p < k1; ++p, ++k) {
-              cols[ent + (int64_t)k * m + r] = ci[p];
-              vals[ent + (int64_t)k * m + r] = lu[p];
-            }
-            for (; k < w; ++k) {
-              cols[ent + (int64_t)k * m + r] = ci[k0];
-              vals[ent + (int64_t)k * m + r] = 0.0;
-            }
-          }
-          q0 = q1;
-        }
-        for (size_t si = first_step; si + 1 < steps.size(); ++si) steps[si].next_level = steps[si + 1].level;
-      }
-      wave_ptr.push_back((int64_t)steps.size());
-    }
-  }
-  F->ngroups = nb;
-  F->s_npos = (int64_t)rows.size();
-  DDMCHECK(upload(ctx, groups.data(), (int64_t)groups.size(), &F->sg));
-  DDMCHECK(upload(ctx, wave_ptr.data(), (int64_t)wave_ptr.size(), &F->s_wave_ptr));
-  DDMCHECK(upload(ctx, lpos.data(), (int64_t)lpos.size(), &F->s_lpos));
-  DDMCHECK(upload(ctx, steps.data(), (int64_t)steps.size(), &F->s_steps));
-  DDMCHECK(upload(ctx, rows.data(), (int64_t)rows.size(), &F->s_rows));
-  DDMCHECK(upload(ctx, cols.data(), (int64_t)cols.size(), &F->s_cols));
-  DDMCHECK(upload(ctx, vals.data(), (int64_t)vals.size(), &F->s_vals));
-  DDMCHECK(upload(ctx, dinv.data(), (int64_t)dinv.size(), &F->s_dinv));
-  HIPCHECK(ctx, hipMalloc((void **)&F->s_dperm, sizeof(double) * (size_t)std::max<int64_t>(F->s_npos, 1)));
-  HIPCHECK(ctx, hipMalloc((void **)&F->s_progress, sizeof(unsigned) * (size_t)std::max<int64_t>(nprog, 1)));
-  HIPCHECK(ctx, hipMemset(F->s_progress, 0, sizeof(unsigned) * (size_t)std::max<int64_t>(nprog, 1)));
-  if (!F->xstate) {
-    HIPCHECK(ctx, hipMalloc((void **)&F->xstate, sizeof(XcdState)));
-    HIPCHECK(ctx, hipMemset(F->xstate, 0, sizeof(XcdState)));
-  }
-  HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_slab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TrsvLds)));
-  F->slab_built = true;
   return DDM_OK;
 }
 
@@ -1281,23 +871,11 @@ extern "C" int ddm_ilu0_debug_stamps(ddm_ctx *ctx, ddm_ilu0 *F, const double *d,
   unsigned long long *st = nullptr;
   HIPCHECK(ctx, hipMalloc((void **)&st, 64));
   HIPCHECK(ctx, hipMemset(st, 0, 64));
-  if (F->mode == 6) {
-    if (F->w_state == 0) DDMCHECK(build_xcdw_schedule(ctx, F));
-    const int64_t nn = F->n;
-    hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
-    hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(nn)), dim3(WG), 0, ctx->stream, nn, F->wlpos, F->wrows, d, F->wdperm);
-    hipLaunchKernelGGL(k_trsv_xcdw, dim3(persistent_grid(ctx)), dim3(128), sizeof(WLds), ctx->stream, F->ngroups, F->wg, F->wlev, F->wchunk, F->wflag_off,
-                       F->widx, F->wvals, F->wdinv, F->wown, F->wdperm, F->wxp, F->wflags, F->xstate, F->err, st);
-    hipLaunchKernelGGL(k_w_permute_out, dim3(grid_for(nn)), dim3(WG), 0, ctx->stream, nn, F->wupos, F->wrows, F->wxp, x);
-    int rc6 = ddm_memcpy_d2h(ctx, out_host, st, 56);
-    (void)hipFree(st);
-    return rc6;
-  }
   if (!F->xcd_built) DDMCHECK(build_xcd_schedule(ctx, F));
   hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
   hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, F->xlpos, F->xrows, d, F->xdperm);
-  hipLaunchKernelGGL(k_trsv_xcd2<false>, dim3(persistent_grid(ctx)), dim3(64 * (1 + TRSV_L_LOADERS)), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off, F->xrows,
-                     F->xcols, F->xvals, F->xdinv, F->xdperm, x, F->ywork, F->xflags, F->xstate, F->err, st);
+  hipLaunchKernelGGL(k_trsv_xcd2, dim3(persistent_grid(ctx)), dim3(64 * (1 + TRSV_L_LOADERS)), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off, F->xrows,
+                     F->xcols, F->xvals, F->xdinv, F->xdperm, x, F->xflags, F->xstate, F->err, st);
   int rc = ddm_memcpy_d2h(ctx, out_host, st, 48);
   (void)hipFree(st);
   return rc;
@@ -1348,53 +926,17 @@ extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double
   }
   if (F->mode == 8 && F->pipe_state == 0) DDMCHECK(build_pipe_schedule(ctx, F));
   if (F->mode == 8 && F->pipe_state < 0) F->mode = 4; // not applicable: the loader engine takes any matrix
-  if (F->mode == 7 && !F->slab_built) DDMCHECK(build_slab_schedule(ctx, F));
-  if (F->mode == 6 && F->w_state == 0) DDMCHECK(build_xcdw_schedule(ctx, F));
-  if (F->mode == 6 && F->w_state < 0) F->mode = 3; // rows wider than a tile: use the gather-based XCD engine
-  if (F->mode >= 3 && F->mode <= 5 && !F->xcd_built) DDMCHECK(build_xcd_schedule(ctx, F));
+  if (F->mode == 4 && !F->xcd_built) DDMCHECK(build_xcd_schedule(ctx, F));
   hipGraph_t g = nullptr;
   HIPCHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
   int rc = DDM_OK;
   if (F->mode == 8) {
     enqueue_pipe(ctx, F, d, x, nullptr);
-  } else if (F->mode == 7) {
-    hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
-    hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, F->s_lpos, F->s_rows, d, F->s_dperm);
-    hipLaunchKernelGGL(k_trsv_slab, dim3(persistent_grid(ctx)), dim3(128), sizeof(TrsvLds), ctx->stream, F->ngroups, F->sg, F->s_wave_ptr, F->s_steps,
-                       F->s_rows, F->s_cols, F->s_vals, F->s_dinv, F->s_dperm, F->ywork, x, F->s_progress, F->xstate, F->err);
-  } else if (F->mode == 6) {
-    const int64_t nn = F->n;
-    hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
-    hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(nn)), dim3(WG), 0, ctx->stream, nn, F->wlpos, F->wrows, d, F->wdperm);
-    hipLaunchKernelGGL(k_trsv_xcdw, dim3(persistent_grid(ctx)), dim3(128), sizeof(WLds), ctx->stream, F->ngroups, F->wg, F->wlev, F->wchunk, F->wflag_off,
-                       F->widx, F->wvals, F->wdinv, F->wown, F->wdperm, F->wxp, F->wflags, F->xstate, F->err, (unsigned long long *)nullptr);
-    hipLaunchKernelGGL(k_w_permute_out, dim3(grid_for(nn)), dim3(WG), 0, ctx->stream, nn, F->wupos, F->wrows, F->wxp, x);
-  } else if (F->mode == 5) {
-    hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
-    (void)hipMemsetAsync(F->ywork, 0xFF, sizeof(double) * (size_t)F->n, ctx->stream); // sentinel = "not computed yet"
-    (void)hipMemsetAsync(x, 0xFF, sizeof(double) * (size_t)F->n, ctx->stream);
-    hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, F->xlpos, F->xrows, d, F->xdperm);
-    hipLaunchKernelGGL(k_trsv_xcd2<true>, dim3(persistent_grid(ctx)), dim3(64 * (1 + TRSV_L_LOADERS)), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off,
-                       F->xrows, F->xcols, F->xvals, F->xdinv, F->xdperm, x, F->ywork, F->xflags, F->xstate, F->err, (unsigned long long *)nullptr);
   } else if (F->mode == 4) {
     hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
     hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, F->xlpos, F->xrows, d, F->xdperm);
-    hipLaunchKernelGGL(k_trsv_xcd2<false>, dim3(persistent_grid(ctx)), dim3(64 * (1 + TRSV_L_LOADERS)), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off,
-                       F->xrows, F->xcols, F->xvals, F->xdinv, F->xdperm, x, F->ywork, F->xflags, F->xstate, F->err, (unsigned long long *)nullptr);
-  } else if (F->mode == 3) {
-    hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
-    hipLaunchKernelGGL(k_trsv_xcd, dim3(persistent_grid(ctx)), dim3(64), 0, ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off, F->xrows, F->xcols,
-                       F->xvals, F->xdinv, d, x, F->xflags, F->xstate, F->err);
-  } else if (F->mode == 2) {
-    // poison both result vectors (all-ones = "not computed yet"), then one data-driven launch
-    (void)hipMemsetAsync(F->ywork, 0xFF, sizeof(double) * (size_t)F->n, ctx->stream);
-    (void)hipMemsetAsync(x, 0xFF, sizeof(double) * (size_t)F->n, ctx->stream);
-    hipLaunchKernelGGL(k_trsv_syncfree, dim3(persistent_grid(ctx)), dim3(64), 0, ctx->stream, (int)F->L.nlev, (int)F->U.nlev, F->L.d_desc, F->U.d_desc,
-                       F->L.rows, F->L.cols, F->L.vals, F->U.rows, F->U.cols, F->U.vals, F->U.dinv, d, F->ywork, x, F->err);
-  } else if (F->mode == 1) {
-    (void)hipMemsetAsync(F->cnt, 0, F->cnt_bytes, ctx->stream); // counters are re-initialised by every replay
-    hipLaunchKernelGGL(k_trsv_persistent, dim3(persistent_grid(ctx)), dim3(64), 0, ctx->stream, (int)F->L.nlev, (int)F->U.nlev, F->L.d_desc, F->U.d_desc,
-                       F->L.rows, F->L.cols, F->L.vals, F->U.rows, F->U.cols, F->U.vals, F->U.dinv, d, x, F->cnt, F->err);
+    hipLaunchKernelGGL(k_trsv_xcd2, dim3(persistent_grid(ctx)), dim3(64 * (1 + TRSV_L_LOADERS)), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off,
+                       F->xrows, F->xcols, F->xvals, F->xdinv, F->xdperm, x, F->xflags, F->xstate, F->err, (unsigned long long *)nullptr);
   } else {
     rc = enqueue_tri(ctx, F->L, false, d, x);
     if (!rc) rc = enqueue_tri(ctx, F->U, true, d, x);

@@ -247,22 +247,8 @@ __global__ __launch_bounds__(TRSV_SMALL_WG) void k_trsv_small_levels(int nlev, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// Persistent level-synchronous triangular solve: the whole x = (LU)^-1 d in ONE launch.
-// Grid = TRSV_P_GRID single-wave workgroups, all co-resident.  Chunk c (64 rows) of a level is
-// owned by wave c mod G; waves walk the levels in order.  Before touching a level a wave waits
-// until the previous level is complete, which it learns from per-level arrival counters
-// (TRSV_P_SHARDS shards on separate 128-B lines: arrivals spread over memory channels, one poll
-// instruction reads all shards, one per lane).  Hand-off protocol = cdna_hip_programming.md
-// Guideline 16, "row 1" form of MI355X_MICROARCH.md: every x value is stored write-through
-// (sc1), the storing wave drains its stores (s_waitcnt vmcnt(0)), ONE lane adds to the counter
-// (agent-scope atomic); consumers poll with sc1 loads and read x ONLY with sc1 loads (bypass the
-// non-coherent L1; no acquire fence needed).  Correct for any wave -> CU/XCD placement.
-// Factor entries / d are read-only in this launch and use plain loads; the entries of a wave's
-// next chunk are fetched BEFORE it starts waiting, so only the x gathers sit on the critical path.
-constexpr int TRSV_P_GRID = 256;
-constexpr int TRSV_P_SHARDS = 16;
-constexpr int TRSV_P_STRIDE = 32; // uint32 per shard = one 128-B line
-
+// Coherent accesses for hand-overs between waves inside one launch (cdna_hip_programming.md Guideline 16):
+// sc1 loads bypass the non-coherent L1, sc1 stores are written through.
 __device__ __forceinline__ double ld_sc1(const double *p)
 {
   return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -272,213 +258,16 @@ __device__ __forceinline__ void st_sc1(double *p, double v)
   __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// returns false on timeout (err word set) -- every wave still runs to completion
-__device__ __forceinline__ bool trsv_wait_level(const unsigned *cnt_level, int nchunk_prev, int lane, unsigned *err)
-{
-  const unsigned expect = (unsigned)(nchunk_prev / TRSV_P_SHARDS) + (lane < nchunk_prev % TRSV_P_SHARDS ? 1u : 0u);
-  const bool need = lane < TRSV_P_SHARDS;
-  for (unsigned spins = 0;; ++spins) {
-    const unsigned v = need ? __hip_atomic_load(cnt_level + lane * TRSV_P_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : expect;
-    if (__all(v == expect)) break;
-    if (spins > (1u << 21)) {
-      if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return false;
-    }
-    __builtin_amdgcn_s_sleep(1);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // compiler-only: keep the x loads below the poll
-  return true;
-}
-
-__global__ __launch_bounds__(64) void k_trsv_persistent(int nlevL, int nlevU, const LevelDesc *__restrict__ descL,
-                                                         const LevelDesc *__restrict__ descU, const int32_t *__restrict__ rowsL,
-                                                         const int32_t *__restrict__ colsL, const double *__restrict__ valsL,
-                                                         const int32_t *__restrict__ rowsU, const int32_t *__restrict__ colsU,
-                                                         const double *__restrict__ valsU, const double *__restrict__ dinv,
-                                                         const double *__restrict__ d, double *x, unsigned *cnt, unsigned *err)
-{
-  const int g = blockIdx.x, G = gridDim.x, lane = threadIdx.x;
-  const int nlev = nlevL + nlevU;
-  int nchunk_prev = 0;
-  for (int lev = 0; lev < nlev; ++lev) {
-    const bool upper = lev >= nlevL;
-    const LevelDesc D = upper ? descU[lev - nlevL] : descL[lev];
-    const int nchunk = (D.m + 63) >> 6;
-    if (g >= nchunk) {
-      nchunk_prev = nchunk;
-      continue; // no work for this wave in this level: no waiting either
-    }
-    const int32_t *rows = (upper ? rowsU : rowsL) + D.row_off;
-    const int32_t *cols = (upper ? colsU : colsL) + D.ent_off;
-    const double *vals = (upper ? valsU : valsL) + D.ent_off;
-    int mine = 0;
-    bool waited = lev == 0;
-    for (int c = g; c < nchunk; c += G, ++mine) {
-      const int r = (c << 6) + lane;
-      const bool act = r < D.m;
-      const int rr = act ? r : D.m - 1; // idle lanes of the last chunk shadow the last row (no store): uniform control flow
-      // ---- independent of x: fetch the row id, the right-hand side and the first tile of entries
-      const int row = rows[rr];
-      int32_t cc[TRSV_UNROLL];
-      double vv[TRSV_UNROLL], xv[TRSV_UNROLL];
-#pragma unroll
-      for (int u = 0; u < TRSV_UNROLL; ++u) {
-        cc[u] = 0;
-        vv[u] = 0.0;
-        if (u < D.w) { // wave-uniform
-          cc[u] = cols[(int64_t)u * D.m + rr];
-          vv[u] = vals[(int64_t)u * D.m + rr];
-        }
-      }
-      double s = upper ? 0.0 : d[row];
-      const double di = upper ? dinv[D.row_off + rr] : 0.0;
-      // ---- now the dependencies: the previous level must be complete
-      if (!waited) {
-        trsv_wait_level(cnt + (int64_t)(lev - 1) * TRSV_P_SHARDS * TRSV_P_STRIDE, nchunk_prev, lane, err);
-        waited = true;
-      }
-#pragma unroll
-      for (int u = 0; u < TRSV_UNROLL; ++u) {
-        xv[u] = 0.0;
-        if (u < D.w) xv[u] = ld_sc1(x + cc[u]);
-      }
-      if (upper) s = ld_sc1(x + row);
-#pragma unroll
-      for (int u = 0; u < TRSV_UNROLL; ++u) s -= vv[u] * xv[u];
-      for (int k0 = TRSV_UNROLL; k0 < D.w; k0 += TRSV_UNROLL) { // rows wider than one tile (rare)
-#pragma unroll
-        for (int u = 0; u < TRSV_UNROLL; ++u) {
-          cc[u] = 0;
-          vv[u] = 0.0;
-          xv[u] = 0.0;
-          if (k0 + u < D.w) {
-            cc[u] = cols[(int64_t)(k0 + u) * D.m + rr];
-            vv[u] = vals[(int64_t)(k0 + u) * D.m + rr];
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < TRSV_UNROLL; ++u)
-          if (k0 + u < D.w) xv[u] = ld_sc1(x + cc[u]);
-#pragma unroll
-        for (int u = 0; u < TRSV_UNROLL; ++u) s -= vv[u] * xv[u];
-      }
-      if (act) st_sc1(x + row, upper ? s * di : s);
-    }
-    // ---- publish: drain this wave's write-through stores, then ONE lane signals for the wave
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0)
-      __hip_atomic_fetch_add(cnt + ((int64_t)lev * TRSV_P_SHARDS + (g % TRSV_P_SHARDS)) * TRSV_P_STRIDE, (unsigned)mine, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-    nchunk_prev = nchunk;
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
-// Data-driven ("sync-free") variant of the persistent solve: no counters and no level barrier.
-// y (forward result) and x (final result) are pre-filled with an all-ones NaN pattern before
-// every solve (memset nodes in the graph); a row polls ITS OWN dependencies with sc1 loads until
-// none of them is the sentinel, computes, and publishes its value with ONE aligned 8-byte sc1
-// store -- the datum is its own flag (Guideline 16, R2: a granule written by one store is never
-// torn).  A hop on the critical path is then a single write-through store -> sc1 load, instead of
-// store + drain + counter add + counter poll + gather.  Waves own the 64-row chunks of the
-// level-sorted row list round-robin and walk them in level order, so every dependency is owned by
-// a chunk that its wave reaches without waiting on a later level: no deadlock while all
-// TRSV_P_GRID waves are resident.  A computed NaN is the canonical quiet NaN, never all-ones.
-constexpr unsigned long long TRSV_SENTINEL = ~0ull;
-
-__device__ __forceinline__ unsigned long long ld_sc1_bits(const double *p)
-{
-  return __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__global__ __launch_bounds__(64) void k_trsv_syncfree(int nlevL, int nlevU, const LevelDesc *__restrict__ descL,
-                                                       const LevelDesc *__restrict__ descU, const int32_t *__restrict__ rowsL,
-                                                       const int32_t *__restrict__ colsL, const double *__restrict__ valsL,
-                                                       const int32_t *__restrict__ rowsU, const int32_t *__restrict__ colsU,
-                                                       const double *__restrict__ valsU, const double *__restrict__ dinv,
-                                                       const double *__restrict__ d, double *y, double *x, unsigned *err)
-{
-  const int g = blockIdx.x, G = gridDim.x, lane = threadIdx.x;
-  const int nlev = nlevL + nlevU;
-  for (int lev = 0; lev < nlev; ++lev) {
-    const bool upper = lev >= nlevL;
-    const LevelDesc D = upper ? descU[lev - nlevL] : descL[lev];
-    const int nchunk = (D.m + 63) >> 6;
-    if (g >= nchunk) continue;
-    const int32_t *rows = (upper ? rowsU : rowsL) + D.row_off;
-    const int32_t *cols = (upper ? colsU : colsL) + D.ent_off;
-    const double *vals = (upper ? valsU : valsL) + D.ent_off;
-    const double *src = upper ? x : y; // where this phase's dependencies are published
-    double *dst = upper ? x : y;
-    for (int c = g; c < nchunk; c += G) {
-      const int r = (c << 6) + lane;
-      const bool act = r < D.m;
-      const int rr = act ? r : D.m - 1;
-      const int row = rows[rr];
-      double s = upper ? 0.0 : d[row];
-      const double di = upper ? dinv[D.row_off + rr] : 0.0;
-      bool have_own = !upper;
-      for (int k0 = 0; k0 < D.w || !have_own; k0 += TRSV_UNROLL) {
-        int32_t cc[TRSV_UNROLL];
-        double vv[TRSV_UNROLL];
-        unsigned long long xb[TRSV_UNROLL];
-#pragma unroll
-        for (int u = 0; u < TRSV_UNROLL; ++u) {
-          cc[u] = 0;
-          vv[u] = 0.0;
-          xb[u] = 0ull;
-          if (k0 + u < D.w) { // wave-uniform
-            cc[u] = cols[(int64_t)(k0 + u) * D.m + rr];
-            vv[u] = vals[(int64_t)(k0 + u) * D.m + rr];
-          }
-        }
-        unsigned long long own = 0ull;
-        for (unsigned spins = 0;; ++spins) {
-          bool ok = true;
-#pragma unroll
-          for (int u = 0; u < TRSV_UNROLL; ++u)
-            if (k0 + u < D.w) {
-              xb[u] = ld_sc1_bits(src + cc[u]);
-              ok &= xb[u] != TRSV_SENTINEL;
-            }
-          if (!have_own) {
-            own = ld_sc1_bits(y + row); // forward result of this row
-            ok &= own != TRSV_SENTINEL;
-          }
-          if (__all(ok)) break;
-          if (spins > (1u << 20)) {
-            if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-        if (!have_own) {
-          s = __longlong_as_double((long long)own);
-          have_own = true;
-        }
-#pragma unroll
-        for (int u = 0; u < TRSV_UNROLL; ++u) s -= vv[u] * __longlong_as_double((long long)xb[u]);
-      }
-      if (act) st_sc1(dst + row, upper ? s * di : s);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// XCD-local persistent solve (default engine).  Measured on MI355X (tools/xcd_handoff_bench.hip):
-// a level hand-off between 32 waves costs 0.9 us when producers and consumers share one XCD
-// (plain stores stay in that XCD's L2, consumers read them with sc1 loads that bypass only L1)
-// against 2.0 us across XCDs (write-through) and 7-9 us for a kernel boundary or a counter barrier.
-// Each independent diagonal block (= subdomain) is therefore solved by the waves of ONE XCD:
-//   * every wave reads its XCD from HW_REG_XCC_ID and draws a ticket on that XCD; after a grid
-//     barrier it knows W = #waves on its XCD and works only on the groups owned by its XCD
-//     (group % 8 == xcc).  Same-XCD membership holds by construction, not by dispatch-order
-//     assumption; if some XCD that owns a group received no wave, all waves take the placement-
-//     independent path instead (first 64 waves, write-through stores).
-//   * chunk c (64 rows) of a level belongs to wave c mod W; a wave that finished its chunks of a
-//     level drains its stores and sets its own flag word flag[group][level][rank] = epoch;
-//     a waiter reads all W flags of the previous level with ONE sc1 load instruction.
-//   * epoch comes from a device word bumped by k_trsv_xcd_prologue, so flags never need zeroing.
+// XCD-local placement shared by the single-launch engines (xcd2 fallback, pipe).  Measured on MI355X
+// (tools/xcd_handoff_bench.hip): a hand-off between waves costs 0.9 us when producers and consumers share one XCD
+// (plain stores stay in that XCD's L2, consumers read them with sc1 loads that bypass only L1) against 2.0 us across
+// XCDs (write-through) and 7-9 us for a kernel boundary or a counter barrier.  Each independent diagonal block
+// (= subdomain) is therefore solved by the waves of ONE XCD: every workgroup reads its XCD from HW_REG_XCC_ID and
+// draws a ticket on that XCD; after a grid barrier it knows how many workgroups its XCD has and works only on the
+// groups owned by its XCD (group % 8 == xcc).  If some XCD that owns a group received no workgroup, all take the
+// placement-independent path (write-through stores).  epoch comes from a device word bumped by
+// k_trsv_xcd_prologue, so flags never need zeroing.
 constexpr int TRSV_X_MAXW = 64;
 struct GroupDesc {
   int32_t nlevL, nlevU;
@@ -498,172 +287,6 @@ __global__ void k_trsv_xcd_prologue(XcdState *st)
   }
 }
 __device__ __forceinline__ unsigned hw_xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u; } // HW_REG_XCC_ID[3:0]
-
-// register tile = everything a chunk needs that does NOT depend on x (row id, rhs / inverse pivot,
-// the first TRSV_UNROLL factor entries of each of its 64 rows)
-struct TrsvTile {
-  int32_t row, rr, act;
-  int32_t cc[TRSV_UNROLL];
-  double vv[TRSV_UNROLL];
-  double s0, di;
-};
-__device__ __forceinline__ void trsv_load_tile(TrsvTile &T, const LevelDesc &D, bool upper, int c, int lane,
-                                               const int32_t *__restrict__ rowsA, const int32_t *__restrict__ colsA,
-                                               const double *__restrict__ valsA, const double *__restrict__ dinvA,
-                                               const double *__restrict__ d)
-{
-  const int r = (c << 6) + lane;
-  T.act = r < D.m;
-  T.rr = T.act ? r : D.m - 1; // idle lanes of the last chunk shadow the last row (no store)
-  T.row = rowsA[D.row_off + T.rr];
-  const int32_t *cols = colsA + D.ent_off;
-  const double *vals = valsA + D.ent_off;
-#pragma unroll
-  for (int u = 0; u < TRSV_UNROLL; ++u) {
-    T.cc[u] = 0;
-    T.vv[u] = 0.0;
-    if (u < D.w) { // wave-uniform
-      T.cc[u] = cols[(int64_t)u * D.m + T.rr];
-      T.vv[u] = vals[(int64_t)u * D.m + T.rr];
-    }
-  }
-  T.s0 = upper ? 0.0 : d[T.row];
-  T.di = upper ? dinvA[D.row_off + T.rr] : 0.0;
-}
-__device__ __forceinline__ void trsv_finish_tile(const TrsvTile &T, const LevelDesc &D, bool upper, bool wt,
-                                                 const int32_t *__restrict__ colsA, const double *__restrict__ valsA, double *x)
-{
-  double xv[TRSV_UNROLL];
-#pragma unroll
-  for (int u = 0; u < TRSV_UNROLL; ++u) {
-    xv[u] = 0.0;
-    if (u < D.w) xv[u] = ld_sc1(x + T.cc[u]);
-  }
-  double s = T.s0;
-  if (upper) s = ld_sc1(x + T.row);
-#pragma unroll
-  for (int u = 0; u < TRSV_UNROLL; ++u) s -= T.vv[u] * xv[u];
-  const int32_t *cols = colsA + D.ent_off;
-  const double *vals = valsA + D.ent_off;
-  for (int k0 = TRSV_UNROLL; k0 < D.w; k0 += TRSV_UNROLL) { // rows wider than one tile (rare)
-    int32_t cc[TRSV_UNROLL];
-    double vv[TRSV_UNROLL];
-#pragma unroll
-    for (int u = 0; u < TRSV_UNROLL; ++u) {
-      cc[u] = 0;
-      vv[u] = 0.0;
-      xv[u] = 0.0;
-      if (k0 + u < D.w) {
-        cc[u] = cols[(int64_t)(k0 + u) * D.m + T.rr];
-        vv[u] = vals[(int64_t)(k0 + u) * D.m + T.rr];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < TRSV_UNROLL; ++u)
-      if (k0 + u < D.w) xv[u] = ld_sc1(x + cc[u]);
-#pragma unroll
-    for (int u = 0; u < TRSV_UNROLL; ++u) s -= vv[u] * xv[u];
-  }
-  const double out = upper ? s * T.di : s;
-  if (T.act) {
-    if (wt) st_sc1(x + T.row, out); // placement-independent path: write through
-    else x[T.row] = out;            // same-XCD path: the line stays in this XCD's L2
-  }
-}
-
-// One diagonal block, solved by the W waves of one XCD.  The tile of a level is requested before the
-// wave polls the previous level's flags.  (Requesting it a level earlier does not help a single wave:
-// vmcnt retires in order, so the flag poll would wait for the younger HBM loads as well -- measured
-// 16.4 ms vs 11.2 ms per solve at 216^3.)
-__device__ __forceinline__ void trsv_xcd_group(const GroupDesc Gd, const LevelDesc *__restrict__ descA, const int32_t *__restrict__ rowsA,
-                                                const int32_t *__restrict__ colsA, const double *__restrict__ valsA,
-                                                const double *__restrict__ dinvA, const double *__restrict__ d, double *x, unsigned *flags,
-                                                unsigned epoch, int rank, int W, bool wt, int lane, unsigned *err)
-{
-  const int nlev = Gd.nlevL + Gd.nlevU;
-  const LevelDesc *desc = descA + Gd.lev_off;
-  int nchunk_prev = 0;
-  for (int lev = 0; lev < nlev; ++lev) {
-    const bool upper = lev >= Gd.nlevL;
-    const LevelDesc D = desc[lev];
-    const int nchunk = (D.m + 63) >> 6;
-    if (rank >= nchunk) {
-      nchunk_prev = nchunk;
-      continue;
-    }
-    TrsvTile cur;
-    trsv_load_tile(cur, D, upper, rank, lane, rowsA, colsA, valsA, dinvA, d);
-    if (lev > 0) { // previous level complete <=> the flags of all waves that owned a chunk of it carry this epoch
-      const unsigned *fp = flags + (int64_t)(lev - 1) * TRSV_X_MAXW;
-      const int nact = nchunk_prev < W ? nchunk_prev : W;
-      for (unsigned spins = 0;; ++spins) {
-        const unsigned v = lane < nact ? __hip_atomic_load(fp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
-        if (__all(v == epoch)) break;
-        if (spins > (1u << 22)) {
-          if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    trsv_finish_tile(cur, D, upper, wt, colsA, valsA, x);
-    for (int c = rank + W; c < nchunk; c += W) { // further chunks of the same level (levels wider than 64 W rows)
-      TrsvTile t2;
-      trsv_load_tile(t2, D, upper, c, lane, rowsA, colsA, valsA, dinvA, d);
-      trsv_finish_tile(t2, D, upper, wt, colsA, valsA, x);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's x stores have reached L2 (or memory)
-    if (lane == 0) {
-      unsigned *f = flags + (int64_t)lev * TRSV_X_MAXW + rank;
-      if (wt) __hip_atomic_store(f, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else *(volatile unsigned *)f = epoch;
-    }
-    nchunk_prev = nchunk;
-  }
-}
-
-__global__ __launch_bounds__(64) void k_trsv_xcd(int ngroups, const GroupDesc *__restrict__ groups, const LevelDesc *__restrict__ desc,
-                                                  const int64_t *__restrict__ flag_off, const int32_t *__restrict__ rows,
-                                                  const int32_t *__restrict__ cols, const double *__restrict__ vals,
-                                                  const double *__restrict__ dinv, const double *__restrict__ d, double *x, unsigned *flags,
-                                                  XcdState *st, unsigned *err)
-{
-  const int lane = threadIdx.x;
-  unsigned xcc = 0, t = 0, gt = 0;
-  if (lane == 0) {
-    xcc = hw_xcc_id();
-    t = __hip_atomic_fetch_add(&st->tickets[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    gt = __hip_atomic_fetch_add(&st->global_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(&st->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  xcc = __builtin_amdgcn_readfirstlane(xcc);
-  t = __builtin_amdgcn_readfirstlane(t);
-  gt = __builtin_amdgcn_readfirstlane(gt);
-  // grid barrier (all workgroups are co-resident: gridDim.x <= #CUs single-wave workgroups)
-  for (unsigned spins = 0; __hip_atomic_load(&st->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x; ++spins) {
-    if (spins > (1u << 22)) {
-      if (lane == 0) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return;
-    }
-    __builtin_amdgcn_s_sleep(2);
-  }
-  const unsigned epoch = __hip_atomic_load(&st->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned tk = lane < 8 ? __hip_atomic_load(&st->tickets[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
-  const int owners = ngroups < 8 ? ngroups : 8;                 // XCDs 0..owners-1 own at least one group
-  const bool local_ok = __all(lane >= owners || tk > 0u);       // every owning XCD has at least one wave
-  if (local_ok) {
-    int W = (int)__shfl((int)tk, (int)xcc, 64);
-    if (W > TRSV_X_MAXW) W = TRSV_X_MAXW;
-    if ((int)t >= W) return;
-    for (int grp = (int)xcc; grp < ngroups; grp += 8)
-      trsv_xcd_group(groups[grp], desc, rows, cols, vals, dinv, d, x, flags + flag_off[grp], epoch, (int)t, W, false, lane, err);
-  } else { // placement-independent path
-    int W = (int)gridDim.x < TRSV_X_MAXW ? (int)gridDim.x : TRSV_X_MAXW;
-    if ((int)gt >= W) return;
-    for (int grp = 0; grp < ngroups; ++grp)
-      trsv_xcd_group(groups[grp], desc, rows, cols, vals, dinv, d, x, flags + flag_off[grp], epoch, (int)gt, W, true, lane, err);
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // XCD-local solve with a dedicated LOADER wave per workgroup ("xcd2" engine).
@@ -731,15 +354,11 @@ struct TrsvWork {
   }
 };
 
-// DATAFLOW = false: level flags (drain + flag per level).  DATAFLOW = true ("xcd3"): y / x are pre-filled with
-// the all-ones sentinel, a row polls its own dependencies in L2 until none is the sentinel and publishes its
-// value with a single 8-byte store: no flag, no drain, no level barrier on the critical path.
-template <bool DATAFLOW>
 __global__ __launch_bounds__(64 * (1 + TRSV_L_LOADERS)) void k_trsv_xcd2(int ngroups, const GroupDesc *__restrict__ groups, const LevelDesc *__restrict__ desc,
                                                     const int64_t *__restrict__ flag_off, const int32_t *__restrict__ rowsA,
                                                     const int32_t *__restrict__ colsA, const double *__restrict__ valsA,
                                                     const double *__restrict__ dinvA, const double *__restrict__ dperm, double *x,
-                                                    double *y, unsigned *flags, XcdState *st, unsigned *err, unsigned long long *stamps)
+                                                    unsigned *flags, XcdState *st, unsigned *err, unsigned long long *stamps)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   TrsvLds &S = *reinterpret_cast<TrsvLds *>(smem_raw);
@@ -815,7 +434,7 @@ __global__ __launch_bounds__(64 * (1 + TRSV_L_LOADERS)) void k_trsv_xcd2(int ngr
       const int32_t row = rowsA[D.row_off + rr];
       R.rowm = r < D.m ? row : -1 - row; // negative = shadow lane (no store)
       R.s0 = upper ? dinvA[D.row_off + rr] : dperm[D.row_off + rr];
-      if (!DATAFLOW) (void)*(volatile const unsigned long long *)(x + row); // warm this XCD's L2 with the line of x[row]
+      (void)*(volatile const unsigned long long *)(x + row); // warm this XCD's L2 with the line of x[row]
       const int32_t *cols = colsA + D.ent_off;
       const double *vals = valsA + D.ent_off;
 #pragma unroll
@@ -934,53 +553,6 @@ __global__ __launch_bounds__(64 * (1 + TRSV_L_LOADERS)) void k_trsv_xcd2(int ngr
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) *consumed = seq + 1; // slot may be refilled
     DDM_STAMP(t_tile)
-    if (DATAFLOW) {
-      const double *src = upper ? x : y;
-      unsigned long long xb[TRSV_UNROLL], own = 0ull;
-      for (unsigned spins = 0;; ++spins) {
-        bool ok = true;
-#pragma unroll
-        for (int u = 0; u < TRSV_UNROLL; ++u) {
-          xb[u] = 0ull;
-          if (u < H.w) {
-            xb[u] = ld_sc1_bits(src + cc[u]);
-            ok &= xb[u] != TRSV_SENTINEL;
-          }
-        }
-        if (upper) {
-          own = ld_sc1_bits(y + row);
-          ok &= own != TRSV_SENTINEL;
-        }
-        if (__all(ok)) break;
-        if (spins > (1u << 20)) {
-          if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-      }
-      double s = upper ? __longlong_as_double((long long)own) : s0;
-#pragma unroll
-      for (int u = 0; u < TRSV_UNROLL; ++u) s -= vv[u] * __longlong_as_double((long long)xb[u]);
-      if (H.w > TRSV_UNROLL) { // rare: rows wider than a tile (their extra dependencies are polled one by one)
-        const int r = (H.c << 6) + lane;
-        const int rr = r < H.m ? r : H.m - 1;
-        for (int k = TRSV_UNROLL; k < H.w; ++k) {
-          const int32_t c2 = colsA[H.ent_off + (int64_t)k * H.m + rr];
-          unsigned long long b2;
-          for (unsigned spins = 0;; ++spins) {
-            b2 = ld_sc1_bits(src + c2);
-            if (__all(b2 != TRSV_SENTINEL) || spins > (1u << 20)) break;
-          }
-          s -= valsA[H.ent_off + (int64_t)k * H.m + rr] * __longlong_as_double((long long)b2);
-        }
-      }
-      const double out = upper ? s * s0 : s;
-      double *dst = upper ? x : y;
-      if (act) {
-        if (wt) st_sc1(dst + row, out);
-        else dst[row] = out;
-      }
-      continue;
-    }
     // previous level of this group complete?
     if (H.nact_prev > 0) {
       const unsigned *fp = flags + H.flag_base - TRSV_X_MAXW;
@@ -1041,40 +613,6 @@ __global__ __launch_bounds__(64 * (1 + TRSV_L_LOADERS)) void k_trsv_xcd2(int ngr
 }
 
 // ---------------------------------------------------------------------------------------------
-// "xcdw" engine: XCD-local solve on LEVEL-PERMUTED vectors with LDS-staged dependency windows.
-// Stamps of the xcd2 engine (ddm_ilu0_debug_stamps, 216^3): per 64-row chunk 0.8 us go into 17 x 64
-// scattered 8-byte L2 reads and 1.6 us into draining 64 scattered stores -- every 8-byte value costs a
-// whole L2 line transaction.  Here the solve runs in level order on xp[pos] (pos = position in the
-// level-sorted row list): the 64 results of a chunk are ONE contiguous 512-byte store, and because level
-// sorting preserves the spatial order inside a level, the dependencies of a chunk fall into a few short
-// position runs ("windows", found on the host).  A wave copies its windows into LDS with coalesced
-// loads and gathers from LDS.  Chunks whose windows do not fit (unstructured matrices) gather from
-// global memory by position.  Hand-off protocol, grouping by XCD, loader wave: as in k_trsv_xcd2.
-constexpr int TRSV_W_MAXPIECE = 24;  // windows are cut into pieces of <= 64 positions = one coalesced load each
-constexpr int TRSV_W_STAGE = 64 * TRSV_W_MAXPIECE; // doubles of LDS staging per compute wave
-struct WChunk {
-  int32_t npiece;                // 0 => gather directly from global memory (entries hold positions)
-  int32_t staged;
-  int32_t lo[TRSV_W_MAXPIECE];   // first position of the piece
-  uint16_t off[TRSV_W_MAXPIECE]; // offset of the piece in the staging buffer
-  uint8_t len[TRSV_W_MAXPIECE];  // 1..64
-};
-constexpr int TRSV_W_META_DWORDS = (int)(sizeof(WChunk) / 4);
-struct WLevel {
-  int32_t m, w;
-  int64_t pos_off, ent_off, chunk_off; // first position / first ELL entry / first WChunk of the level
-};
-struct WTile {
-  double s0[64];                 // L: permuted right-hand side; U: inverse pivot
-  int32_t idx[TRSV_UNROLL][64];  // staging index (or position, if nwin == 0)
-  double vv[TRSV_UNROLL][64];
-  WChunk meta;
-};
-struct WLds {
-  WTile tile[TRSV_L_SLOTS];
-  double stage[TRSV_W_STAGE];
-  unsigned produced, consumed;
-};
 // xp[pos] <- d[row(pos)] for the L positions of every group; x[row(pos)] <- xp[pos] for the U positions
 __global__ void k_w_permute_in(int64_t n, const int64_t *__restrict__ lpos, const int32_t *__restrict__ rows, const double *__restrict__ d,
                                double *__restrict__ dperm)
@@ -1085,565 +623,6 @@ __global__ void k_w_permute_out(int64_t n, const int64_t *__restrict__ upos, con
                                 double *__restrict__ x)
 {
   for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG) x[rows[upos[i]]] = xp[upos[i]];
-}
-
-struct WWork { // work items (level, chunk) of one wave, in processing order
-  const GroupDesc *groups;
-  const WLevel *lev_;
-  int ngroups, gstep, grp, lev, c, rank, W;
-  __device__ bool valid() const { return grp < ngroups; }
-  __device__ void init(const GroupDesc *g, const WLevel *l, int ng, int first, int step, int rank_, int W_)
-  {
-    groups = g; lev_ = l; ngroups = ng; gstep = step; grp = first; lev = 0; c = rank_; rank = rank_; W = W_;
-    settle();
-  }
-  __device__ void settle()
-  {
-    while (grp < ngroups) {
-      const GroupDesc G = groups[grp];
-      const int nlev = G.nlevL + G.nlevU;
-      while (lev < nlev) {
-        if (c < ((lev_[G.lev_off + lev].m + 63) >> 6)) return;
-        ++lev;
-        c = rank;
-      }
-      grp += gstep;
-      lev = 0;
-      c = rank;
-    }
-  }
-  __device__ void advance()
-  {
-    c += W;
-    settle();
-  }
-};
-
-__global__ __launch_bounds__(128) void k_trsv_xcdw(int ngroups, const GroupDesc *__restrict__ groups, const WLevel *__restrict__ levels,
-                                                    const WChunk *__restrict__ chunks, const int64_t *__restrict__ flag_off,
-                                                    const int32_t *__restrict__ idxA, const double *__restrict__ valsA,
-                                                    const double *__restrict__ dinvA, const int32_t *__restrict__ ownA,
-                                                    const double *__restrict__ dperm, double *xp, unsigned *flags, XcdState *st, unsigned *err,
-                                                    unsigned long long *stamps)
-{
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  WLds &S = *reinterpret_cast<WLds *>(smem_raw);
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  __shared__ unsigned sh_xcc, sh_t, sh_gt, sh_fail;
-  if (threadIdx.x == 0) {
-    S.produced = 0;
-    S.consumed = 0;
-    const unsigned xcc = hw_xcc_id();
-    sh_xcc = xcc;
-    sh_t = __hip_atomic_fetch_add(&st->tickets[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    sh_gt = __hip_atomic_fetch_add(&st->global_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(&st->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned fail_ = 0;
-    for (unsigned spins = 0; __hip_atomic_load(&st->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x; ++spins) {
-      if (spins > (1u << 22)) {
-        __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        fail_ = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-    sh_fail = fail_;
-  }
-  __syncthreads();
-  if (sh_fail) return;
-  const unsigned xcc = sh_xcc, t = sh_t, gt = sh_gt;
-  const unsigned epoch = __hip_atomic_load(&st->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned tk = lane < 8 ? __hip_atomic_load(&st->tickets[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
-  const int owners = ngroups < 8 ? ngroups : 8;
-  const bool local_ok = __all(lane >= owners || tk > 0u);
-  int W, rank, first, step;
-  bool wt;
-  if (local_ok) {
-    W = (int)__shfl((int)tk, (int)xcc, 64);
-    if (W > TRSV_X_MAXW) W = TRSV_X_MAXW;
-    rank = (int)t; first = (int)xcc; step = 8; wt = false;
-  } else {
-    W = (int)gridDim.x < TRSV_X_MAXW ? (int)gridDim.x : TRSV_X_MAXW;
-    rank = (int)gt; first = 0; step = 1; wt = true;
-  }
-  if (rank >= W) return;
-  WWork wk;
-  wk.init(groups, levels, ngroups, first, step, rank, W);
-  volatile unsigned *produced = &S.produced;
-  volatile unsigned *consumed = &S.consumed;
-
-  if (wave == 1) {
-    // ---------------- loader: HBM -> LDS tile ring, two tiles in flight ----------------
-    struct Regs {
-      int32_t w, metaw[2];
-      double s0;
-      int32_t idx[TRSV_UNROLL];
-      double vv[TRSV_UNROLL];
-    };
-    static_assert(sizeof(WChunk) % 4 == 0 && TRSV_W_META_DWORDS <= 64, "WChunk layout");
-    auto issue = [&](Regs &R, const WWork &k) {
-      const GroupDesc G = groups[k.grp];
-      const WLevel D = levels[G.lev_off + k.lev];
-      const bool upper = k.lev >= G.nlevL;
-      const int r = (k.c << 6) + lane;
-      const int rr = r < D.m ? r : D.m - 1;
-      R.w = D.w;
-      R.s0 = upper ? dinvA[D.pos_off + rr] : dperm[D.pos_off + rr];
-      const int32_t *mp = reinterpret_cast<const int32_t *>(chunks + D.chunk_off + k.c);
-      R.metaw[0] = lane < TRSV_W_META_DWORDS ? mp[lane] : 0;
-      const int32_t *idx = idxA + D.ent_off;
-      const double *vals = valsA + D.ent_off;
-#pragma unroll
-      for (int u = 0; u < TRSV_UNROLL; ++u) {
-        R.idx[u] = 0;
-        R.vv[u] = 0.0;
-        if (u < D.w) {
-          R.idx[u] = idx[(int64_t)u * D.m + rr];
-          R.vv[u] = vals[(int64_t)u * D.m + rr];
-        }
-      }
-    };
-    Regs A, B;
-    if (!wk.valid()) return;
-    issue(A, wk);
-    for (unsigned seq = 0;; ++seq) {
-      wk.advance();
-      const bool more = wk.valid();
-      if (more) issue(B, wk);
-      for (unsigned spins = 0; seq >= *consumed + TRSV_L_SLOTS; ++spins) {
-        if (spins > (1u << 24)) {
-          if (lane == 0) __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          return;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      WTile &T = S.tile[seq % TRSV_L_SLOTS];
-      T.s0[lane] = A.s0;
-      if (lane < TRSV_W_META_DWORDS) reinterpret_cast<int32_t *>(&T.meta)[lane] = A.metaw[0];
-#pragma unroll
-      for (int u = 0; u < TRSV_UNROLL; ++u)
-        if (u < A.w) {
-          T.idx[u][lane] = A.idx[u];
-          T.vv[u][lane] = A.vv[u];
-        }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane == 0) *produced = seq + 1;
-      if (!more) return;
-      A = B;
-    }
-  }
-
-  // ---------------- compute wave ----------------
-  const bool stamp = stamps != nullptr && rank == 0 && (local_ok ? xcc == 0 : true);
-  unsigned long long t_tile = 0, t_poll = 0, t_gather = 0, t_drain = 0, n_items = 0, n_direct = 0, t_begin = 0, tq = 0;
-#define DDM_STAMP(acc)                                                 \
-  if (stamp) {                                                         \
-    const unsigned long long now_ = __builtin_amdgcn_s_memtime();      \
-    acc += now_ - tq;                                                  \
-    tq = now_;                                                         \
-  }
-  if (stamp) t_begin = tq = __builtin_amdgcn_s_memtime();
-  for (unsigned seq = 0; wk.valid(); ++seq) {
-    const int grp = wk.grp, lev = wk.lev, c = wk.c;
-    const GroupDesc G = groups[grp];
-    const WLevel D = levels[G.lev_off + lev];
-    const bool upper = lev >= G.nlevL;
-    unsigned *gflags = flags + flag_off[grp];
-    for (unsigned spins = 0; *produced <= seq; ++spins) {
-      if (spins > (1u << 24)) {
-        if (lane == 0) __hip_atomic_store(err, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    const WTile &T = S.tile[seq % TRSV_L_SLOTS];
-    const int r = (c << 6) + lane;
-    const bool act = r < D.m;
-    const double s0 = T.s0[lane];
-    int32_t idx[TRSV_UNROLL];
-    double vv[TRSV_UNROLL];
-#pragma unroll
-    for (int u = 0; u < TRSV_UNROLL; ++u) {
-      idx[u] = 0;
-      vv[u] = 0.0;
-      if (u < D.w) {
-        idx[u] = T.idx[u][lane];
-        vv[u] = T.vv[u][lane];
-      }
-    }
-    const int npiece = T.meta.npiece;
-    const int plo = lane < TRSV_W_MAXPIECE ? T.meta.lo[lane] : 0;
-    const int plen = lane < TRSV_W_MAXPIECE ? (int)T.meta.len[lane] : 0;
-    const int poff = lane < TRSV_W_MAXPIECE ? (int)T.meta.off[lane] : 0;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) *consumed = seq + 1;
-    DDM_STAMP(t_tile)
-    if (npiece == 0) n_direct += 1;
-    // previous level of this group complete?
-    if (lev > 0 && c == rank) {
-      const unsigned *fp = gflags + (int64_t)(lev - 1) * TRSV_X_MAXW;
-      const int ncp = (levels[G.lev_off + lev - 1].m + 63) >> 6;
-      const int nact = ncp < W ? ncp : W;
-      for (unsigned spins = 0;; ++spins) {
-        const unsigned v = lane < nact ? __hip_atomic_load(fp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
-        if (__all(v == epoch)) break;
-        if (spins > (1u << 22)) {
-          if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    DDM_STAMP(t_poll)
-    // own forward value (U phase): one scattered read per row
-    const int rr = act ? r : D.m - 1;
-    double s = s0;
-    if (upper) s = ld_sc1(xp + ownA[D.pos_off + rr]);
-    double xv[TRSV_UNROLL];
-    if (npiece > 0) {
-      // stage the dependency windows: one coalesced sc1 load per piece, 8 in flight, then LDS
-      for (int p0 = 0; p0 < npiece; p0 += 8) {
-        double buf[8];
-        int offs[8], lens[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int lo = __shfl(plo, p0 + u, 64);
-          lens[u] = p0 + u < npiece ? __shfl(plen, p0 + u, 64) : 0;
-          offs[u] = __shfl(poff, p0 + u, 64);
-          buf[u] = 0.0;
-          if (p0 + u < npiece) buf[u] = ld_sc1(xp + lo + (lane < lens[u] ? lane : 0));
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (lane < lens[u]) S.stage[offs[u] + lane] = buf[u];
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int u = 0; u < TRSV_UNROLL; ++u) {
-        xv[u] = 0.0;
-        if (u < D.w) xv[u] = S.stage[idx[u]];
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < TRSV_UNROLL; ++u) {
-        xv[u] = 0.0;
-        if (u < D.w) xv[u] = ld_sc1(xp + idx[u]);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < TRSV_UNROLL; ++u) s -= vv[u] * xv[u];
-    for (int k = TRSV_UNROLL; k < D.w; ++k) // rows wider than a tile (rare): the rest by position from global memory
-      s -= valsA[D.ent_off + (int64_t)k * D.m + rr] * ld_sc1(xp + idxA[D.ent_off + (int64_t)k * D.m + rr]);
-    if (stamp) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      DDM_STAMP(t_gather)
-    }
-    const double out = upper ? s * s0 : s;
-    if (act) {
-      if (wt) st_sc1(xp + D.pos_off + r, out);
-      else xp[D.pos_off + r] = out; // contiguous: one 512-byte store per wave
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // staging buffer is free again
-    wk.advance();
-    const bool level_done = !wk.valid() || wk.grp != grp || wk.lev != lev;
-    if (level_done) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) {
-        unsigned *f = gflags + (int64_t)lev * TRSV_X_MAXW + rank;
-        if (wt) __hip_atomic_store(f, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else *(volatile unsigned *)f = epoch;
-      }
-    }
-    DDM_STAMP(t_drain)
-    n_items += 1;
-  }
-  if (stamp && lane == 0) {
-    stamps[0] = t_tile;
-    stamps[1] = t_poll;
-    stamps[2] = t_gather;
-    stamps[3] = t_drain;
-    stamps[4] = n_items;
-    stamps[5] = __builtin_amdgcn_s_memtime() - t_begin;
-    stamps[6] = n_direct;
-  }
-#undef DDM_STAMP
-}
-
-// ---------------------------------------------------------------------------------------------
-// "slab" engine: XCD-local solve with ROW OWNERSHIP.  The level-barrier engines need four dependent L2
-// round trips per level (flag poll, gathers, store drain, flag visibility).  Here every wave owns a
-// contiguous slab of rows of its subdomain (natural order => a few grid planes) for the whole solve and
-// walks its own rows level by level:
-//   * dependencies inside the slab were stored by the same wave: the sc1 gather simply follows the
-//     store through L2 (same wave, same address: in order) -- no flag, no drain;
-//   * dependencies on other slabs (lower slabs in the L sweep, higher slabs in the U sweep) are guarded
-//     by one monotone progress word per wave ("all my rows of levels < p are stored"), published every
-//     SLAB_PUB steps after a drain; the value is cached, so a wave that runs behind its neighbours
-//     (the natural pipeline skew) polls rarely;
-//   * the forward result goes to y, the backward result to x, so the two sweeps never race.
-// tools/xcd_handoff_bench.hip mode 2 measures 1.76 us per level for this pattern (13 x 64 scattered
-// gathers + 64 stores) against 5-6 us per level for the level-barrier engines.
-constexpr int SLAB_W = 32;      // waves (slabs) per subdomain; one XCD normally hosts 32 single-CU workgroups
-constexpr int SLAB_PUB = 4;     // (unused by the lazy-publish protocol; kept for the schedule builder's gap rule)
-struct SlabStep {
-  int32_t level, m, w, next_level; // next_level = level of the wave's next step (or #levels of the sweep)
-  int64_t pos_off, ent_off;        // first position (rows / rhs / inverse pivots) and first ELL entry of the step
-  uint32_t dep_mask, pad;          // waves (other than the owner) that own a dependency of this step
-};
-struct SlabGroup {
-  int32_t nlevL, nlevU;
-  int64_t step_ptr;                // index into wave_step_ptr: SLAB_W + 1 offsets for this group
-  int64_t prog_off;                // first progress word (2 * SLAB_W words of 32 uint32 each: L then U)
-};
-
-__global__ __launch_bounds__(128) void k_trsv_slab(int ngroups, const SlabGroup *__restrict__ groups, const int64_t *__restrict__ wave_step_ptr,
-                                                    const SlabStep *__restrict__ steps, const int32_t *__restrict__ rowsA,
-                                                    const int32_t *__restrict__ colsA, const double *__restrict__ valsA,
-                                                    const double *__restrict__ dinvA, const double *__restrict__ dperm, double *y, double *x,
-                                                    unsigned *progress, XcdState *st, unsigned *err)
-{
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  TrsvLds &S = *reinterpret_cast<TrsvLds *>(smem_raw);
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  __shared__ unsigned sh_xcc, sh_t, sh_gt, sh_fail;
-  if (threadIdx.x == 0) {
-    S.produced = 0;
-    S.consumed = 0;
-    const unsigned xcc = hw_xcc_id();
-    sh_xcc = xcc;
-    sh_t = __hip_atomic_fetch_add(&st->tickets[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    sh_gt = __hip_atomic_fetch_add(&st->global_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(&st->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned fail_ = 0;
-    for (unsigned spins = 0; __hip_atomic_load(&st->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x; ++spins) {
-      if (spins > (1u << 22)) {
-        __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        fail_ = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-    sh_fail = fail_;
-  }
-  __syncthreads();
-  if (sh_fail) return;
-  const unsigned xcc = sh_xcc, t = sh_t, gt = sh_gt;
-  const unsigned epoch = __hip_atomic_load(&st->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x3FFu;
-  const unsigned tk = lane < 8 ? __hip_atomic_load(&st->tickets[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (unsigned)SLAB_W;
-  const int owners = ngroups < 8 ? ngroups : 8;
-  const bool local_ok = __all(lane >= owners || tk >= (unsigned)SLAB_W); // every owning XCD hosts a full set of slab waves
-  int rank, first, step;
-  bool wt;
-  if (local_ok) {
-    rank = (int)t; first = (int)xcc; step = 8; wt = false;
-  } else { // placement-independent path: the first SLAB_W workgroups, write-through stores
-    rank = (int)gt; first = 0; step = 1; wt = true;
-  }
-  if (rank >= SLAB_W) return;
-  volatile unsigned *produced = &S.produced;
-  volatile unsigned *consumed = &S.consumed;
-
-  if (wave == 1) {
-    // ---------------- loader: HBM -> LDS tile ring, two tiles in flight ----------------
-    struct Regs {
-      int32_t rowm, w;
-      double s0;
-      int32_t cc[TRSV_UNROLL];
-      double vv[TRSV_UNROLL];
-    };
-    struct Cursor {
-      int grp, sweep;
-      int64_t s, s_end;
-      int c;
-    };
-    auto settle = [&](Cursor &k) { // advance to the next existing (step, chunk)
-      while (k.grp < ngroups) {
-        const SlabGroup G = groups[k.grp];
-        while (k.sweep < 2) {
-          if (k.s < 0) {
-            const int64_t *sp = wave_step_ptr + G.step_ptr + (int64_t)k.sweep * (SLAB_W + 1);
-            k.s = sp[rank];
-            k.s_end = sp[rank + 1];
-            k.c = 0;
-          }
-          while (k.s < k.s_end) {
-            if (k.c < ((steps[k.s].m + 63) >> 6)) return;
-            ++k.s;
-            k.c = 0;
-          }
-          ++k.sweep;
-          k.s = -1;
-        }
-        k.grp += step;
-        k.sweep = 0;
-        k.s = -1;
-      }
-    };
-    auto issue = [&](Regs &R, const Cursor &k) {
-      const SlabStep D = steps[k.s];
-      const bool upper = k.sweep == 1;
-      const int r = (k.c << 6) + lane;
-      const int rr = r < D.m ? r : D.m - 1;
-      const int32_t row = rowsA[D.pos_off + rr];
-      R.rowm = r < D.m ? row : -1 - row;
-      R.w = D.w;
-      R.s0 = upper ? dinvA[D.pos_off + rr] : dperm[D.pos_off + rr];
-      const int32_t *cols = colsA + D.ent_off;
-      const double *vals = valsA + D.ent_off;
-#pragma unroll
-      for (int u = 0; u < TRSV_UNROLL; ++u) {
-        R.cc[u] = 0;
-        R.vv[u] = 0.0;
-        if (u < D.w) {
-          R.cc[u] = cols[(int64_t)u * D.m + rr];
-          R.vv[u] = vals[(int64_t)u * D.m + rr];
-        }
-      }
-    };
-    Cursor cur{first, 0, -1, 0, 0};
-    settle(cur);
-    if (cur.grp >= ngroups) return;
-    Regs A, B;
-    issue(A, cur);
-    for (unsigned seq = 0;; ++seq) {
-      ++cur.c;
-      settle(cur);
-      const bool more = cur.grp < ngroups;
-      if (more) issue(B, cur);
-      for (unsigned spins = 0; seq >= *consumed + TRSV_L_SLOTS; ++spins) {
-        if (spins > (1u << 24)) {
-          if (lane == 0) __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          return;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      TrsvLdsTile &T = S.tile[seq % TRSV_L_SLOTS];
-      T.row[lane] = A.rowm;
-      T.s0[lane] = A.s0;
-#pragma unroll
-      for (int u = 0; u < TRSV_UNROLL; ++u)
-        if (u < A.w) {
-          T.cc[u][lane] = A.cc[u];
-          T.vv[u][lane] = A.vv[u];
-        }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane == 0) *produced = seq + 1;
-      if (!more) return;
-      A = B;
-    }
-  }
-
-  // ---------------- compute wave ----------------
-  unsigned seq = 0;
-  for (int grp = first; grp < ngroups; grp += step) {
-    const SlabGroup G = groups[grp];
-    for (int sweep = 0; sweep < 2; ++sweep) {
-      const bool upper = sweep == 1;
-      const int64_t *sp = wave_step_ptr + G.step_ptr + (int64_t)sweep * (SLAB_W + 1);
-      const int64_t s_begin = sp[rank], s_end = sp[rank + 1];
-      unsigned *prog = progress + G.prog_off + (int64_t)sweep * SLAB_W * 32;
-      const int nlev = upper ? G.nlevU : G.nlevL;
-      const double *src = upper ? x : y;
-      double *dst = upper ? x : y;
-      // progress protocol: word[k] = (epoch, p) means "every row of wave k with level < p is stored".
-      //  * lazy publish: once the gathers of a step have returned, all earlier stores of this wave are complete
-      //    (vmcnt retires in order), so p = level of the current step can be published without a drain;
-      //  * before blocking on other waves the wave drains and publishes, so nobody waits on a wave that waits.
-      int pl = 0; // lane j: last progress seen of wave j
-      unsigned *myword = prog + rank * 32;
-      auto publish = [&](int p) {
-        if (lane == 0) {
-          const unsigned word = (epoch << 22) | (unsigned)p;
-          if (wt) __hip_atomic_store(myword, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else *(volatile unsigned *)myword = word;
-        }
-      };
-      for (int64_t si = s_begin; si < s_end; ++si) {
-        const SlabStep D = steps[si];
-        const int nchunk = (D.m + 63) >> 6;
-        for (int c = 0; c < nchunk; ++c, ++seq) {
-          for (unsigned spins = 0; *produced <= seq; ++spins) {
-            if (spins > (1u << 24)) {
-              if (lane == 0) __hip_atomic_store(err, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              return;
-            }
-            __builtin_amdgcn_s_sleep(1);
-          }
-          const TrsvLdsTile &T = S.tile[seq % TRSV_L_SLOTS];
-          const int32_t rowm = T.row[lane];
-          const bool act = rowm >= 0;
-          const int32_t row = act ? rowm : -1 - rowm;
-          const double s0 = T.s0[lane];
-          int32_t cc[TRSV_UNROLL];
-          double vv[TRSV_UNROLL], xv[TRSV_UNROLL];
-#pragma unroll
-          for (int u = 0; u < TRSV_UNROLL; ++u) {
-            cc[u] = 0;
-            vv[u] = 0.0;
-            if (u < D.w) {
-              cc[u] = T.cc[u][lane];
-              vv[u] = T.vv[u][lane];
-            }
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (lane == 0) *consumed = seq + 1;
-          // rows of level D.level need the rows of levels < D.level of the waves in dep_mask
-          if (c == 0) {
-            const bool dep = lane < SLAB_W && ((D.dep_mask >> lane) & 1u);
-            if (!__all(!dep || pl >= D.level)) {
-              asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // about to wait: first tell the others how far this wave is
-              publish(D.level);
-              for (unsigned spins = 0;; ++spins) {
-                if (dep) {
-                  const unsigned v = __hip_atomic_load(prog + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  pl = (v >> 22) == epoch ? (int)(v & 0x3FFFFFu) : 0;
-                }
-                if (__all(!dep || pl >= D.level)) break;
-                if (spins > (1u << 22)) {
-                  if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  break;
-                }
-              }
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < TRSV_UNROLL; ++u) {
-            xv[u] = 0.0;
-            if (u < D.w) xv[u] = ld_sc1(src + cc[u]);
-          }
-          double s = upper ? ld_sc1(y + row) : s0;
-#pragma unroll
-          for (int u = 0; u < TRSV_UNROLL; ++u) s -= vv[u] * xv[u];
-          if (D.w > TRSV_UNROLL) {
-            const int r = (c << 6) + lane;
-            const int rr = r < D.m ? r : D.m - 1;
-            for (int k = TRSV_UNROLL; k < D.w; ++k)
-              s -= valsA[D.ent_off + (int64_t)k * D.m + rr] * ld_sc1(src + colsA[D.ent_off + (int64_t)k * D.m + rr]);
-          }
-          asm volatile("" ::"v"(s)); // the gathers have returned here => every earlier store of this wave is complete
-          if (c == 0) publish(D.level);
-          const double out = upper ? s * s0 : s;
-          if (act) {
-            if (wt) st_sc1(dst + row, out);
-            else dst[row] = out;
-          }
-        }
-      }
-      if (s_begin < s_end) { // end of the sweep: everything is stored
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        publish(nlev);
-      }
-      if (s_begin == s_end && lane == 0) { // a wave without rows in this sweep still reports completion
-        const unsigned word = (epoch << 22) | (unsigned)nlev;
-        unsigned *f = prog + rank * 32;
-        if (wt) __hip_atomic_store(f, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else *(volatile unsigned *)f = word;
-      }
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
