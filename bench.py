@@ -129,6 +129,7 @@ def main():
     elapsed = time.perf_counter() - t0
     tl.ctx.timing(False)
     deff = cg.defect()
+    tl.prec.check_status()      # a timed-out single-launch local solve would invalidate the timing (raises)
     local_ms, local_cnt = tl.ctx.timer("Schwarz/local solve")
     timers = {name: tl.ctx.timer(name) for name in ("Operator/apply", "Schwarz/get defect", "Schwarz/local solve",
                                                     "Schwarz/add solution", "GalerkinPrec/apply", "CombinedPreconditioner/apply")}

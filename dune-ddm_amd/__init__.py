@@ -68,6 +68,10 @@ SYMBOLS = {
     "ddm_ilu0_status": (_I32, [_P, _P, ctypes.POINTER(ctypes.c_int)]),
     "ddm_ilu0_pipe_trace": (_I32, [_P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(ctypes.c_int64)]),
     "ddm_ilu0_num_levels": (_I64, [_P, _I32]),
+    "ddm_ilu0_engine": (_I32, [_P]),
+    "ddm_schwarz_engine": (_I32, [_P]),
+    "ddm_schwarz_status": (_I32, [_P, _P]),
+    "ddm_combined_status": (_I32, [_P, _P]),
     "ddm_ilu0_get_factors_host": (_I32, [_P, _P, _P]),
     "ddm_halo_create": (_I32, [_P, _I32, _I32, _I64, _P, _P, _P, _I64, _P, _P, _P, _PP]),
     "ddm_halo_destroy": (None, [_P]),
@@ -264,6 +268,9 @@ class Ilu0:
         self.ctx.check(self.ctx.lib.ddm_ilu0_pipe_trace(self.ctx.h, self.h, _ptr(d), _ptr(x), _hp(out), _hp(meta), nt.value, ctypes.byref(nt)))
         return out, meta
 
+    def engine(self):
+        return SchwarzPreconditioner.ENGINES[int(self.ctx.lib.ddm_ilu0_engine(self.h))]
+
     def status(self):
         st = ctypes.c_int()
         self.ctx.check(self.ctx.lib.ddm_ilu0_status(self.ctx.h, self.h, ctypes.byref(st)))
@@ -362,6 +369,16 @@ class SchwarzPreconditioner:
     def num_levels(self):
         return (int(self.ctx.lib.ddm_schwarz_num_levels(self.h, 0)), int(self.ctx.lib.ddm_schwarz_num_levels(self.h, 1)))
 
+    ENGINES = {8: "pipe", 4: "xcd2", 0: "levels"}
+
+    def engine(self):
+        """triangular-solve engine of the local solver: 'pipe', 'xcd2' (also when pipe declined the matrix) or 'levels'"""
+        return self.ENGINES[int(self.ctx.lib.ddm_schwarz_engine(self.h))]
+
+    def check_status(self):
+        """raises DdmError if a single-launch local solve timed out since creation (synchronous)"""
+        self.ctx.check(self.ctx.lib.ddm_schwarz_status(self.ctx.h, self.h))
+
 
 class GalerkinPreconditioner:
     """dune/ddm/galerkin_preconditioner.hh:40-363 (apply path; the coarse matrix is assembled by
@@ -412,6 +429,9 @@ class CombinedPreconditioner:
 
     def apply(self, x, d):
         self.ctx.check(self.ctx.lib.ddm_combined_apply(self.ctx.h, self.h, _ptr(x), _ptr(d)))
+
+    def check_status(self):
+        self.ctx.check(self.ctx.lib.ddm_combined_status(self.ctx.h, self.h))
 
 
 def cg_solve(ctx: Context, op: NonOverlappingOperator, prec: CombinedPreconditioner, x, b, reduction=1e-10, maxit=1000,

@@ -626,6 +626,12 @@ extern "C" int ddm_ilu0_status(ddm_ctx *ctx, const ddm_ilu0 *F, int *status)
   return DDM_OK;
 }
 extern "C" int64_t ddm_ilu0_num_levels(const ddm_ilu0 *F, int upper) { return upper ? F->U.nlev : F->L.nlev; }
+// engine the next ddm_ilu0_solve uses: 8 = pipe, 4 = xcd2 (also when pipe declined the matrix), 0 = one launch per level
+extern "C" int ddm_ilu0_engine(const ddm_ilu0 *F)
+{
+  if (!F) return -1;
+  return (F->mode == 8 && F->pipe_state < 0) ? 4 : F->mode;
+}
 extern "C" int ddm_ilu0_get_factors_host(ddm_ctx *ctx, const ddm_ilu0 *F, double *lu_host)
 {
   if (!F || !lu_host) return fail(ctx, DDM_EINVAL, "bad arguments");
@@ -1200,6 +1206,18 @@ extern "C" void ddm_schwarz_destroy(ddm_schwarz *S)
   delete S;
 }
 extern "C" int64_t ddm_schwarz_num_levels(const ddm_schwarz *S, int upper) { return ddm_ilu0_num_levels(S->solver, upper); }
+extern "C" int ddm_schwarz_engine(const ddm_schwarz *S) { return S ? ddm_ilu0_engine(S->solver) : -1; }
+// Synchronous.  DDM_OK, or DDM_ENUMERIC when a single-launch local solve gave up waiting (its results are invalid: the
+// GPU is shared with another process, or the grid was not co-resident) -- the reference's apply has no error return
+// (schwarz.hh:131 discards the InverseOperatorResult), so the adaptors poll this in post() and the Krylov drivers at the end.
+extern "C" int ddm_schwarz_status(ddm_ctx *ctx, const ddm_schwarz *S)
+{
+  if (!S) return fail(ctx, DDM_EINVAL, "ddm_schwarz_status: bad arguments");
+  int st = 0;
+  DDMCHECK(ddm_ilu0_status(ctx, S->solver, &st));
+  if (st) return fail(ctx, DDM_ENUMERIC, "local triangular solve timed out waiting for a dependency (code %d): results are invalid", st);
+  return DDM_OK;
+}
 // x (= or +=) R~^T [D] A_dir^-1 R~ d
 static int schwarz_apply_impl(ddm_ctx *ctx, ddm_schwarz *S, double *x, const double *d, bool acc)
 {
@@ -1413,6 +1431,11 @@ extern "C" int ddm_combined_create(ddm_ctx *ctx, int mode, ddm_op *op, ddm_schwa
   }
   *out = C;
   return DDM_OK;
+}
+extern "C" int ddm_combined_status(ddm_ctx *ctx, const ddm_combined *C)
+{
+  if (!C) return fail(ctx, DDM_EINVAL, "ddm_combined_status: bad arguments");
+  return C->schwarz ? ddm_schwarz_status(ctx, C->schwarz) : DDM_OK;
 }
 extern "C" void ddm_combined_destroy(ddm_combined *C)
 {

@@ -50,11 +50,13 @@ class Decomposition:
         return len(self.subs)
 
 
-def build_structured(grid, overlap=2, pou_type="distance", shrink=0, neumann=False) -> Decomposition:
+def build_structured(grid, overlap=2, pou_type="distance", shrink=0, neumann=False, second_region="overlap") -> Decomposition:
     """Runs the L3 setup of the reference (make_communication ->
-    make_overlapping_communication -> assemble_overlapping_matrices -> PartitionOfUnity) on a
-    synth.StructuredPoisson grid.  neumann=True also assembles A_neu (NeumannRegion::All) and
-    B_neu (NeumannRegion::Overlap) as examples/poisson.cc:206 requests for GenEO."""
+    make_overlapping_communication -> assemble_overlapping_matrices -> PartitionOfUnity) on one of the
+    synth problems (StructuredPoisson, StructuredDG2D, StructuredElasticity).  neumann=True also assembles
+    A_neu (NeumannRegion::All) and B_neu: on NeumannRegion::Overlap as examples/poisson.cc:206 and
+    examples/pdelab_schwarz.hh:62 request for GenEO, or, with second_region="all", the same matrix as A_neu
+    (examples/linearelasticity.hh:222)."""
     nov = grid.subdomains()
     ng = grid.nglobal
     if grid.nranks == 1:
@@ -68,7 +70,7 @@ def build_structured(grid, overlap=2, pou_type="distance", shrink=0, neumann=Fal
     ovlp_all = sh.interface_pairs(idx, ng, "all_to_all")
     ovlp_owner = sh.interface_pairs(idx, ng, "owner_to_all")
     dmask = [grid.dirichlet_of(i.glob) for i in idx]
-    A_dir = [grid.region_matrix(i.glob, None, dm, neumann=False) for i, dm in zip(idx, dmask)]
+    A_dir = [grid.dirichlet_matrix(i.glob, dm) for i, dm in zip(idx, dmask)]
     pou, bmask, dist = sh.partition_of_unity(idx, A_dir, ovlp_all, ng, pou_type, shrink, overlap)
     if bmask is None and neumann:
         bmask = sh.subdomain_boundary(idx, A_dir, ng)
@@ -77,8 +79,8 @@ def build_structured(grid, overlap=2, pou_type="distance", shrink=0, neumann=Fal
         sd = SubdomainData(r, i.n_o, len(i.glob), i.glob, s.A, s.owner, s.b, A_dir[r], i.owner, dmask[r], pou[r])
         if neumann:
             d = dist[r] if dist is not None else sh.bfs_distance(A_dir[r], bmask[r], 4 * overlap + 1)
-            sd.A_neu = grid.region_matrix(i.glob, None, dmask[r], neumann=True)
-            sd.B_neu = grid.region_matrix(i.glob, d <= 2 * overlap, dmask[r], neumann=True)
+            sd.A_neu = grid.neumann_matrix(i.glob, None, dmask[r])
+            sd.B_neu = sd.A_neu if second_region == "all" else grid.neumann_matrix(i.glob, d <= 2 * overlap, dmask[r])
         subs.append(sd)
     return Decomposition(subs, novlp_all, ovlp_owner, ovlp_all, overlap, ng,
                          {"pou_type": pou_type, "shrink": shrink, "ext_boundary": [i.ext_boundary for i in idx],

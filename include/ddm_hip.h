@@ -97,6 +97,8 @@ int64_t ddm_ilu0_num_levels(const ddm_ilu0 *F, int upper);
 /* status of the persistent (single-launch) triangular solve: 0 ok, 1 = a wave timed out waiting for a
  * dependency level (results invalid).  Synchronous.  DDM_TRSV_MODE=levels selects one launch per level. */
 int ddm_ilu0_status(ddm_ctx *ctx, const ddm_ilu0 *F, int *status);
+/* engine the next ddm_ilu0_solve uses: 8 = pipe, 4 = xcd2 (also when pipe declined the matrix), 0 = one launch per level */
+int ddm_ilu0_engine(const ddm_ilu0 *F);
 /* diagnostic: one solve with in-kernel cycle stamps of one compute wave */
 int ddm_ilu0_debug_stamps(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, unsigned long long *out6_host);
 /* diagnostic: one solve with the stamped build of the pipe engine's kernel (DDM_TRSV_MODE=pipe, the default); per task 272
@@ -147,6 +149,10 @@ int ddm_schwarz_create(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t nblocks, cons
 void ddm_schwarz_destroy(ddm_schwarz *S);
 int ddm_schwarz_apply(ddm_ctx *ctx, ddm_schwarz *S, double *x, const double *d); /* :115-149 */
 int64_t ddm_schwarz_num_levels(const ddm_schwarz *S, int upper); /* dependency levels of the local L / U solve */
+int ddm_schwarz_engine(const ddm_schwarz *S);                    /* ddm_ilu0_engine of the local solver */
+/* Synchronous: DDM_OK, or DDM_ENUMERIC if a local solve since creation gave up waiting (results invalid).  apply has no
+ * error return in the reference (schwarz.hh:131 discards the InverseOperatorResult); adaptors call this in post(). */
+int ddm_schwarz_status(ddm_ctx *ctx, const ddm_schwarz *S);
 
 /* ---- GalerkinPreconditioner (galerkin_preconditioner.hh:40-363) ---------------------------
  * basis_host: kmax x n row-major (vector j contiguous), zero rows where a subdomain has fewer
@@ -172,6 +178,7 @@ int ddm_galerkin_products(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t nleft, con
 int ddm_combined_create(ddm_ctx *ctx, int mode, ddm_op *op, ddm_schwarz *schwarz, ddm_galerkin *galerkin,
                         ddm_combined **out);
 void ddm_combined_destroy(ddm_combined *C);
+int ddm_combined_status(ddm_ctx *ctx, const ddm_combined *C); /* ddm_schwarz_status of the fine level */
 int ddm_combined_apply(ddm_ctx *ctx, ddm_combined *C, double *x, const double *d); /* :127-163 */
 
 /* ---- outer Krylov loop: dune-istl CGSolver::apply as driven by examples/poisson.cc:311-319 -- */
