@@ -69,6 +69,16 @@ SYMBOLS = {
     "ddm_ilu0_pipe_trace": (_I32, [_P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(ctypes.c_int64)]),
     "ddm_ilu0_num_levels": (_I64, [_P, _I32]),
     "ddm_ilu0_engine": (_I32, [_P]),
+    "ddm_chol_create": (_I32, [_P, _P, _I64, _P, _D, _PP]),
+    "ddm_ilu0_is_direct": (_I32, [_P]),
+    "ddm_ilu0_nnz": (_I64, [_P]),
+    "ddm_chol_host_create": (_I32, [_I64, _P, _P, _P, _I64, _P, _PP]),
+    "ddm_chol_host_destroy": (None, [_P]),
+    "ddm_chol_host_nnz": (_I64, [_P]),
+    "ddm_chol_host_nnz_factor": (_I64, [_P]),
+    "ddm_chol_host_flops": (_D, [_P]),
+    "ddm_chol_host_get": (_I32, [_P, _P, _P, _P, _P]),
+    "ddm_schwarz_create_ex": (_I32, [_P, _P, _I64, _P, _I64, _P, _P, _I32, ctypes.c_char_p, _P, _P, _PP]),
     "ddm_schwarz_engine": (_I32, [_P]),
     "ddm_schwarz_status": (_I32, [_P, _P]),
     "ddm_combined_status": (_I32, [_P, _P]),
@@ -235,13 +245,48 @@ class CsrMatrix:
             pass
 
 
+def chol_host(M, block_ptr=None, numeric=True):
+    """The host part of the sparse direct solver alone (ordering, symbolic analysis, numeric Cholesky; no device needed).
+    Returns dict(perm, rowptr, col, lu, nnzL, flops); lu follows the ILU(0) storage convention over the permuted indices."""
+    import scipy.sparse as sp
+    lib = load_library()
+    M = sp.csr_matrix(M)
+    if not M.has_sorted_indices:
+        M = M.sorted_indices()
+    n = M.shape[0]
+    bp = _np([0, n] if block_ptr is None else block_ptr, np.int64)
+    rp, ci, va = _np(M.indptr, np.int64), _np(M.indices, np.int32), _np(M.data, np.float64)
+    h = ctypes.c_void_p()
+    rc = lib.ddm_chol_host_create(n, _hp(rp), _hp(ci), _hp(va) if numeric else None, len(bp) - 1, _hp(bp), ctypes.byref(h))
+    if rc != DDM_OK:
+        raise DdmError(rc, "sparse Cholesky failed (DDM_ENUMERIC: matrix not positive definite)")
+    try:
+        nz = lib.ddm_chol_host_nnz(h)
+        out = {"perm": np.empty(n, dtype=np.int32), "rowptr": np.empty(n + 1, dtype=np.int64) if nz else None,
+               "col": np.empty(nz, dtype=np.int32) if nz else None, "lu": np.empty(nz, dtype=np.float64) if nz else None,
+               "nnzL": int(lib.ddm_chol_host_nnz_factor(h)), "flops": float(lib.ddm_chol_host_flops(h))}
+        lib.ddm_chol_host_get(h, _hp(out["perm"]), _hp(out["rowptr"]), _hp(out["col"]), _hp(out["lu"]))
+    finally:
+        lib.ddm_chol_host_destroy(h)
+    return out
+
+
 class Ilu0:
-    def __init__(self, ctx: Context, A: CsrMatrix, block_ptr=None):
+    """ddm_ilu0: a local factor solver -- ILU(0) in natural order, or (direct=True) the sparse Cholesky of ddm_chol_create."""
+
+    def __init__(self, ctx: Context, A: CsrMatrix, block_ptr=None, direct=False, max_flops=0.0):
         self.ctx, self.A = ctx, A
         bp = _np([0, A.shape[0]] if block_ptr is None else block_ptr, np.int64)
         h = ctypes.c_void_p()
-        ctx.check(ctx.lib.ddm_ilu0_create(ctx.h, A.h, len(bp) - 1, _hp(bp), ctypes.byref(h)))
+        if direct:
+            ctx.check(ctx.lib.ddm_chol_create(ctx.h, A.h, len(bp) - 1, _hp(bp), float(max_flops), ctypes.byref(h)))
+        else:
+            ctx.check(ctx.lib.ddm_ilu0_create(ctx.h, A.h, len(bp) - 1, _hp(bp), ctypes.byref(h)))
         self.h = h
+
+    @property
+    def nnz(self):
+        return int(self.ctx.lib.ddm_ilu0_nnz(self.h))
 
     def solve(self, d, x):
         self.ctx.check(self.ctx.lib.ddm_ilu0_solve(self.ctx.h, self.h, _ptr(d), _ptr(x)))
@@ -350,7 +395,7 @@ class SchwarzPreconditioner:
     TYPES = {"standard": 0, "restricted": 1}
 
     def __init__(self, ctx: Context, A_dir: CsrMatrix, block_ptr, n_novlp, ext_map, pou, type, ovlp_copy: Halo | None,
-                 ovlp_add: Halo | None):
+                 ovlp_add: Halo | None, subdomain_solver="ilu0"):
         if type not in self.TYPES:
             raise NotImplementedError("Unknown Schwarz type '" + str(type) + "'")   # schwarz.hh:83
         self.ctx = ctx
@@ -358,8 +403,9 @@ class SchwarzPreconditioner:
         em = _np(ext_map, np.int32)
         pw = None if pou is None else _np(pou, np.float64)
         h = ctypes.c_void_p()
-        ctx.check(ctx.lib.ddm_schwarz_create(ctx.h, A_dir.h, len(bp) - 1, _hp(bp), int(n_novlp), _hp(em), _hp(pw), self.TYPES[type],
-                                             ovlp_copy.h if ovlp_copy else None, ovlp_add.h if ovlp_add else None, ctypes.byref(h)))
+        ctx.check(ctx.lib.ddm_schwarz_create_ex(ctx.h, A_dir.h, len(bp) - 1, _hp(bp), int(n_novlp), _hp(em), _hp(pw), self.TYPES[type],
+                                                str(subdomain_solver).encode(), ovlp_copy.h if ovlp_copy else None,
+                                                ovlp_add.h if ovlp_add else None, ctypes.byref(h)))
         self.h = h
         self._keep = (A_dir, ovlp_copy, ovlp_add)
 

@@ -3,6 +3,7 @@
 #include "../../include/ddm_hip.h"
 #include "kernels.hpp"
 #include "trsv_pipe.hpp"
+#include "sparse_chol_host.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -429,6 +430,14 @@ struct ddm_ilu0 {
   pipe::Stats p_stats;
   int64_t p_stream_bytes = 0;
   unsigned *err = nullptr;
+  // sparse direct factor (ddm_chol_create): the factor lives in a fill-reducing order; d / x are permuted around the solve
+  ddm_csr *own_pattern = nullptr; // host-only CSR pattern of L + D + L^T in the permuted order (owned)
+  int32_t *perm = nullptr;        // device: perm[new] = old
+  double *pd = nullptr, *px = nullptr; // permuted right-hand side / solution (n doubles each)
+  double *pD = nullptr, *pX = nullptr; // the same for row-major blocks (n x pm_nrhs)
+  int pm_nrhs = 0;
+  int direct = 0;
+  double direct_flops = 0.0;
   std::vector<double> h_lu; // factor values in the pattern of A
   TriSchedule L, U;
   // HIP graph cache of the whole solve for one (d, x) pointer pair
@@ -541,6 +550,19 @@ static void free_schedule(TriSchedule &S)
 }
 
 static int build_pipe_schedule(ddm_ctx *ctx, ddm_ilu0 *F);
+// Level schedules, engine selection and the pipe schedule for factor values F->h_lu stored in the pattern of A.
+static int ilu0_build_engines(ddm_ctx *ctx, ddm_ilu0 *F, const ddm_csr *A, const std::vector<int64_t> &diag, int64_t nblocks, const int64_t *block_ptr)
+{
+  int rc = build_schedule(ctx, A, F->h_lu, diag, false, F->L);
+  if (!rc) rc = build_schedule(ctx, A, F->h_lu, diag, true, F->U);
+  if (const char *m = std::getenv("DDM_TRSV_MODE")) F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "xcd2") ? 4 : 8);
+  F->A = A;
+  F->h_diag = diag;
+  F->h_block_ptr.assign(block_ptr, block_ptr + nblocks + 1);
+  if (!rc && (hipMalloc((void **)&F->err, 128) != hipSuccess || hipMemset(F->err, 0, 128) != hipSuccess)) rc = fail(ctx, DDM_EHIP, "ILU(0): allocation failed");
+  if (!rc && F->mode == 8 && F->n > 0) rc = build_pipe_schedule(ctx, F); // part of the setup, not of the first solve (not applicable: pipe_state < 0, see ddm_ilu0_solve)
+  return rc;
+}
 extern "C" int ddm_ilu0_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, ddm_ilu0 **out)
 {
   if (!ctx || !A || !out || nblocks < 1 || !block_ptr) return fail(ctx, DDM_EINVAL, "ddm_ilu0_create: bad arguments");
@@ -571,14 +593,7 @@ extern "C" int ddm_ilu0_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, 
       if (rc == -3) return fail(ctx, DDM_EINVAL, "ILU(0): rows must have sorted column indices");
       return fail(ctx, DDM_ENUMERIC, "ILU(0): missing or zero pivot in block %lld", (long long)b);
     }
-  int rc = build_schedule(ctx, A, F->h_lu, diag, false, F->L);
-  if (!rc) rc = build_schedule(ctx, A, F->h_lu, diag, true, F->U);
-  if (const char *m = std::getenv("DDM_TRSV_MODE")) F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "xcd2") ? 4 : 8);
-  F->A = A;
-  F->h_diag = diag;
-  F->h_block_ptr.assign(block_ptr, block_ptr + nblocks + 1);
-  if (!rc && (hipMalloc((void **)&F->err, 128) != hipSuccess || hipMemset(F->err, 0, 128) != hipSuccess)) rc = fail(ctx, DDM_EHIP, "ILU(0): allocation failed");
-  if (!rc && F->mode == 8 && F->n > 0) rc = build_pipe_schedule(ctx, F); // part of the setup, not of the first solve (not applicable: pipe_state < 0, see ddm_ilu0_solve)
+  const int rc = ilu0_build_engines(ctx, F, A, diag, nblocks, block_ptr);
   if (rc) {
     ddm_ilu0_destroy(F);
     return rc;
@@ -586,11 +601,165 @@ extern "C" int ddm_ilu0_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, 
   *out = F;
   return DDM_OK;
 }
+
+// ---- sparse direct local solver (host Cholesky, device triangular solves) ----------------------------------------
+struct CholResult {
+  std::vector<int32_t> perm; // perm[new] = old (rank-local indices; blocks stay contiguous)
+  std::vector<int64_t> rp, diag;
+  std::vector<int32_t> ci;
+  std::vector<double> lu;
+  double flops = 0.0;
+  int64_t nnzL = 0;
+  std::string error;
+};
+// rc: DDM_OK, DDM_ENOTIMPL (more than max_flops: nothing was factorised), DDM_ENUMERIC (not positive definite), DDM_EINVAL
+static int chol_build(int64_t n, const int64_t *rp, const int32_t *ci, const double *va, int64_t nblocks, const int64_t *block_ptr, double max_flops,
+                      bool numeric, CholResult &R)
+{
+  if (n < 0 || !rp || !ci || nblocks < 1 || !block_ptr || block_ptr[0] != 0 || block_ptr[nblocks] != n) {
+    R.error = "bad arguments";
+    return DDM_EINVAL;
+  }
+  std::vector<chol::BlockFactor> BF((size_t)nblocks);
+  std::vector<chol::PermutedLower> PL((size_t)nblocks);
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const int nthreads = (int)std::min<int64_t>(nblocks, hw);
+  auto parallel = [&](auto fn) {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t)
+      th.emplace_back([&, t]() {
+        for (int64_t b = t; b < nblocks; b += nthreads) fn(b);
+      });
+    for (auto &t : th) t.join();
+  };
+  std::vector<int> bad((size_t)nblocks, 0);
+  parallel([&](int64_t b) {
+    const int64_t r0 = block_ptr[b], r1 = block_ptr[b + 1];
+    for (int64_t i = r0; i < r1 && !bad[(size_t)b]; ++i)
+      for (int64_t k = rp[i]; k < rp[i + 1]; ++k)
+        if (ci[k] < r0 || ci[k] >= r1) bad[(size_t)b] = 1;
+    if (bad[(size_t)b]) return;
+    chol::Graph G = chol::block_graph(rp, ci, r0, r1);
+    BF[(size_t)b].perm = chol::nested_dissection(G);
+    PL[(size_t)b] = chol::permute_lower(rp, ci, va, r0, r1, BF[(size_t)b].perm);
+    chol::analyze(PL[(size_t)b], (int32_t)(r1 - r0), BF[(size_t)b]);
+  });
+  for (int64_t b = 0; b < nblocks; ++b)
+    if (bad[(size_t)b]) {
+      R.error = "block " + std::to_string(b) + " has entries outside its diagonal block";
+      return DDM_EINVAL;
+    }
+  R.flops = 0.0;
+  R.nnzL = 0;
+  for (auto &f : BF) {
+    R.flops += f.flops;
+    R.nnzL += f.nnzL;
+  }
+  R.perm.resize((size_t)n);
+  for (int64_t b = 0; b < nblocks; ++b)
+    for (int32_t k = 0; k < BF[(size_t)b].n; ++k) R.perm[(size_t)(block_ptr[b] + k)] = (int32_t)(block_ptr[b] + BF[(size_t)b].perm[(size_t)k]);
+  if (max_flops > 0.0 && R.flops > max_flops) {
+    R.error = "sparse Cholesky needs " + std::to_string(R.flops) + " flops (limit " + std::to_string(max_flops) + ")";
+    return DDM_ENOTIMPL;
+  }
+  if (!numeric) return DDM_OK;
+  if (!va) {
+    R.error = "bad arguments";
+    return DDM_EINVAL;
+  }
+  parallel([&](int64_t b) {
+    if (!chol::factorize(PL[(size_t)b], BF[(size_t)b])) bad[(size_t)b] = 1;
+    PL[(size_t)b] = chol::PermutedLower(); // release
+  });
+  for (int64_t b = 0; b < nblocks; ++b)
+    if (bad[(size_t)b]) {
+      R.error = "block " + std::to_string(b) + ": " + BF[(size_t)b].error;
+      return DDM_ENUMERIC;
+    }
+  R.rp.assign(1, 0);
+  R.rp.reserve((size_t)n + 1);
+  R.diag.reserve((size_t)n);
+  for (int64_t b = 0; b < nblocks; ++b) {
+    chol::append_rows(BF[(size_t)b], block_ptr[b], R.rp, R.ci, R.lu, R.diag);
+    BF[(size_t)b] = chol::BlockFactor();
+  }
+  return DDM_OK;
+}
+
+struct ddm_chol_host {
+  CholResult R;
+};
+extern "C" int ddm_chol_host_create(int64_t n, const int64_t *rp, const int32_t *ci, const double *va, int64_t nblocks, const int64_t *block_ptr,
+                                    ddm_chol_host **out)
+{
+  if (!out) return DDM_EINVAL;
+  ddm_chol_host *H = new ddm_chol_host;
+  const int rc = chol_build(n, rp, ci, va, nblocks, block_ptr, 0.0, va != nullptr, H->R);
+  if (rc) {
+    delete H;
+    return rc;
+  }
+  *out = H;
+  return DDM_OK;
+}
+extern "C" void ddm_chol_host_destroy(ddm_chol_host *H) { delete H; }
+extern "C" int64_t ddm_chol_host_nnz(const ddm_chol_host *H) { return H ? (int64_t)H->R.ci.size() : 0; }
+extern "C" int64_t ddm_chol_host_nnz_factor(const ddm_chol_host *H) { return H ? H->R.nnzL : 0; }
+extern "C" double ddm_chol_host_flops(const ddm_chol_host *H) { return H ? H->R.flops : 0.0; }
+extern "C" int ddm_chol_host_get(const ddm_chol_host *H, int32_t *perm, int64_t *rp, int32_t *ci, double *lu)
+{
+  if (!H) return DDM_EINVAL;
+  if (perm) std::copy(H->R.perm.begin(), H->R.perm.end(), perm);
+  if (rp) std::copy(H->R.rp.begin(), H->R.rp.end(), rp);
+  if (ci) std::copy(H->R.ci.begin(), H->R.ci.end(), ci);
+  if (lu) std::copy(H->R.lu.begin(), H->R.lu.end(), lu);
+  return DDM_OK;
+}
+
+extern "C" int ddm_chol_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, double max_flops, ddm_ilu0 **out)
+{
+  if (!ctx || !A || !out || nblocks < 1 || !block_ptr) return fail(ctx, DDM_EINVAL, "ddm_chol_create: bad arguments");
+  if (A->nrows != A->ncols) return fail(ctx, DDM_EINVAL, "the sparse direct solver needs a square matrix");
+  CholResult R;
+  const int rc0 = chol_build(A->nrows, A->h_rp.data(), A->h_ci.data(), A->h_va.data(), nblocks, block_ptr, max_flops, true, R);
+  if (rc0) return fail(ctx, rc0, "ddm_chol_create: %s", R.error.c_str());
+  ddm_ilu0 *F = new ddm_ilu0;
+  F->n = A->nrows;
+  F->nnz = (int64_t)R.ci.size();
+  F->direct = 1;
+  F->direct_flops = R.flops;
+  F->h_lu = std::move(R.lu);
+  ddm_csr *P = new ddm_csr; // host-only pattern of the factor (the schedule builders read h_rp / h_ci)
+  P->nrows = P->ncols = A->nrows;
+  P->nnz = F->nnz;
+  P->h_rp = std::move(R.rp);
+  P->h_ci = std::move(R.ci);
+  F->own_pattern = P;
+  int rc = ilu0_build_engines(ctx, F, P, R.diag, nblocks, block_ptr);
+  if (!rc) rc = upload(ctx, R.perm.data(), A->nrows, &F->perm);
+  if (!rc && (hipMalloc((void **)&F->pd, sizeof(double) * (size_t)std::max<int64_t>(F->n, 1)) != hipSuccess ||
+              hipMalloc((void **)&F->px, sizeof(double) * (size_t)std::max<int64_t>(F->n, 1)) != hipSuccess))
+    rc = fail(ctx, DDM_EHIP, "ddm_chol_create: allocation failed");
+  if (rc) {
+    ddm_ilu0_destroy(F);
+    return rc;
+  }
+  *out = F;
+  return DDM_OK;
+}
+extern "C" int ddm_ilu0_is_direct(const ddm_ilu0 *F) { return F ? F->direct : 0; }
+extern "C" int64_t ddm_ilu0_nnz(const ddm_ilu0 *F) { return F ? F->nnz : 0; }
 extern "C" void ddm_ilu0_destroy(ddm_ilu0 *F)
 {
   if (!F) return;
   if (F->graph) (void)hipGraphExecDestroy(F->graph);
   (void)hipFree(F->err);
+  (void)hipFree(F->perm);
+  (void)hipFree(F->pd);
+  (void)hipFree(F->px);
+  (void)hipFree(F->pD);
+  (void)hipFree(F->pX);
+  delete F->own_pattern; // host-only pattern: no device arrays
   (void)hipFree(F->xg);
   (void)hipFree(F->xdesc);
   (void)hipFree(F->xflag_off);
@@ -936,6 +1105,13 @@ extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double
   hipGraph_t g = nullptr;
   HIPCHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
   int rc = DDM_OK;
+  const double *d_user = d;
+  double *x_user = x;
+  if (F->perm) { // sparse direct factor: solve in the fill-reducing order
+    hipLaunchKernelGGL(k_perm_gather, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, 1, F->perm, d_user, F->pd);
+    d = F->pd;
+    x = F->px;
+  }
   if (F->mode == 8) {
     enqueue_pipe(ctx, F, d, x, nullptr);
   } else if (F->mode == 4) {
@@ -947,6 +1123,9 @@ extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double
     rc = enqueue_tri(ctx, F->L, false, d, x);
     if (!rc) rc = enqueue_tri(ctx, F->U, true, d, x);
   }
+  if (F->perm) hipLaunchKernelGGL(k_perm_scatter, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, 1, F->perm, (const double *)F->px, x_user);
+  d = d_user;
+  x = x_user;
   hipError_t e = hipStreamEndCapture(ctx->stream, &g);
   if (rc) return rc;
   if (e != hipSuccess) return fail(ctx, DDM_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
@@ -967,6 +1146,22 @@ extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double
 extern "C" int ddm_ilu0_solve_multi(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double *D, double *X)
 {
   if (!F || !D || !X || D == X || nrhs < 1) return fail(ctx, DDM_EINVAL, "ddm_ilu0_solve_multi: bad arguments");
+  const double *D_user = D;
+  double *X_user = X;
+  if (F->perm) {
+    if (F->pm_nrhs < nrhs) {
+      (void)hipFree(F->pD);
+      (void)hipFree(F->pX);
+      F->pD = F->pX = nullptr;
+      F->pm_nrhs = 0;
+      HIPCHECK(ctx, hipMalloc((void **)&F->pD, sizeof(double) * (size_t)std::max<int64_t>(F->n, 1) * (size_t)nrhs));
+      HIPCHECK(ctx, hipMalloc((void **)&F->pX, sizeof(double) * (size_t)std::max<int64_t>(F->n, 1) * (size_t)nrhs));
+      F->pm_nrhs = nrhs;
+    }
+    hipLaunchKernelGGL(k_perm_gather, dim3(grid_for(F->n * nrhs)), dim3(WG), 0, ctx->stream, F->n, nrhs, F->perm, D_user, F->pD);
+    D = F->pD;
+    X = F->pX;
+  }
   for (int pass = 0; pass < 2; ++pass) {
     const TriSchedule &S = pass ? F->U : F->L;
     for (int64_t l = 0; l < S.nlev; ++l) {
@@ -982,6 +1177,7 @@ extern "C" int ddm_ilu0_solve_multi(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const d
                            S.cols + L.ent_off, S.vals + L.ent_off, (const double *)nullptr, D, X);
     }
   }
+  if (F->perm) hipLaunchKernelGGL(k_perm_scatter, dim3(grid_for(F->n * nrhs)), dim3(WG), 0, ctx->stream, F->n, nrhs, F->perm, (const double *)F->pX, X_user);
   HIPCHECK(ctx, hipGetLastError());
   return DDM_OK;
 }
@@ -1170,7 +1366,19 @@ extern "C" int ddm_schwarz_create(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t nb
                                   const int32_t *ext_map_host, const double *pou_host, int type, ddm_halo *ovlp_copy,
                                   ddm_halo *ovlp_add, ddm_schwarz **out)
 {
+  return ddm_schwarz_create_ex(ctx, A_dir, nblocks, block_ptr, n_novlp, ext_map_host, pou_host, type, "ilu0", ovlp_copy, ovlp_add, out);
+}
+// subdomain_solver: the `type` key of the [schwarz.subdomain_solver] sub-tree (schwarz.hh:85-92): "ilu0" (dune-istl's SeqILU,
+// n = 0) or one of "cholmod" / "ldl" / "spqr"-less synonyms "direct", "cholesky" for the sparse direct solver of this library
+// (SPD matrices; "umfpack" is accepted for symmetric positive definite input only).
+extern "C" int ddm_schwarz_create_ex(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t nblocks, const int64_t *block_ptr, int64_t n_novlp,
+                                     const int32_t *ext_map_host, const double *pou_host, int type, const char *subdomain_solver,
+                                     ddm_halo *ovlp_copy, ddm_halo *ovlp_add, ddm_schwarz **out)
+{
   if (!ctx || !A_dir || !out || !ext_map_host) return fail(ctx, DDM_EINVAL, "ddm_schwarz_create: bad arguments");
+  const std::string st = subdomain_solver ? subdomain_solver : "ilu0";
+  const bool direct = st == "cholmod" || st == "direct" || st == "cholesky" || st == "umfpack" || st == "ldl";
+  if (!direct && st != "ilu0" && st != "ilu") return fail(ctx, DDM_ENOTIMPL, "Unknown subdomain solver type '%s'", st.c_str()); // solver factory lookup (:85-92)
   if (type != 0 && type != 1) return fail(ctx, DDM_ENOTIMPL, "Unknown Schwarz type %d", type); // schwarz.hh:83
   if (ovlp_copy && ovlp_copy->mode != 0) return fail(ctx, DDM_EINVAL, "ovlp_copy must be a 'copy' halo");
   if (ovlp_add && ovlp_add->mode != 1) return fail(ctx, DDM_EINVAL, "ovlp_add must be an 'add' halo");
@@ -1183,7 +1391,8 @@ extern "C" int ddm_schwarz_create(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t nb
   S->type = type;
   S->copy = ovlp_copy;
   S->add = ovlp_add;
-  int rc = ddm_ilu0_create(ctx, A_dir, nblocks, block_ptr, &S->solver); // factorisation happens in the ctor (:92)
+  int rc = direct ? ddm_chol_create(ctx, A_dir, nblocks, block_ptr, 0.0, &S->solver)
+                  : ddm_ilu0_create(ctx, A_dir, nblocks, block_ptr, &S->solver); // factorisation happens in the ctor (:92)
   if (!rc) rc = upload(ctx, ext_map_host, n, &S->ext_map);
   if (!rc && pou_host) rc = upload(ctx, pou_host, n, &S->pou);
   if (!rc && hipMalloc((void **)&S->d_ovlp, sizeof(double) * (size_t)std::max<int64_t>(n, 1)) != hipSuccess) rc = fail(ctx, DDM_EHIP, "alloc");

@@ -627,6 +627,23 @@ __global__ void k_w_permute_out(int64_t n, const int64_t *__restrict__ upos, con
 
 // ---------------------------------------------------------------------------------------------
 // K2 extend (schwarz.hh:121-122), K5 restrict (schwarz.hh:146), K4 POU scaling (schwarz.hh:141)
+// dst[i,:] = src[perm[i],:] / dst[perm[i],:] = src[i,:] for row-major n x nrhs blocks (fill-reducing order of the direct solver)
+__global__ void k_perm_gather(int64_t n, int nrhs, const int32_t *__restrict__ perm, const double *__restrict__ src, double *__restrict__ dst)
+{
+  const int64_t tot = n * nrhs;
+  for (int64_t t = blockIdx.x * (int64_t)WG + threadIdx.x; t < tot; t += (int64_t)gridDim.x * WG) {
+    const int64_t i = t / nrhs;
+    dst[t] = src[(int64_t)perm[i] * nrhs + (t - i * nrhs)];
+  }
+}
+__global__ void k_perm_scatter(int64_t n, int nrhs, const int32_t *__restrict__ perm, const double *__restrict__ src, double *__restrict__ dst)
+{
+  const int64_t tot = n * nrhs;
+  for (int64_t t = blockIdx.x * (int64_t)WG + threadIdx.x; t < tot; t += (int64_t)gridDim.x * WG) {
+    const int64_t i = t / nrhs;
+    dst[(int64_t)perm[i] * nrhs + (t - i * nrhs)] = src[t];
+  }
+}
 __global__ void k_extend(int64_t n, const int32_t *__restrict__ ext_map, const double *__restrict__ d, double *__restrict__ dov)
 {
   for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG) {

@@ -111,6 +111,30 @@ int ddm_ilu0_pipe_trace(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, u
 /* factor values in the pattern of A (inverse pivots on the diagonal), for parity tests */
 int ddm_ilu0_get_factors_host(ddm_ctx *ctx, const ddm_ilu0 *F, double *lu_host);
 
+/* ---- sparse direct local solver -------------------------------------------------------------
+ * What the reference gets from SuiteSparse through the solver factory: [subdomain_solver] type = cholmod / umfpack
+ * (schwarz.hh:85-92, examples/poisson.ini:23,26) and the factorisation of A - sigma B inside the GenEO eigensolver
+ * (eigensolvers/spectra.hh:28-89).  Sparse Cholesky of a symmetric positive definite block-diagonal matrix: nested-dissection
+ * ordering, symbolic analysis and numeric factorisation on host threads (setup work, one thread per block, like the ILU(0)
+ * factorisation); the factor is handed to the same device triangular-solve engines as an ILU(0) factor (the returned object IS a
+ * ddm_ilu0: ddm_ilu0_solve / _solve_multi / _destroy apply), solves run in the fill-reducing order with a permutation on either side.
+ * max_flops > 0: analyse first and return DDM_ENOTIMPL without factorising if the factorisation needs more floating-point
+ * operations (sum of squared column counts) -- the caller then stays with ILU(0).  DDM_ENUMERIC: not positive definite. */
+int ddm_chol_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, double max_flops, ddm_ilu0 **out);
+int ddm_ilu0_is_direct(const ddm_ilu0 *F); /* 1 for a ddm_chol_create factor */
+int64_t ddm_ilu0_nnz(const ddm_ilu0 *F);   /* stored factor entries (L + D + U) */
+/* The host part alone (no device needed; used by the CPU tests): va == NULL stops after the symbolic analysis.
+ * get: perm[n] (perm[new] = old), and the factor in the storage convention of ddm_ilu0_get_factors_host -- CSR over the
+ * PERMUTED indices with pattern L + D + L^T: unit lower factor, inverse pivots on the diagonal, D L^T above. */
+typedef struct ddm_chol_host ddm_chol_host;
+int ddm_chol_host_create(int64_t n, const int64_t *rowptr, const int32_t *col, const double *val, int64_t nblocks,
+                         const int64_t *block_ptr, ddm_chol_host **out);
+void ddm_chol_host_destroy(ddm_chol_host *H);
+int64_t ddm_chol_host_nnz(const ddm_chol_host *H);        /* entries of the factor CSR (0 after a symbolic-only run) */
+int64_t ddm_chol_host_nnz_factor(const ddm_chol_host *H); /* nnz(L) from the symbolic analysis */
+double ddm_chol_host_flops(const ddm_chol_host *H);       /* sum of squared column counts */
+int ddm_chol_host_get(const ddm_chol_host *H, int32_t *perm, int64_t *rowptr, int32_t *col, double *lu);
+
 /* ---- halo exchange plan: one per DUNE interface -------------------------------------------
  * (copyOwnerToAll: schwarz.hh:125, galerkin_preconditioner.hh:162;
  *  addOwnerCopyToOwnerCopy: nonoverlapping_operator.hh:38,48, schwarz.hh:138,142;
@@ -146,6 +170,11 @@ int ddm_norm(ddm_ctx *ctx, ddm_op *op, const double *x, double *result_host);   
 int ddm_schwarz_create(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t nblocks, const int64_t *block_ptr, int64_t n_novlp,
                        const int32_t *ext_map_host, const double *pou_host, int type, ddm_halo *ovlp_copy,
                        ddm_halo *ovlp_add, ddm_schwarz **out);
+/* the same with the `type` key of [schwarz.subdomain_solver] (schwarz.hh:85-92): "ilu0" (default of ddm_schwarz_create) or
+ * "cholmod" / "umfpack" / "ldl" / "direct" = this library's sparse Cholesky (SPD input; DDM_ENUMERIC otherwise) */
+int ddm_schwarz_create_ex(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t nblocks, const int64_t *block_ptr, int64_t n_novlp,
+                          const int32_t *ext_map_host, const double *pou_host, int type, const char *subdomain_solver,
+                          ddm_halo *ovlp_copy, ddm_halo *ovlp_add, ddm_schwarz **out);
 void ddm_schwarz_destroy(ddm_schwarz *S);
 int ddm_schwarz_apply(ddm_ctx *ctx, ddm_schwarz *S, double *x, const double *d); /* :115-149 */
 int64_t ddm_schwarz_num_levels(const ddm_schwarz *S, int upper); /* dependency levels of the local L / U solve */
