@@ -35,6 +35,18 @@ class SolveResult(ctypes.Structure):
                 ("reduction", ctypes.c_double), ("elapsed_s", ctypes.c_double)]
 
 
+class GeneoParams(ctypes.Structure):
+    """ddm_geneo_params: the keys of `<prefix>.eigensolver` (dune/ddm/eigensolvers/eigensolver_params.hh:8-62)"""
+    _fields_ = [("nev", ctypes.c_int32), ("nev_max", ctypes.c_int32), ("tolerance", ctypes.c_double), ("shift", ctypes.c_double),
+                ("threshold", ctypes.c_double), ("maxit", ctypes.c_int32), ("extra", ctypes.c_int32), ("seed", ctypes.c_int32),
+                ("preconditioner", ctypes.c_int32), ("max_direct_flops", ctypes.c_double), ("verbose", ctypes.c_int32)]
+
+
+class GeneoInfo(ctypes.Structure):
+    _fields_ = [("iterations", ctypes.c_int32), ("converged", ctypes.c_int32), ("used_direct", ctypes.c_int32), ("nev", ctypes.c_int32),
+                ("worst_residual", ctypes.c_double), ("setup_s", ctypes.c_double), ("iterate_s", ctypes.c_double), ("direct_flops", ctypes.c_double)]
+
+
 A2A_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
 
@@ -102,6 +114,12 @@ SYMBOLS = {
     "ddm_galerkin_destroy": (None, [_P]),
     "ddm_galerkin_apply": (_I32, [_P, _P, _P, _P]),
     "ddm_galerkin_products": (_I32, [_P, _P, _I64, _P, _I64, _P, _I64, _I64, _P]),
+    "ddm_geneo_params_default": (_I32, [ctypes.POINTER(GeneoParams)]),
+    "ddm_geneo_basis": (_I32, [_P, _P, _P, _I64, _P, _P, _P, ctypes.POINTER(GeneoParams), _I64, _P, _P, _P, ctypes.POINTER(GeneoInfo)]),
+    "ddm_blockvec_gram": (_I32, [_P, _I64, _P, _P, _I64, _I32, _P, _I64, _I32, _P]),
+    "ddm_blockvec_rotate": (_I32, [_P, _I64, _P, _P, _I64, _I32, _P, _I32, _P, _I64, _P, _I64]),
+    "ddm_dense_sym_eig_host": (_I32, [_I32, _P, _P]),
+    "ddm_dense_rayleigh_ritz_host": (_I32, [_I32, _P, _P, _I32, _D, _P, _P]),
     "ddm_combined_create": (_I32, [_P, _I32, _P, _P, _P, _PP]),
     "ddm_combined_destroy": (None, [_P]),
     "ddm_combined_apply": (_I32, [_P, _P, _P, _P]),
@@ -524,3 +542,20 @@ class CgIteration:
         if self.h:
             self.ctx.lib.ddm_cg_end(self.ctx.h, self.h)
             self.h = None
+
+
+def blockvec_gram(ctx: Context, sub_ptr, U, V):
+    """per-subdomain U^T V of row-major device tensors (n, pu), (n, pv) -> ndarray (nsub, pu, pv)"""
+    bp = _np(sub_ptr, np.int64)
+    assert U.is_contiguous() and V.is_contiguous() and U.shape[0] == V.shape[0] == bp[-1]
+    out = np.empty((len(bp) - 1, U.shape[1], V.shape[1]), dtype=np.float64)
+    ctx.check(ctx.lib.ddm_blockvec_gram(ctx.h, len(bp) - 1, _hp(bp), _ptr(U), U.stride(0), U.shape[1], _ptr(V), V.stride(0), V.shape[1], _hp(out)))
+    return out
+
+
+def blockvec_rotate(ctx: Context, sub_ptr, U, Y, out, base=None):
+    """out[rows of s] = (base[rows of s] -) U[rows of s] @ Y[s]; U (n, p), Y ndarray (nsub, p, q), out (n, >= q) device tensors"""
+    bp = _np(sub_ptr, np.int64)
+    Yh = _np(Y, np.float64)
+    ctx.check(ctx.lib.ddm_blockvec_rotate(ctx.h, len(bp) - 1, _hp(bp), _ptr(U), U.stride(0), U.shape[1], _hp(Yh), Yh.shape[2],
+                                          _ptr(base) if base is not None else None, base.stride(0) if base is not None else 0, _ptr(out), out.stride(0)))

@@ -335,17 +335,18 @@ extern "C" int ddm_csr_usmv(ddm_ctx *ctx, const ddm_csr *A, double alpha, const 
   return csr_mv_impl(ctx, A, alpha, x, y, true);
 }
 
-// Y = A X, row-major n x nrhs block vectors (MatOp::perform_op on a block; spectra.hh:100-105)
-extern "C" int ddm_csr_mm(ddm_ctx *ctx, const ddm_csr *A, int nrhs, const double *X, double *Y)
+// Y = A X, row-major n x nrhs block vectors with leading dimensions ldx / ldy (MatOp::perform_op on a block; spectra.hh:100-105)
+static int csr_mm_ld(ddm_ctx *ctx, const ddm_csr *A, int nrhs, const double *X, int64_t ldx, double *Y, int64_t ldy)
 {
-  if (!A || !X || !Y || X == Y || nrhs < 1) return fail(ctx, DDM_EINVAL, "ddm_csr_mm: bad arguments");
+  if (!A || !X || !Y || X == Y || nrhs < 1 || ldx < nrhs || ldy < nrhs) return fail(ctx, DDM_EINVAL, "ddm_csr_mm: bad arguments");
   const int64_t threads = A->nrows * (int64_t)nrhs;
   if (threads == 0) return DDM_OK;
   hipLaunchKernelGGL(k_spmm_rowmajor, dim3((unsigned)((threads + WG - 1) / WG)), dim3(WG), 0, ctx->stream, A->nrows, nrhs, A->rp, A->ci,
-                     A->va, X, Y);
+                     A->va, X, ldx, Y, ldy);
   HIPCHECK(ctx, hipGetLastError());
   return DDM_OK;
 }
+extern "C" int ddm_csr_mm(ddm_ctx *ctx, const ddm_csr *A, int nrhs, const double *X, double *Y) { return csr_mm_ld(ctx, A, nrhs, X, nrhs, Y, nrhs); }
 
 // ---- ILU(0) -----------------------------------------------------------------------------------
 // Host factorisation: dune-istl blockILU0Decomposition semantics (IKJ in the pattern, multipliers
@@ -440,6 +441,12 @@ struct ddm_ilu0 {
   double direct_flops = 0.0;
   std::vector<double> h_lu; // factor values in the pattern of A
   TriSchedule L, U;
+  // HIP graph cache of the multi-RHS solve for one (D, X, nrhs, ld) combination
+  hipGraphExec_t mgraph = nullptr;
+  const double *mg_D = nullptr;
+  double *mg_X = nullptr;
+  int mg_nrhs = 0;
+  int64_t mg_ldd = 0, mg_ldx = 0;
   // HIP graph cache of the whole solve for one (d, x) pointer pair
   hipGraphExec_t graph = nullptr;
   const double *g_d = nullptr;
@@ -551,11 +558,13 @@ static void free_schedule(TriSchedule &S)
 
 static int build_pipe_schedule(ddm_ctx *ctx, ddm_ilu0 *F);
 // Level schedules, engine selection and the pipe schedule for factor values F->h_lu stored in the pattern of A.
-static int ilu0_build_engines(ddm_ctx *ctx, ddm_ilu0 *F, const ddm_csr *A, const std::vector<int64_t> &diag, int64_t nblocks, const int64_t *block_ptr)
+static int ilu0_build_engines(ddm_ctx *ctx, ddm_ilu0 *F, const ddm_csr *A, const std::vector<int64_t> &diag, int64_t nblocks, const int64_t *block_ptr,
+                              bool multi_rhs_only = false)
 {
   int rc = build_schedule(ctx, A, F->h_lu, diag, false, F->L);
   if (!rc) rc = build_schedule(ctx, A, F->h_lu, diag, true, F->U);
   if (const char *m = std::getenv("DDM_TRSV_MODE")) F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "xcd2") ? 4 : 8);
+  if (multi_rhs_only) F->mode = 0; // only ddm_ilu0_solve_multi will be called (level kernels): no pipe schedule, no tile stream
   F->A = A;
   F->h_diag = diag;
   F->h_block_ptr.assign(block_ptr, block_ptr + nblocks + 1);
@@ -563,7 +572,12 @@ static int ilu0_build_engines(ddm_ctx *ctx, ddm_ilu0 *F, const ddm_csr *A, const
   if (!rc && F->mode == 8 && F->n > 0) rc = build_pipe_schedule(ctx, F); // part of the setup, not of the first solve (not applicable: pipe_state < 0, see ddm_ilu0_solve)
   return rc;
 }
+static int ilu0_create_impl(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, bool multi_rhs_only, ddm_ilu0 **out);
 extern "C" int ddm_ilu0_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, ddm_ilu0 **out)
+{
+  return ilu0_create_impl(ctx, A, nblocks, block_ptr, false, out);
+}
+static int ilu0_create_impl(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, bool multi_rhs_only, ddm_ilu0 **out)
 {
   if (!ctx || !A || !out || nblocks < 1 || !block_ptr) return fail(ctx, DDM_EINVAL, "ddm_ilu0_create: bad arguments");
   if (A->nrows != A->ncols) return fail(ctx, DDM_EINVAL, "ILU(0) needs a square matrix");
@@ -593,7 +607,7 @@ extern "C" int ddm_ilu0_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, 
       if (rc == -3) return fail(ctx, DDM_EINVAL, "ILU(0): rows must have sorted column indices");
       return fail(ctx, DDM_ENUMERIC, "ILU(0): missing or zero pivot in block %lld", (long long)b);
     }
-  const int rc = ilu0_build_engines(ctx, F, A, diag, nblocks, block_ptr);
+  const int rc = ilu0_build_engines(ctx, F, A, diag, nblocks, block_ptr, multi_rhs_only);
   if (rc) {
     ddm_ilu0_destroy(F);
     return rc;
@@ -753,6 +767,7 @@ extern "C" void ddm_ilu0_destroy(ddm_ilu0 *F)
 {
   if (!F) return;
   if (F->graph) (void)hipGraphExecDestroy(F->graph);
+  if (F->mgraph) (void)hipGraphExecDestroy(F->mgraph);
   (void)hipFree(F->err);
   (void)hipFree(F->perm);
   (void)hipFree(F->pd);
@@ -1108,7 +1123,7 @@ extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double
   const double *d_user = d;
   double *x_user = x;
   if (F->perm) { // sparse direct factor: solve in the fill-reducing order
-    hipLaunchKernelGGL(k_perm_gather, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, 1, F->perm, d_user, F->pd);
+    hipLaunchKernelGGL(k_perm_gather, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, 1, F->perm, d_user, (int64_t)1, F->pd);
     d = F->pd;
     x = F->px;
   }
@@ -1123,7 +1138,7 @@ extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double
     rc = enqueue_tri(ctx, F->L, false, d, x);
     if (!rc) rc = enqueue_tri(ctx, F->U, true, d, x);
   }
-  if (F->perm) hipLaunchKernelGGL(k_perm_scatter, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, 1, F->perm, (const double *)F->px, x_user);
+  if (F->perm) hipLaunchKernelGGL(k_perm_scatter, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, 1, F->perm, (const double *)F->px, x_user, (int64_t)1);
   d = d_user;
   x = x_user;
   hipError_t e = hipStreamEndCapture(ctx->stream, &g);
@@ -1141,46 +1156,84 @@ extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double
   return DDM_OK;
 }
 
-// Multi-RHS solve X = (LU)^-1 D for row-major n x nrhs block vectors (GenEO setup path; eager
-// launches, one per level -- the per-level work is nrhs times larger, so launch overhead matters less).
-extern "C" int ddm_ilu0_solve_multi(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double *D, double *X)
+// Multi-RHS solve X = (LU)^-1 D for row-major n x nrhs block vectors with leading dimensions ldd / ldx (GenEO setup path).
+// One launch per level (wide levels of direct factors: one workgroup per row); the launches of one (D, X, nrhs) combination are
+// captured into a HIP graph on first use and replayed afterwards (the block eigensolver calls with the same buffers every iteration).
+static void enqueue_multi_levels(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double *D, int64_t ldd, double *X, int64_t ldx)
 {
-  if (!F || !D || !X || D == X || nrhs < 1) return fail(ctx, DDM_EINVAL, "ddm_ilu0_solve_multi: bad arguments");
-  const double *D_user = D;
-  double *X_user = X;
-  if (F->perm) {
-    if (F->pm_nrhs < nrhs) {
-      (void)hipFree(F->pD);
-      (void)hipFree(F->pX);
-      F->pD = F->pX = nullptr;
-      F->pm_nrhs = 0;
-      HIPCHECK(ctx, hipMalloc((void **)&F->pD, sizeof(double) * (size_t)std::max<int64_t>(F->n, 1) * (size_t)nrhs));
-      HIPCHECK(ctx, hipMalloc((void **)&F->pX, sizeof(double) * (size_t)std::max<int64_t>(F->n, 1) * (size_t)nrhs));
-      F->pm_nrhs = nrhs;
-    }
-    hipLaunchKernelGGL(k_perm_gather, dim3(grid_for(F->n * nrhs)), dim3(WG), 0, ctx->stream, F->n, nrhs, F->perm, D_user, F->pD);
-    D = F->pD;
-    X = F->pX;
-  }
   for (int pass = 0; pass < 2; ++pass) {
     const TriSchedule &S = pass ? F->U : F->L;
     for (int64_t l = 0; l < S.nlev; ++l) {
       const LevelDesc &L = S.desc[l];
+      if (L.m == 0) continue;
+      const bool wide = L.w >= 96 && nrhs <= WG;
       const int64_t threads = (int64_t)L.m * nrhs;
-      const unsigned grid = (unsigned)((threads + WG - 1) / WG);
-      if (grid == 0) continue;
-      if (pass)
-        hipLaunchKernelGGL(k_trsv_level_multi<true>, dim3(grid), dim3(WG), 0, ctx->stream, L.m, L.w, nrhs, S.rows + L.row_off,
-                           S.cols + L.ent_off, S.vals + L.ent_off, S.dinv + L.row_off, D, X);
-      else
-        hipLaunchKernelGGL(k_trsv_level_multi<false>, dim3(grid), dim3(WG), 0, ctx->stream, L.m, L.w, nrhs, S.rows + L.row_off,
-                           S.cols + L.ent_off, S.vals + L.ent_off, (const double *)nullptr, D, X);
+      const unsigned grid = wide ? (unsigned)L.m : (unsigned)((threads + WG - 1) / WG);
+      if (pass) {
+        if (wide)
+          hipLaunchKernelGGL(k_trsv_level_multi_wide<true>, dim3(grid), dim3(WG), 0, ctx->stream, L.m, L.w, nrhs, S.rows + L.row_off, S.cols + L.ent_off,
+                             S.vals + L.ent_off, S.dinv + L.row_off, D, ldd, X, ldx);
+        else
+          hipLaunchKernelGGL(k_trsv_level_multi<true>, dim3(grid), dim3(WG), 0, ctx->stream, L.m, L.w, nrhs, S.rows + L.row_off, S.cols + L.ent_off,
+                             S.vals + L.ent_off, S.dinv + L.row_off, D, ldd, X, ldx);
+      } else {
+        if (wide)
+          hipLaunchKernelGGL(k_trsv_level_multi_wide<false>, dim3(grid), dim3(WG), 0, ctx->stream, L.m, L.w, nrhs, S.rows + L.row_off, S.cols + L.ent_off,
+                             S.vals + L.ent_off, (const double *)nullptr, D, ldd, X, ldx);
+        else
+          hipLaunchKernelGGL(k_trsv_level_multi<false>, dim3(grid), dim3(WG), 0, ctx->stream, L.m, L.w, nrhs, S.rows + L.row_off, S.cols + L.ent_off,
+                             S.vals + L.ent_off, (const double *)nullptr, D, ldd, X, ldx);
+      }
     }
   }
-  if (F->perm) hipLaunchKernelGGL(k_perm_scatter, dim3(grid_for(F->n * nrhs)), dim3(WG), 0, ctx->stream, F->n, nrhs, F->perm, (const double *)F->pX, X_user);
-  HIPCHECK(ctx, hipGetLastError());
+}
+static int ilu0_solve_multi_ld(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double *D, int64_t ldd, double *X, int64_t ldx)
+{
+  if (!F || !D || !X || D == X || nrhs < 1 || ldd < nrhs || ldx < nrhs) return fail(ctx, DDM_EINVAL, "ddm_ilu0_solve_multi: bad arguments");
+  if (F->n == 0) return DDM_OK;
+  if (F->mgraph && F->mg_D == D && F->mg_X == X && F->mg_nrhs == nrhs && F->mg_ldd == ldd && F->mg_ldx == ldx) {
+    HIPCHECK(ctx, hipGraphLaunch(F->mgraph, ctx->stream));
+    return DDM_OK;
+  }
+  if (F->mgraph) {
+    (void)hipGraphExecDestroy(F->mgraph);
+    F->mgraph = nullptr;
+  }
+  if (F->perm && F->pm_nrhs < nrhs) {
+    (void)hipFree(F->pD);
+    (void)hipFree(F->pX);
+    F->pD = F->pX = nullptr;
+    F->pm_nrhs = 0;
+    HIPCHECK(ctx, hipMalloc((void **)&F->pD, sizeof(double) * (size_t)F->n * (size_t)nrhs));
+    HIPCHECK(ctx, hipMalloc((void **)&F->pX, sizeof(double) * (size_t)F->n * (size_t)nrhs));
+    F->pm_nrhs = nrhs;
+  }
+  hipGraph_t g = nullptr;
+  HIPCHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  if (F->perm) { // sparse direct factor: solve in the fill-reducing order on packed work blocks
+    hipLaunchKernelGGL(k_perm_gather, dim3(grid_for(F->n * nrhs)), dim3(WG), 0, ctx->stream, F->n, nrhs, F->perm, D, ldd, F->pD);
+    enqueue_multi_levels(ctx, F, nrhs, F->pD, nrhs, F->pX, nrhs);
+    hipLaunchKernelGGL(k_perm_scatter, dim3(grid_for(F->n * nrhs)), dim3(WG), 0, ctx->stream, F->n, nrhs, F->perm, (const double *)F->pX, X, ldx);
+  } else {
+    enqueue_multi_levels(ctx, F, nrhs, D, ldd, X, ldx);
+  }
+  hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+  if (e != hipSuccess) return fail(ctx, DDM_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+  e = hipGraphInstantiate(&F->mgraph, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) {
+    F->mgraph = nullptr;
+    return fail(ctx, DDM_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+  }
+  F->mg_D = D;
+  F->mg_X = X;
+  F->mg_nrhs = nrhs;
+  F->mg_ldd = ldd;
+  F->mg_ldx = ldx;
+  HIPCHECK(ctx, hipGraphLaunch(F->mgraph, ctx->stream));
   return DDM_OK;
 }
+extern "C" int ddm_ilu0_solve_multi(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double *D, double *X) { return ilu0_solve_multi_ld(ctx, F, nrhs, D, nrhs, X, nrhs); }
 
 // ---- halo --------------------------------------------------------------------------------------
 struct ddm_halo {
@@ -1955,4 +2008,13 @@ extern "C" int ddm_gmres_solve(ddm_ctx *ctx, ddm_op *op, ddm_combined *prec, dou
     if (!rc && st) rc = fail(ctx, DDM_ENUMERIC, "persistent triangular solve timed out waiting for a level (results invalid)");
   }
   return cleanup(rc);
+}
+
+#include "geneo.hpp"
+
+// ---- dense host helpers exposed for the CPU tests (host logic of the GenEO Rayleigh-Ritz step) -------------------------
+extern "C" int ddm_dense_sym_eig_host(int n, double *V, double *w) { return dense::sym_eig(n, V, w) ? DDM_OK : DDM_ENUMERIC; }
+extern "C" int ddm_dense_rayleigh_ritz_host(int p, const double *gA, const double *gC, int keep, double tau, double *mu, double *Y)
+{
+  return dense::rayleigh_ritz(p, gA, gC, keep, tau, mu, Y);
 }

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(WG) void k_trsv_upper_level(int m, int w, const int
 // n x nrhs, a thread owns one (row, rhs) pair; the nrhs lanes of a row read the same factor
 // entries (broadcast) and gather nrhs consecutive doubles of x (coalesced).
 template <class IDX>
-__device__ __forceinline__ double trsv_row_sum_multi(double s, int w, IDX m, IDX r, int nrhs, int j,
+__device__ __forceinline__ double trsv_row_sum_multi(double s, int w, IDX m, IDX r, int64_t nrhs, int j,
                                                      const int32_t *__restrict__ cols, const double *__restrict__ vals,
                                                      const double *x)
 {
@@ -176,24 +176,52 @@ __device__ __forceinline__ double trsv_row_sum_multi(double s, int w, IDX m, IDX
   return s;
 }
 
+// ldd / ldx: leading dimensions of the row-major blocks d and x (>= nrhs)
 template <bool UPPER>
 __global__ __launch_bounds__(WG) void k_trsv_level_multi(int m, int w, int nrhs, const int32_t *__restrict__ rows,
                                                           const int32_t *__restrict__ cols, const double *__restrict__ vals,
-                                                          const double *__restrict__ dinv, const double *__restrict__ d, double *x)
+                                                          const double *__restrict__ dinv, const double *__restrict__ d, int64_t ldd, double *x, int64_t ldx)
 {
   const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x;
   const int r = (int)(t / nrhs);
   if (r >= m) return;
   const int j = (int)(t - (int64_t)r * nrhs);
-  const int64_t o = (int64_t)rows[r] * nrhs + j;
-  const double s = trsv_row_sum_multi<int64_t>(UPPER ? x[o] : d[o], w, m, r, nrhs, j, cols, vals, x);
+  const int64_t o = (int64_t)rows[r] * ldx + j;
+  const double s = trsv_row_sum_multi<int64_t>(UPPER ? x[o] : d[(int64_t)rows[r] * ldd + j], w, m, r, ldx, j, cols, vals, x);
   x[o] = UPPER ? s * dinv[r] : s;
+}
+// The same for levels of WIDE rows (factors of the sparse direct solver: separator rows have thousands of entries and a
+// level often holds a single row): one workgroup per row, the 256 threads split the row's entries into 256 / nrhs slices
+// per right-hand side, slice sums meet in LDS and are added in slice order (deterministic).
+template <bool UPPER>
+__global__ __launch_bounds__(WG) void k_trsv_level_multi_wide(int m, int w, int nrhs, const int32_t *__restrict__ rows,
+                                                               const int32_t *__restrict__ cols, const double *__restrict__ vals,
+                                                               const double *__restrict__ dinv, const double *__restrict__ d, int64_t ldd, double *x, int64_t ldx)
+{
+  __shared__ double part[WG];
+  const int r = blockIdx.x;
+  const int nsl = WG / nrhs;
+  const int sl = threadIdx.x / nrhs, j = threadIdx.x - sl * nrhs;
+  double s = 0.0;
+  if (sl < nsl)
+    for (int k = sl; k < w; k += nsl) {
+      const double v = vals[(int64_t)k * m + r];
+      s += v * x[(int64_t)cols[(int64_t)k * m + r] * ldx + j];
+    }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < nrhs) {
+    const int64_t o = (int64_t)rows[r] * ldx + threadIdx.x;
+    double acc = UPPER ? x[o] : d[(int64_t)rows[r] * ldd + threadIdx.x];
+    for (int q = 0; q < nsl; ++q) acc -= part[q * nrhs + threadIdx.x];
+    x[o] = UPPER ? acc * dinv[r] : acc;
+  }
 }
 
 // Y = A X for row-major block vectors (n x nrhs): one thread per (row, rhs)
 __global__ __launch_bounds__(WG) void k_spmm_rowmajor(int64_t n, int nrhs, const int64_t *__restrict__ rp,
                                                        const int32_t *__restrict__ ci, const double *__restrict__ va,
-                                                       const double *__restrict__ x, double *__restrict__ y)
+                                                       const double *__restrict__ x, int64_t ldx, double *__restrict__ y, int64_t ldy)
 {
   const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x;
   const int64_t row = t / nrhs;
@@ -211,11 +239,11 @@ __global__ __launch_bounds__(WG) void k_spmm_rowmajor(int64_t n, int nrhs, const
       v[u] = ok ? va[kb + u] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) xv[u] = c[u] >= 0 ? x[(int64_t)c[u] * nrhs + j] : 0.0;
+    for (int u = 0; u < 8; ++u) xv[u] = c[u] >= 0 ? x[(int64_t)c[u] * ldx + j] : 0.0;
 #pragma unroll
     for (int u = 0; u < 8; ++u) s += v[u] * xv[u];
   }
-  y[row * nrhs + j] = s;
+  y[row * ldy + j] = s;
 }
 
 // Several consecutive small levels (each <= WG*TRSV_SMALL_ROWS rows) in ONE workgroup: the levels
@@ -628,20 +656,21 @@ __global__ void k_w_permute_out(int64_t n, const int64_t *__restrict__ upos, con
 // ---------------------------------------------------------------------------------------------
 // K2 extend (schwarz.hh:121-122), K5 restrict (schwarz.hh:146), K4 POU scaling (schwarz.hh:141)
 // dst[i,:] = src[perm[i],:] / dst[perm[i],:] = src[i,:] for row-major n x nrhs blocks (fill-reducing order of the direct solver)
-__global__ void k_perm_gather(int64_t n, int nrhs, const int32_t *__restrict__ perm, const double *__restrict__ src, double *__restrict__ dst)
+// (src / dst of the un-permuted side have leading dimension ld; the permuted side is packed, ld = nrhs)
+__global__ void k_perm_gather(int64_t n, int nrhs, const int32_t *__restrict__ perm, const double *__restrict__ src, int64_t ld, double *__restrict__ dst)
 {
   const int64_t tot = n * nrhs;
   for (int64_t t = blockIdx.x * (int64_t)WG + threadIdx.x; t < tot; t += (int64_t)gridDim.x * WG) {
     const int64_t i = t / nrhs;
-    dst[t] = src[(int64_t)perm[i] * nrhs + (t - i * nrhs)];
+    dst[t] = src[(int64_t)perm[i] * ld + (t - i * nrhs)];
   }
 }
-__global__ void k_perm_scatter(int64_t n, int nrhs, const int32_t *__restrict__ perm, const double *__restrict__ src, double *__restrict__ dst)
+__global__ void k_perm_scatter(int64_t n, int nrhs, const int32_t *__restrict__ perm, const double *__restrict__ src, double *__restrict__ dst, int64_t ld)
 {
   const int64_t tot = n * nrhs;
   for (int64_t t = blockIdx.x * (int64_t)WG + threadIdx.x; t < tot; t += (int64_t)gridDim.x * WG) {
     const int64_t i = t / nrhs;
-    dst[(int64_t)perm[i] * nrhs + (t - i * nrhs)] = src[t];
+    dst[(int64_t)perm[i] * ld + (t - i * nrhs)] = src[t];
   }
 }
 __global__ void k_extend(int64_t n, const int32_t *__restrict__ ext_map, const double *__restrict__ d, double *__restrict__ dov)

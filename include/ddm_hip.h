@@ -202,6 +202,56 @@ int ddm_galerkin_apply(ddm_ctx *ctx, ddm_galerkin *G, double *x, const double *d
 int ddm_galerkin_products(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t nleft, const double *left, int64_t nright,
                           const double *right, int64_t row0, int64_t row1, double *out_host);
 
+/* ---- GenEO coarse-basis builder ---------------------------------------------------------------
+ * GenEOCoarseSpace(A, B, pou, ptree, taskflow, prefix) -> get_basis() (dune/ddm/coarsespaces/coarse_spaces.hh:219-256, 286-331):
+ * C = D B_neu D, the lowest nev eigenpairs of A_neu x = lambda C x per subdomain, v <- D v / ||D v||_2, entries of Dirichlet
+ * DoFs zeroed (the caller's zero_at_dirichlet, examples/poisson.cc:235-238).  The fields of ddm_geneo_params are the keys of the
+ * `<prefix>.eigensolver` sub-tree (dune/ddm/eigensolvers/eigensolver_params.hh:8-62); the block method behind it is described
+ * in csrc/geneo.hpp (ncv / blocksize / maxit of the reference's single-vector Lanczos have no meaning for it).
+ *   A_neu, B_neu : block-diagonal over the rank's subdomains (sub_ptr[nsub+1] row ranges), B_neu may be the same object as A_neu
+ *   pou_host[n], dirichlet_host[n] (may be NULL)
+ *   basis_host   : kmax x n row-major (vector j of every subdomain in row j, zero outside the subdomain's rows is NOT implied:
+ *                  row j holds vector j of ALL local subdomains side by side); info->nev rows are written
+ *   nconv[nsub]  : vectors to use per subdomain (= nev, or the count below `threshold` in threshold mode, spectra.hh:157-163)
+ *   eigenvalues_host : nsub x kmax, ascending
+ * Synchronous.  DDM_ENUMERIC if a projected eigenproblem breaks down; not converged within maxit is reported in info only. */
+typedef struct {
+  int32_t nev;             /* eigensolver.nev (default 16) */
+  int32_t nev_max;         /* upper bound of the threshold mode (default 2 nev) */
+  double tolerance;        /* eigensolver.tolerance (1e-5) */
+  double shift;            /* eigensolver.shift (1e-3) */
+  double threshold;        /* eigensolver.threshold (-0.5 = off) */
+  int32_t maxit;           /* block iterations (400) */
+  int32_t extra;           /* guard vectors iterated beyond nev (4) */
+  int32_t seed;            /* start block */
+  int32_t preconditioner;  /* 0 = sparse Cholesky of A + shift C if its flop count <= max_direct_flops, else ILU(0); 1 = ILU(0); 2 = Cholesky */
+  double max_direct_flops; /* 4e10 */
+  int32_t verbose;
+} ddm_geneo_params;
+typedef struct {
+  int32_t iterations, converged, used_direct, nev;
+  double worst_residual, setup_s, iterate_s, direct_flops;
+} ddm_geneo_info;
+int ddm_geneo_params_default(ddm_geneo_params *p);
+int ddm_geneo_basis(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, int64_t nsub, const int64_t *sub_ptr, const double *pou_host,
+                    const uint8_t *dirichlet_host, const ddm_geneo_params *params, int64_t kmax, double *basis_host, int32_t *nconv,
+                    double *eigenvalues_host, ddm_geneo_info *info);
+/* The two dense contractions of the block eigensolver on their own (FP64 MFMA, csrc/geneo_kernels.hpp), for row-major DEVICE
+ * blocks split into subdomain row ranges sub_ptr[nsub+1]:
+ *   gram  : G_host[s] = U[rows of s]^T V[rows of s]   (nsub matrices pu x pv, row-major; split-K over 2048-row chunks, summed in
+ *           chunk order)                              -- Spectra's V^T B f / Gram products
+ *   rotate: Out[rows of s, 0:q) = (Base[rows of s, 0:q) -) U[rows of s, 0:p) Y_host[s]   (Y: nsub matrices p x q, q <= 48)
+ *                                                     -- Spectra's compress_V (Arnoldi.h:310-329)
+ * Synchronous. */
+int ddm_blockvec_gram(ddm_ctx *ctx, int64_t nsub, const int64_t *sub_ptr, const double *U, int64_t ldu, int pu, const double *V, int64_t ldv,
+                      int pv, double *G_host);
+int ddm_blockvec_rotate(ddm_ctx *ctx, int64_t nsub, const int64_t *sub_ptr, const double *U, int64_t ldu, int p, const double *Y_host, int q,
+                        const double *Base, int64_t ldb, double *Out, int64_t ldo);
+/* host logic of the Rayleigh-Ritz step, exposed for the CPU tests: symmetric eigen-decomposition (V: matrix in, eigenvectors as
+ * columns out; w ascending) and the rank-revealing Rayleigh-Ritz of gC y = mu gA y (returns the rank used, < 0 on failure) */
+int ddm_dense_sym_eig_host(int n, double *V, double *w);
+int ddm_dense_rayleigh_ritz_host(int p, const double *gA, const double *gC, int keep, double tau, double *mu, double *Y);
+
 /* ---- CombinedPreconditioner (combined_preconditioner.hh:39-180) --------------------------- */
 /* mode 0 = additive, 1 = multiplicative (:56-69).  galerkin may be NULL (one-level). */
 int ddm_combined_create(ddm_ctx *ctx, int mode, ddm_op *op, ddm_schwarz *schwarz, ddm_galerkin *galerkin,
