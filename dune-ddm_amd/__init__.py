@@ -85,6 +85,8 @@ SYMBOLS = {
     "ddm_ilu0_is_direct": (_I32, [_P]),
     "ddm_ilu0_nnz": (_I64, [_P]),
     "ddm_chol_host_create": (_I32, [_I64, _P, _P, _P, _I64, _P, _PP]),
+    "ddm_direct_host_create": (_I32, [_I64, _P, _P, _P, _I64, _P, _I32, _PP]),
+    "ddm_direct_create": (_I32, [_P, _P, _I64, _P, _I32, _D, _PP]),
     "ddm_chol_host_destroy": (None, [_P]),
     "ddm_chol_host_nnz": (_I64, [_P]),
     "ddm_chol_host_nnz_factor": (_I64, [_P]),
@@ -263,7 +265,7 @@ class CsrMatrix:
             pass
 
 
-def chol_host(M, block_ptr=None, numeric=True):
+def chol_host(M, block_ptr=None, numeric=True, general=False):
     """The host part of the sparse direct solver alone (ordering, symbolic analysis, numeric Cholesky; no device needed).
     Returns dict(perm, rowptr, col, lu, nnzL, flops); lu follows the ILU(0) storage convention over the permuted indices."""
     import scipy.sparse as sp
@@ -275,7 +277,7 @@ def chol_host(M, block_ptr=None, numeric=True):
     bp = _np([0, n] if block_ptr is None else block_ptr, np.int64)
     rp, ci, va = _np(M.indptr, np.int64), _np(M.indices, np.int32), _np(M.data, np.float64)
     h = ctypes.c_void_p()
-    rc = lib.ddm_chol_host_create(n, _hp(rp), _hp(ci), _hp(va) if numeric else None, len(bp) - 1, _hp(bp), ctypes.byref(h))
+    rc = lib.ddm_direct_host_create(n, _hp(rp), _hp(ci), _hp(va) if numeric else None, len(bp) - 1, _hp(bp), int(general), ctypes.byref(h))
     if rc != DDM_OK:
         raise DdmError(rc, "sparse Cholesky failed (DDM_ENUMERIC: matrix not positive definite)")
     try:
@@ -292,12 +294,12 @@ def chol_host(M, block_ptr=None, numeric=True):
 class Ilu0:
     """ddm_ilu0: a local factor solver -- ILU(0) in natural order, or (direct=True) the sparse Cholesky of ddm_chol_create."""
 
-    def __init__(self, ctx: Context, A: CsrMatrix, block_ptr=None, direct=False, max_flops=0.0):
+    def __init__(self, ctx: Context, A: CsrMatrix, block_ptr=None, direct=False, max_flops=0.0, general=False):
         self.ctx, self.A = ctx, A
         bp = _np([0, A.shape[0]] if block_ptr is None else block_ptr, np.int64)
         h = ctypes.c_void_p()
         if direct:
-            ctx.check(ctx.lib.ddm_chol_create(ctx.h, A.h, len(bp) - 1, _hp(bp), float(max_flops), ctypes.byref(h)))
+            ctx.check(ctx.lib.ddm_direct_create(ctx.h, A.h, len(bp) - 1, _hp(bp), int(general), float(max_flops), ctypes.byref(h)))
         else:
             ctx.check(ctx.lib.ddm_ilu0_create(ctx.h, A.h, len(bp) - 1, _hp(bp), ctypes.byref(h)))
         self.h = h

@@ -627,8 +627,9 @@ struct CholResult {
   std::string error;
 };
 // rc: DDM_OK, DDM_ENOTIMPL (more than max_flops: nothing was factorised), DDM_ENUMERIC (not positive definite), DDM_EINVAL
+// general = true: L U without pivoting on the pattern of A + A^T (matrices with a positive definite symmetric part)
 static int chol_build(int64_t n, const int64_t *rp, const int32_t *ci, const double *va, int64_t nblocks, const int64_t *block_ptr, double max_flops,
-                      bool numeric, CholResult &R)
+                      bool numeric, CholResult &R, bool general = false)
 {
   if (n < 0 || !rp || !ci || nblocks < 1 || !block_ptr || block_ptr[0] != 0 || block_ptr[nblocks] != n) {
     R.error = "bad arguments";
@@ -636,6 +637,8 @@ static int chol_build(int64_t n, const int64_t *rp, const int32_t *ci, const dou
   }
   std::vector<chol::BlockFactor> BF((size_t)nblocks);
   std::vector<chol::PermutedLower> PL((size_t)nblocks);
+  std::vector<chol::PermutedLowerLU> PU((size_t)(general ? nblocks : 0));
+  std::vector<std::vector<double>> UX((size_t)(general ? nblocks : 0));
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
   const int nthreads = (int)std::min<int64_t>(nblocks, hw);
   auto parallel = [&](auto fn) {
@@ -655,8 +658,13 @@ static int chol_build(int64_t n, const int64_t *rp, const int32_t *ci, const dou
     if (bad[(size_t)b]) return;
     chol::Graph G = chol::block_graph(rp, ci, r0, r1);
     BF[(size_t)b].perm = chol::nested_dissection(G);
-    PL[(size_t)b] = chol::permute_lower(rp, ci, va, r0, r1, BF[(size_t)b].perm);
-    chol::analyze(PL[(size_t)b], (int32_t)(r1 - r0), BF[(size_t)b]);
+    if (general) {
+      PU[(size_t)b] = chol::permute_lower_lu(rp, ci, va, r0, r1, BF[(size_t)b].perm);
+      chol::analyze(PU[(size_t)b].lo, (int32_t)(r1 - r0), BF[(size_t)b]);
+    } else {
+      PL[(size_t)b] = chol::permute_lower(rp, ci, va, r0, r1, BF[(size_t)b].perm);
+      chol::analyze(PL[(size_t)b], (int32_t)(r1 - r0), BF[(size_t)b]);
+    }
   });
   for (int64_t b = 0; b < nblocks; ++b)
     if (bad[(size_t)b]) {
@@ -666,14 +674,14 @@ static int chol_build(int64_t n, const int64_t *rp, const int32_t *ci, const dou
   R.flops = 0.0;
   R.nnzL = 0;
   for (auto &f : BF) {
-    R.flops += f.flops;
+    R.flops += (general ? 2.0 : 1.0) * f.flops;
     R.nnzL += f.nnzL;
   }
   R.perm.resize((size_t)n);
   for (int64_t b = 0; b < nblocks; ++b)
     for (int32_t k = 0; k < BF[(size_t)b].n; ++k) R.perm[(size_t)(block_ptr[b] + k)] = (int32_t)(block_ptr[b] + BF[(size_t)b].perm[(size_t)k]);
   if (max_flops > 0.0 && R.flops > max_flops) {
-    R.error = "sparse Cholesky needs " + std::to_string(R.flops) + " flops (limit " + std::to_string(max_flops) + ")";
+    R.error = "sparse direct factorisation needs " + std::to_string(R.flops) + " flops (limit " + std::to_string(max_flops) + ")";
     return DDM_ENOTIMPL;
   }
   if (!numeric) return DDM_OK;
@@ -682,8 +690,13 @@ static int chol_build(int64_t n, const int64_t *rp, const int32_t *ci, const dou
     return DDM_EINVAL;
   }
   parallel([&](int64_t b) {
-    if (!chol::factorize(PL[(size_t)b], BF[(size_t)b])) bad[(size_t)b] = 1;
-    PL[(size_t)b] = chol::PermutedLower(); // release
+    if (general) {
+      if (!chol::factorize_lu(PU[(size_t)b], BF[(size_t)b], UX[(size_t)b])) bad[(size_t)b] = 1;
+      PU[(size_t)b] = chol::PermutedLowerLU();
+    } else {
+      if (!chol::factorize(PL[(size_t)b], BF[(size_t)b])) bad[(size_t)b] = 1;
+      PL[(size_t)b] = chol::PermutedLower(); // release
+    }
   });
   for (int64_t b = 0; b < nblocks; ++b)
     if (bad[(size_t)b]) {
@@ -694,7 +707,11 @@ static int chol_build(int64_t n, const int64_t *rp, const int32_t *ci, const dou
   R.rp.reserve((size_t)n + 1);
   R.diag.reserve((size_t)n);
   for (int64_t b = 0; b < nblocks; ++b) {
-    chol::append_rows(BF[(size_t)b], block_ptr[b], R.rp, R.ci, R.lu, R.diag);
+    if (general) {
+      chol::append_rows_lu(BF[(size_t)b], UX[(size_t)b], block_ptr[b], R.rp, R.ci, R.lu, R.diag);
+      std::vector<double>().swap(UX[(size_t)b]);
+    } else
+      chol::append_rows(BF[(size_t)b], block_ptr[b], R.rp, R.ci, R.lu, R.diag);
     BF[(size_t)b] = chol::BlockFactor();
   }
   return DDM_OK;
@@ -706,9 +723,14 @@ struct ddm_chol_host {
 extern "C" int ddm_chol_host_create(int64_t n, const int64_t *rp, const int32_t *ci, const double *va, int64_t nblocks, const int64_t *block_ptr,
                                     ddm_chol_host **out)
 {
+  return ddm_direct_host_create(n, rp, ci, va, nblocks, block_ptr, 0, out);
+}
+extern "C" int ddm_direct_host_create(int64_t n, const int64_t *rp, const int32_t *ci, const double *va, int64_t nblocks, const int64_t *block_ptr,
+                                      int general, ddm_chol_host **out)
+{
   if (!out) return DDM_EINVAL;
   ddm_chol_host *H = new ddm_chol_host;
-  const int rc = chol_build(n, rp, ci, va, nblocks, block_ptr, 0.0, va != nullptr, H->R);
+  const int rc = chol_build(n, rp, ci, va, nblocks, block_ptr, 0.0, va != nullptr, H->R, general != 0);
   if (rc) {
     delete H;
     return rc;
@@ -732,11 +754,15 @@ extern "C" int ddm_chol_host_get(const ddm_chol_host *H, int32_t *perm, int64_t 
 
 extern "C" int ddm_chol_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, double max_flops, ddm_ilu0 **out)
 {
-  if (!ctx || !A || !out || nblocks < 1 || !block_ptr) return fail(ctx, DDM_EINVAL, "ddm_chol_create: bad arguments");
+  return ddm_direct_create(ctx, A, nblocks, block_ptr, 0, max_flops, out);
+}
+extern "C" int ddm_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, int general, double max_flops, ddm_ilu0 **out)
+{
+  if (!ctx || !A || !out || nblocks < 1 || !block_ptr) return fail(ctx, DDM_EINVAL, "ddm_direct_create: bad arguments");
   if (A->nrows != A->ncols) return fail(ctx, DDM_EINVAL, "the sparse direct solver needs a square matrix");
   CholResult R;
-  const int rc0 = chol_build(A->nrows, A->h_rp.data(), A->h_ci.data(), A->h_va.data(), nblocks, block_ptr, max_flops, true, R);
-  if (rc0) return fail(ctx, rc0, "ddm_chol_create: %s", R.error.c_str());
+  const int rc0 = chol_build(A->nrows, A->h_rp.data(), A->h_ci.data(), A->h_va.data(), nblocks, block_ptr, max_flops, true, R, general != 0);
+  if (rc0) return fail(ctx, rc0, "sparse direct solver: %s", R.error.c_str());
   ddm_ilu0 *F = new ddm_ilu0;
   F->n = A->nrows;
   F->nnz = (int64_t)R.ci.size();
@@ -1432,6 +1458,20 @@ extern "C" int ddm_schwarz_create_ex(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t
   const std::string st = subdomain_solver ? subdomain_solver : "ilu0";
   const bool direct = st == "cholmod" || st == "direct" || st == "cholesky" || st == "umfpack" || st == "ldl";
   if (!direct && st != "ilu0" && st != "ilu") return fail(ctx, DDM_ENOTIMPL, "Unknown subdomain solver type '%s'", st.c_str()); // solver factory lookup (:85-92)
+  bool general = st == "umfpack";
+  if (st == "direct") { // pick the factorisation by looking at the values: symmetric -> Cholesky
+    general = false;
+    const int64_t nn = A_dir->nrows;
+    for (int64_t i = 0; i < nn && !general; ++i)
+      for (int64_t k = A_dir->h_rp[i]; k < A_dir->h_rp[i + 1] && !general; ++k) {
+        const int64_t j = A_dir->h_ci[k];
+        if (j <= i) continue;
+        const auto b = A_dir->h_ci.begin() + A_dir->h_rp[j], e = A_dir->h_ci.begin() + A_dir->h_rp[j + 1];
+        const auto it = std::lower_bound(b, e, (int32_t)i);
+        const double vt = (it != e && *it == i) ? A_dir->h_va[(size_t)(it - A_dir->h_ci.begin())] : 0.0;
+        if (std::fabs(vt - A_dir->h_va[k]) > 1e-12 * (std::fabs(vt) + std::fabs(A_dir->h_va[k]))) general = true;
+      }
+  }
   if (type != 0 && type != 1) return fail(ctx, DDM_ENOTIMPL, "Unknown Schwarz type %d", type); // schwarz.hh:83
   if (ovlp_copy && ovlp_copy->mode != 0) return fail(ctx, DDM_EINVAL, "ovlp_copy must be a 'copy' halo");
   if (ovlp_add && ovlp_add->mode != 1) return fail(ctx, DDM_EINVAL, "ovlp_add must be an 'add' halo");
@@ -1444,7 +1484,7 @@ extern "C" int ddm_schwarz_create_ex(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t
   S->type = type;
   S->copy = ovlp_copy;
   S->add = ovlp_add;
-  int rc = direct ? ddm_chol_create(ctx, A_dir, nblocks, block_ptr, 0.0, &S->solver)
+  int rc = direct ? ddm_direct_create(ctx, A_dir, nblocks, block_ptr, general ? 1 : 0, 0.0, &S->solver)
                   : ddm_ilu0_create(ctx, A_dir, nblocks, block_ptr, &S->solver); // factorisation happens in the ctor (:92)
   if (!rc) rc = upload(ctx, ext_map_host, n, &S->ext_map);
   if (!rc && pou_host) rc = upload(ctx, pou_host, n, &S->pou);

@@ -41,7 +41,7 @@ extern "C" int ddm_geneo_params_default(ddm_geneo_params *p)
   p->extra = 4;
   p->seed = 0;
   p->preconditioner = 0;
-  p->max_direct_flops = 4e10;
+  p->max_direct_flops = 3e11;
   p->verbose = 0;
   return DDM_OK;
 }

@@ -326,6 +326,169 @@ inline bool factorize(const PermutedLower &P, BlockFactor &F)
   return true;
 }
 
+// ---- general (non-symmetric) blocks: L U without pivoting on the symmetrised pattern -----------------------------------
+// For matrices whose symmetric part is positive definite (the SIPG / upwind DG operator of BASELINE configs[3]; what the
+// reference hands to UMFPACK) Gaussian elimination without pivoting is stable; the pattern of L and of U^T is the Cholesky
+// pattern of A + A^T, so ordering, elimination tree and storage are shared with the symmetric case: position q of column j
+// holds L(k, j) in Lx and U(j, k) in Ux.  The diagonal of U sits at the head of each column in Ux (Lx there is 1).
+struct PermutedLowerLU {
+  PermutedLower lo;            // lo.val = a(k, j), j < k (new numbering), lo.diag = a(k, k)
+  std::vector<double> valT;    // a(j, k) at the same positions
+};
+inline PermutedLowerLU permute_lower_lu(const int64_t *rp, const int32_t *ci, const double *va, int64_t r0, int64_t r1, const std::vector<int32_t> &perm)
+{
+  const int32_t n = (int32_t)(r1 - r0);
+  std::vector<int32_t> iperm(n);
+  for (int32_t k = 0; k < n; ++k) iperm[perm[k]] = k;
+  // transpose of the block (local indices), rows sorted because the input rows are visited in order
+  std::vector<int64_t> tp(n + 1, 0);
+  for (int64_t i = r0; i < r1; ++i)
+    for (int64_t p = rp[i]; p < rp[i + 1]; ++p)
+      if (ci[p] >= r0 && ci[p] < r1) tp[ci[p] - r0 + 1]++;
+  for (int32_t i = 0; i < n; ++i) tp[i + 1] += tp[i];
+  std::vector<int32_t> tj((size_t)tp[n]);
+  std::vector<double> tv((size_t)tp[n]);
+  {
+    std::vector<int64_t> pos(tp.begin(), tp.end() - 1);
+    for (int64_t i = r0; i < r1; ++i)
+      for (int64_t p = rp[i]; p < rp[i + 1]; ++p)
+        if (ci[p] >= r0 && ci[p] < r1) {
+          const int64_t q = pos[ci[p] - r0]++;
+          tj[(size_t)q] = (int32_t)(i - r0);
+          tv[(size_t)q] = va ? va[p] : 0.0;
+        }
+  }
+  PermutedLowerLU P;
+  P.lo.ptr.assign(n + 1, 0);
+  P.lo.diag.assign(n, 0.0);
+  // merged (pattern of A + A^T) lower rows in the new numbering; two passes: count, fill
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1) {
+      for (int32_t k = 0; k < n; ++k) P.lo.ptr[k + 1] += P.lo.ptr[k];
+      P.lo.col.resize((size_t)P.lo.ptr[n]);
+      P.lo.val.resize((size_t)P.lo.ptr[n]);
+      P.valT.resize((size_t)P.lo.ptr[n]);
+    }
+    for (int32_t k = 0; k < n; ++k) {
+      const int32_t io = perm[k];
+      int64_t a = rp[r0 + io], b = tp[io];
+      const int64_t a1 = rp[r0 + io + 1], b1 = tp[io + 1];
+      int64_t q = pass ? P.lo.ptr[k] : 0;
+      while (a < a1 || b < b1) {
+        while (a < a1 && (ci[a] < r0 || ci[a] >= r1)) ++a;
+        const int32_t ca = a < a1 ? (int32_t)(ci[a] - r0) : INT32_MAX, cb = b < b1 ? tj[(size_t)b] : INT32_MAX;
+        if (ca == INT32_MAX && cb == INT32_MAX) break;
+        const int32_t c = std::min(ca, cb);
+        double v = 0.0, vt = 0.0;
+        if (ca == c) v = va ? va[a++] : (a++, 0.0);
+        if (cb == c) vt = tv[(size_t)b++];
+        const int32_t jn = iperm[c];
+        if (jn < k) {
+          if (pass) {
+            P.lo.col[(size_t)q] = jn;
+            P.lo.val[(size_t)q] = v;
+            P.valT[(size_t)q] = vt;
+          }
+          ++q;
+        } else if (jn == k && pass) P.lo.diag[k] = v;
+      }
+      if (!pass) P.lo.ptr[k + 1] = q;
+    }
+  }
+  return P;
+}
+// graph of A + A^T is what block_graph builds already (it inserts both directions)
+
+inline bool factorize_lu(const PermutedLowerLU &P, BlockFactor &F, std::vector<double> &Ux)
+{
+  const int32_t n = F.n;
+  F.Li.resize((size_t)F.nnzL);
+  F.Lx.resize((size_t)F.nnzL);
+  Ux.resize((size_t)F.nnzL);
+  std::vector<int64_t> c(F.Lp.begin(), F.Lp.end() - 1);
+  std::vector<int32_t> w(n, -1), s(n);
+  std::vector<double> x(n, 0.0), y(n, 0.0);
+  double amax = 0.0;
+  for (double d : P.lo.diag) amax = std::max(amax, std::fabs(d));
+  for (int32_t k = 0; k < n; ++k) {
+    int32_t top = n;
+    w[k] = k;
+    for (int64_t p = P.lo.ptr[k]; p < P.lo.ptr[k + 1]; ++p) {
+      int32_t i = P.lo.col[(size_t)p];
+      x[i] = P.lo.val[(size_t)p];
+      y[i] = P.valT[(size_t)p];
+      int32_t len = 0;
+      for (; i != -1 && w[i] != k; i = F.parent[i]) {
+        s[len++] = i;
+        w[i] = k;
+      }
+      while (len > 0) s[--top] = s[--len];
+    }
+    double d = P.lo.diag[k];
+    for (; top < n; ++top) {
+      const int32_t i = s[top];
+      const double lki = x[i] / Ux[(size_t)F.Lp[i]]; // L(k, i)
+      const double uik = y[i];                        // U(i, k)
+      x[i] = 0.0;
+      y[i] = 0.0;
+      for (int64_t p = F.Lp[i] + 1; p < c[i]; ++p) {
+        const int32_t r = F.Li[(size_t)p];
+        x[r] -= Ux[(size_t)p] * lki; // a(k, r) -= L(k, i) U(i, r)
+        y[r] -= F.Lx[(size_t)p] * uik; // a(r, k) -= L(r, i) U(i, k)
+      }
+      d -= lki * uik;
+      const int64_t q = c[i]++;
+      F.Li[(size_t)q] = k;
+      F.Lx[(size_t)q] = lki;
+      Ux[(size_t)q] = uik;
+    }
+    if (!(std::fabs(d) > 1e-14 * amax) || !std::isfinite(d)) {
+      F.error = "zero pivot without pivoting (pivot " + std::to_string(d) + " in eliminated row " + std::to_string(k) + ")";
+      return false;
+    }
+    const int64_t q = c[k]++;
+    F.Li[(size_t)q] = k;
+    F.Lx[(size_t)q] = 1.0;
+    Ux[(size_t)q] = d;
+  }
+  return true;
+}
+// rows of an L U block factor in the ILU(0) storage convention: L(i, j) below the diagonal, 1 / U(i, i) on it, U(i, j) above
+inline void append_rows_lu(const BlockFactor &F, const std::vector<double> &Ux, int64_t r0, std::vector<int64_t> &rp, std::vector<int32_t> &ci, std::vector<double> &lu,
+                           std::vector<int64_t> &diag)
+{
+  const int32_t n = F.n;
+  std::vector<int64_t> lcnt(n + 1, 0);
+  for (int32_t j = 0; j < n; ++j)
+    for (int64_t p = F.Lp[j] + 1; p < F.Lp[j + 1]; ++p) lcnt[F.Li[(size_t)p] + 1]++;
+  const int64_t base = (int64_t)ci.size();
+  std::vector<int64_t> start(n + 1, 0);
+  for (int32_t i = 0; i < n; ++i) start[i + 1] = start[i] + lcnt[i + 1] + (F.Lp[i + 1] - F.Lp[i]);
+  ci.resize((size_t)(base + start[n]));
+  lu.resize((size_t)(base + start[n]));
+  std::vector<int64_t> pos(n);
+  for (int32_t i = 0; i < n; ++i) pos[i] = base + start[i];
+  for (int32_t j = 0; j < n; ++j)
+    for (int64_t p = F.Lp[j] + 1; p < F.Lp[j + 1]; ++p) {
+      const int32_t i = F.Li[(size_t)p];
+      ci[(size_t)pos[i]] = (int32_t)(r0 + j);
+      lu[(size_t)pos[i]] = F.Lx[(size_t)p];
+      pos[i]++;
+    }
+  for (int32_t i = 0; i < n; ++i) {
+    diag.push_back(pos[i]);
+    ci[(size_t)pos[i]] = (int32_t)(r0 + i);
+    lu[(size_t)pos[i]] = 1.0 / Ux[(size_t)F.Lp[i]];
+    pos[i]++;
+    for (int64_t p = F.Lp[i] + 1; p < F.Lp[i + 1]; ++p) {
+      ci[(size_t)pos[i]] = (int32_t)(r0 + F.Li[(size_t)p]);
+      lu[(size_t)pos[i]] = Ux[(size_t)p];
+      pos[i]++;
+    }
+    rp.push_back(pos[i]);
+  }
+}
+
 // Appends the rows of this block's factor to a CSR in the storage convention of the ILU(0) engines (global permuted
 // row numbers = r0 + new local index): strictly lower part l_ij / l_jj (unit lower factor), diagonal 1 / l_ii^2
 // (inverse pivot), strictly upper part l_ii * l_ji (= D L^T).  Columns ascending in every row.

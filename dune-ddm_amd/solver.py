@@ -103,7 +103,7 @@ def pou_basis(rl: RankLocal, template_vecs=None):
 
 class TwoLevelSchwarz:
     def __init__(self, dec: Decomposition, rank=0, nranks=1, device=0, comm: TorchComm | None = None,
-                 schwarz_type="standard", mode="additive", coarse="pou", use_pou_in_schwarz=True):
+                 schwarz_type="standard", mode="additive", coarse="pou", use_pou_in_schwarz=True, subdomain_solver="ilu0"):
         import torch
         self.torch = torch
         torch.cuda.set_device(device)
@@ -131,7 +131,8 @@ class TwoLevelSchwarz:
                 comm.register(h)
         self.op = NonOverlappingOperator(ctx, self.A, self.h_novlp, rl.owner_novlp)
         self.schwarz = SchwarzPreconditioner(ctx, self.A_dir, rl.block_ptr, rl.n_o, rl.ext_map,
-                                             rl.pou if use_pou_in_schwarz else None, schwarz_type, self.h_copy, self.h_add)
+                                             rl.pou if use_pou_in_schwarz else None, schwarz_type, self.h_copy, self.h_add,
+                                             subdomain_solver=subdomain_solver)   # [schwarz.subdomain_solver] type (schwarz.hh:85-92)
         self.galerkin = None
         self.a0 = None
         if coarse is not None and coarse != "none":

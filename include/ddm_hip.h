@@ -121,7 +121,10 @@ int ddm_ilu0_get_factors_host(ddm_ctx *ctx, const ddm_ilu0 *F, double *lu_host);
  * max_flops > 0: analyse first and return DDM_ENOTIMPL without factorising if the factorisation needs more floating-point
  * operations (sum of squared column counts) -- the caller then stays with ILU(0).  DDM_ENUMERIC: not positive definite. */
 int ddm_chol_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, double max_flops, ddm_ilu0 **out);
-int ddm_ilu0_is_direct(const ddm_ilu0 *F); /* 1 for a ddm_chol_create factor */
+/* general != 0: L U without pivoting on the pattern of A + A^T, for non-symmetric matrices whose symmetric part is positive
+ * definite (the DG convection-diffusion operator; `type = umfpack`); DDM_ENUMERIC on a vanishing pivot.  general == 0 = ddm_chol_create. */
+int ddm_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, int general, double max_flops, ddm_ilu0 **out);
+int ddm_ilu0_is_direct(const ddm_ilu0 *F); /* 1 for a ddm_chol_create / ddm_direct_create factor */
 int64_t ddm_ilu0_nnz(const ddm_ilu0 *F);   /* stored factor entries (L + D + U) */
 /* The host part alone (no device needed; used by the CPU tests): va == NULL stops after the symbolic analysis.
  * get: perm[n] (perm[new] = old), and the factor in the storage convention of ddm_ilu0_get_factors_host -- CSR over the
@@ -129,6 +132,8 @@ int64_t ddm_ilu0_nnz(const ddm_ilu0 *F);   /* stored factor entries (L + D + U) 
 typedef struct ddm_chol_host ddm_chol_host;
 int ddm_chol_host_create(int64_t n, const int64_t *rowptr, const int32_t *col, const double *val, int64_t nblocks,
                          const int64_t *block_ptr, ddm_chol_host **out);
+int ddm_direct_host_create(int64_t n, const int64_t *rowptr, const int32_t *col, const double *val, int64_t nblocks,
+                           const int64_t *block_ptr, int general, ddm_chol_host **out);
 void ddm_chol_host_destroy(ddm_chol_host *H);
 int64_t ddm_chol_host_nnz(const ddm_chol_host *H);        /* entries of the factor CSR (0 after a symbolic-only run) */
 int64_t ddm_chol_host_nnz_factor(const ddm_chol_host *H); /* nnz(L) from the symbolic analysis */
@@ -171,7 +176,8 @@ int ddm_schwarz_create(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t nblocks, cons
                        const int32_t *ext_map_host, const double *pou_host, int type, ddm_halo *ovlp_copy,
                        ddm_halo *ovlp_add, ddm_schwarz **out);
 /* the same with the `type` key of [schwarz.subdomain_solver] (schwarz.hh:85-92): "ilu0" (default of ddm_schwarz_create) or
- * "cholmod" / "umfpack" / "ldl" / "direct" = this library's sparse Cholesky (SPD input; DDM_ENUMERIC otherwise) */
+ * "cholmod" / "ldl" = this library's sparse Cholesky (SPD input; DDM_ENUMERIC otherwise), "umfpack" = its L U without pivoting,
+ * "direct" = Cholesky if the values are symmetric, else L U */
 int ddm_schwarz_create_ex(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t nblocks, const int64_t *block_ptr, int64_t n_novlp,
                           const int32_t *ext_map_host, const double *pou_host, int type, const char *subdomain_solver,
                           ddm_halo *ovlp_copy, ddm_halo *ovlp_add, ddm_schwarz **out);
@@ -225,7 +231,7 @@ typedef struct {
   int32_t extra;           /* guard vectors iterated beyond nev (4) */
   int32_t seed;            /* start block */
   int32_t preconditioner;  /* 0 = sparse Cholesky of A + shift C if its flop count <= max_direct_flops, else ILU(0); 1 = ILU(0); 2 = Cholesky */
-  double max_direct_flops; /* 4e10 */
+  double max_direct_flops; /* 3e11: about 10-20 s on 8 host threads */
   int32_t verbose;
 } ddm_geneo_params;
 typedef struct {

@@ -78,3 +78,30 @@ def test_nested_dissection_fill(ddm):
         A = synth.StructuredPoisson(N, P).subdomain(0).A
         f = ddm.chol_host(A, numeric=False)
         assert f["nnzL"] < per_row * A.shape[0], (N, f["nnzL"] / A.shape[0])
+
+
+def test_lu_without_pivoting_for_the_nonsymmetric_dg_operator(ddm):
+    """general = True: L U on the pattern of A + A^T for the non-symmetric SIPG / upwind matrix of BASELINE configs[3] (what the
+    reference hands to UMFPACK): solves to rounding, L U = P A P^T on the pattern; also a structurally non-symmetric input."""
+    from dune_ddm_amd import synth
+    from dune_ddm_amd.problem import build_structured
+    rng = np.random.default_rng(9)
+    dg = build_structured(synth.StructuredDG2D((16, 16), (2, 2)), overlap=2, neumann=False)
+    mats = [sd.A_dir for sd in dg.subs[:2]]
+    M = sp.block_diag(mats, format="csr")
+    M.sort_indices()
+    bp = np.cumsum([0] + [m.shape[0] for m in mats])
+    T = sp.csr_matrix(M.copy())
+    T.data = np.where(rng.random(T.nnz) < 0.2, 0.0, T.data)      # drop entries on one side only
+    T.eliminate_zeros()
+    T = (T + 50 * sp.eye(T.shape[0])).tocsr()
+    T.sort_indices()
+    for name, A, b_ptr in (("dg", M, bp), ("structurally non-symmetric", T, bp)):
+        assert abs(A - A.T).max() > 1e-3
+        f = ddm.chol_host(A, b_ptr, general=True)
+        d = rng.standard_normal(A.shape[0])
+        x, Lm, Um = _apply(f, d)
+        xs = spl.spsolve(A.tocsc(), d)
+        assert np.abs(x - xs).max() <= 1e-9 * np.abs(xs).max(), name
+        PAP = A[f["perm"]][:, f["perm"]]
+        assert abs(Lm @ Um - PAP).max() <= 1e-12 * abs(A).max(), name

@@ -18,6 +18,7 @@ from dune_ddm_amd.problem import build_structured  # noqa: E402
 from dune_ddm_amd.solver import TwoLevelSchwarz  # noqa: E402
 
 which, size = sys.argv[1], int(sys.argv[2])
+local = os.environ.get("DDM_LOCAL_SOLVER", "ilu0")     # ilu0 | cholmod | umfpack | direct
 t0 = time.time()
 if which == "dg":
     nev = int(sys.argv[3]) if len(sys.argv) > 3 else 16
@@ -28,7 +29,9 @@ else:
     dec = build_structured(synth.StructuredElasticity(refine=size, parts=8), overlap=1, neumann=True, second_region="all")
     cfg = dict(schwarz_type="restricted", mode="multiplicative", restart=100, reduction=1e-6, tol=1e-6)
 print(f"{which}: {dec.nglobal} DoF, {dec.nsub} subdomains, n = {[sd.n for sd in dec.subs]}, host setup {time.time() - t0:.1f} s", flush=True)
-tl = TwoLevelSchwarz(dec, coarse="none", schwarz_type=cfg["schwarz_type"], mode=cfg["mode"])
+t0 = time.time()
+tl = TwoLevelSchwarz(dec, coarse="none", schwarz_type=cfg["schwarz_type"], mode=cfg["mode"], subdomain_solver=local)
+print(f"subdomain solver '{local}': device setup {time.time() - t0:.1f} s", flush=True)
 print("engine", tl.schwarz.engine(), "levels", tl.schwarz_levels(), "max row nnz", int(np.diff(tl.rl.A_dir.indptr).max()), flush=True)
 d = tl.to_device(np.random.default_rng(0).standard_normal(tl.rl.n_o))
 x = tl.zeros(tl.rl.n_o)
