@@ -398,6 +398,25 @@ struct TriSchedule { // one triangular factor, level by level in sliced ELL
   int64_t ell_entries = 0;
 };
 
+struct TriCsr { // one triangular factor of the sparse direct solver: rows in level order, CSR entries (kernels.hpp: CsrLevel)
+  int64_t nlev = 0;
+  std::vector<CsrLevel> desc;
+  int32_t *rows = nullptr;
+  int64_t *lrp = nullptr;
+  int32_t *cols = nullptr;
+  double *vals = nullptr;
+  double *dinv = nullptr; // upper only
+  CsrLevel *d_desc = nullptr;
+  struct Launch {
+    int first, count;
+    bool fused;
+  };
+  std::vector<Launch> plan;
+  // block-wise variant (rows ordered by (block, level)): one workgroup per block runs the block's whole solve
+  int nblocks = 0;
+  int32_t *blk_lev_ptr = nullptr;
+};
+
 struct ddm_ilu0 {
   int64_t n = 0, nnz = 0;
   int mode = 8;                 // 8 = pipe (default; falls back to 4 when not applicable), 4 = xcd2 (XCD-local + loader waves), 0 = one launch per level
@@ -441,6 +460,8 @@ struct ddm_ilu0 {
   double direct_flops = 0.0;
   std::vector<double> h_lu; // factor values in the pattern of A
   TriSchedule L, U;
+  TriCsr Lc, Uc;   // direct factors use these instead of L / U (global levels: multi-RHS solves, one launch per level)
+  TriCsr Lb, Ub;   // the same factors ordered by (block, level): single right-hand side, one workgroup per block
   // HIP graph cache of the multi-RHS solve for one (D, X, nrhs, ld) combination
   hipGraphExec_t mgraph = nullptr;
   const double *mg_D = nullptr;
@@ -547,6 +568,151 @@ static int build_schedule(ddm_ctx *ctx, const ddm_csr *A, const std::vector<doub
   return DDM_OK;
 }
 
+// block_ptr != nullptr: rows ordered by (block, level), levels numbered per block (blk_lev_ptr), for k_trsv_csr_blocks
+static int build_csr_schedule(ddm_ctx *ctx, const ddm_csr *A, const std::vector<double> &lu, const std::vector<int64_t> &diag, bool upper, TriCsr &S,
+                              int64_t nblocks = 0, const int64_t *block_ptr = nullptr)
+{
+  const int64_t n = A->nrows;
+  const int64_t *rp = A->h_rp.data();
+  const int32_t *ci = A->h_ci.data();
+  std::vector<int32_t> level(n, 0);
+  int32_t maxlev = -1;
+  if (!upper)
+    for (int64_t i = 0; i < n; ++i) {
+      int32_t l = 0;
+      for (int64_t k = rp[i]; k < diag[i]; ++k) l = std::max(l, level[ci[k]] + 1);
+      level[i] = l;
+      maxlev = std::max(maxlev, l);
+    }
+  else
+    for (int64_t i = n - 1; i >= 0; --i) {
+      int32_t l = 0;
+      for (int64_t k = diag[i] + 1; k < rp[i + 1]; ++k) l = std::max(l, level[ci[k]] + 1);
+      level[i] = l;
+      maxlev = std::max(maxlev, l);
+    }
+  int64_t nlev = (int64_t)maxlev + 1;
+  std::vector<int32_t> blp;
+  if (block_ptr) { // renumber: level of block b -> (levels of the blocks before) + level
+    blp.assign(1, 0);
+    for (int64_t b = 0; b < nblocks; ++b) {
+      int32_t mx = -1;
+      for (int64_t i = block_ptr[b]; i < block_ptr[b + 1]; ++i) mx = std::max(mx, level[i]);
+      for (int64_t i = block_ptr[b]; i < block_ptr[b + 1]; ++i) level[i] += blp.back();
+      blp.push_back(blp.back() + mx + 1);
+    }
+    nlev = blp.back();
+    S.nblocks = (int)nblocks;
+  }
+  S.nlev = nlev;
+  std::vector<int64_t> lptr(nlev + 1, 0);
+  for (int64_t i = 0; i < n; ++i) lptr[level[i] + 1]++;
+  for (int64_t l = 0; l < nlev; ++l) lptr[l + 1] += lptr[l];
+  std::vector<int32_t> rows(n);
+  {
+    std::vector<int64_t> pos(lptr.begin(), lptr.end() - 1);
+    for (int64_t i = 0; i < n; ++i) rows[pos[level[i]]++] = (int32_t)i;
+  }
+  std::vector<int64_t> lrp(n + 1, 0);
+  for (int64_t q = 0; q < n; ++q) {
+    const int64_t i = rows[q];
+    lrp[q + 1] = lrp[q] + (upper ? rp[i + 1] - diag[i] - 1 : diag[i] - rp[i]);
+  }
+  std::vector<int32_t> cols((size_t)std::max<int64_t>(lrp[n], 1));
+  std::vector<double> vals((size_t)std::max<int64_t>(lrp[n], 1)), dinv;
+  if (upper) dinv.resize(n);
+  for (int64_t q = 0; q < n; ++q) {
+    const int64_t i = rows[q];
+    const int64_t k0 = upper ? diag[i] + 1 : rp[i], k1 = upper ? rp[i + 1] : diag[i];
+    std::copy(ci + k0, ci + k1, cols.begin() + lrp[q]);
+    std::copy(lu.begin() + k0, lu.begin() + k1, vals.begin() + lrp[q]);
+    if (upper) dinv[q] = lu[diag[i]];
+  }
+  S.desc.resize(nlev);
+  for (int64_t l = 0; l < nlev; ++l) {
+    const int64_t m = lptr[l + 1] - lptr[l];
+    const int64_t ent = lrp[lptr[l + 1]] - lrp[lptr[l]];
+    int Sl = 1; // lanes per row: about a quarter of the average row length, and in a fused level no more than the workgroup holds
+    while (Sl < 64 && 4 * Sl * m < ent) Sl <<= 1;
+    S.desc[l] = CsrLevel{(int32_t)m, Sl, lptr[l]};
+  }
+  int l = 0;
+  while (l < nlev) { // runs of levels whose rows x lanes fit a few rounds of one workgroup are fused
+    auto small = [&](int q) { return (int64_t)S.desc[q].m * S.desc[q].S <= 4 * TRSV_SMALL_WG; };
+    if (small(l)) {
+      int c = 0;
+      while (l + c < nlev && c < 4096 && small(l + c)) ++c;
+      S.plan.push_back({l, c, true});
+      l += c;
+    } else {
+      S.plan.push_back({l, 1, false});
+      l += 1;
+    }
+  }
+  DDMCHECK(upload(ctx, rows.data(), n, &S.rows));
+  DDMCHECK(upload(ctx, lrp.data(), n + 1, &S.lrp));
+  DDMCHECK(upload(ctx, cols.data(), lrp[n], &S.cols));
+  DDMCHECK(upload(ctx, vals.data(), lrp[n], &S.vals));
+  if (upper) DDMCHECK(upload(ctx, dinv.data(), n, &S.dinv));
+  DDMCHECK(upload(ctx, S.desc.data(), nlev, &S.d_desc));
+  if (block_ptr) DDMCHECK(upload(ctx, blp.data(), (int64_t)blp.size(), &S.blk_lev_ptr));
+  return DDM_OK;
+}
+static void free_csr_schedule(TriCsr &S)
+{
+  (void)hipFree(S.blk_lev_ptr);
+  (void)hipFree(S.rows);
+  (void)hipFree(S.lrp);
+  (void)hipFree(S.cols);
+  (void)hipFree(S.vals);
+  (void)hipFree(S.dinv);
+  (void)hipFree(S.d_desc);
+}
+static int enqueue_tri_csr(ddm_ctx *ctx, const TriCsr &S, bool upper, const double *d, double *x)
+{
+  if (S.nblocks > 0) { // one workgroup per independent block
+    if (upper)
+      hipLaunchKernelGGL(k_trsv_csr_blocks<true>, dim3(S.nblocks), dim3(TRSV_SMALL_WG), 0, ctx->stream, S.blk_lev_ptr, S.d_desc, S.rows, S.lrp, S.cols, S.vals, S.dinv, d, x);
+    else
+      hipLaunchKernelGGL(k_trsv_csr_blocks<false>, dim3(S.nblocks), dim3(TRSV_SMALL_WG), 0, ctx->stream, S.blk_lev_ptr, S.d_desc, S.rows, S.lrp, S.cols, S.vals, S.dinv, d, x);
+    HIPCHECK(ctx, hipGetLastError());
+    return DDM_OK;
+  }
+  for (const auto &p : S.plan) {
+    if (p.fused) {
+      if (upper)
+        hipLaunchKernelGGL(k_trsv_csr_fused<true>, dim3(1), dim3(TRSV_SMALL_WG), 0, ctx->stream, p.count, S.d_desc + p.first, S.rows, S.lrp, S.cols, S.vals, S.dinv, d, x);
+      else
+        hipLaunchKernelGGL(k_trsv_csr_fused<false>, dim3(1), dim3(TRSV_SMALL_WG), 0, ctx->stream, p.count, S.d_desc + p.first, S.rows, S.lrp, S.cols, S.vals, S.dinv, d, x);
+    } else {
+      const CsrLevel &L = S.desc[p.first];
+      const int gpb = WG / L.S;
+      const int grid = (int)std::min<int64_t>(((int64_t)L.m + gpb - 1) / gpb, 8192);
+      if (upper)
+        hipLaunchKernelGGL(k_trsv_csr_level<true>, dim3(grid), dim3(WG), 0, ctx->stream, L, S.rows, S.lrp, S.cols, S.vals, S.dinv, d, x);
+      else
+        hipLaunchKernelGGL(k_trsv_csr_level<false>, dim3(grid), dim3(WG), 0, ctx->stream, L, S.rows, S.lrp, S.cols, S.vals, S.dinv, d, x);
+    }
+  }
+  HIPCHECK(ctx, hipGetLastError());
+  return DDM_OK;
+}
+static void enqueue_multi_levels_csr(ddm_ctx *ctx, const TriCsr &S, bool upper, int nrhs, const double *D, int64_t ldd, double *X, int64_t ldx)
+{
+  int smax = 1;
+  while (2 * smax * nrhs <= WG && smax < 64) smax <<= 1;
+  for (int64_t l = 0; l < S.nlev; ++l) {
+    const CsrLevel &L = S.desc[l];
+    if (L.m == 0) continue;
+    const int Sm = std::min(L.S, smax);
+    const int rpb = WG / (Sm * nrhs);
+    const unsigned grid = (unsigned)((L.m + rpb - 1) / rpb);
+    if (upper)
+      hipLaunchKernelGGL(k_trsv_csr_level_multi<true>, dim3(grid), dim3(WG), 0, ctx->stream, L, Sm, nrhs, S.rows, S.lrp, S.cols, S.vals, S.dinv, D, ldd, X, ldx);
+    else
+      hipLaunchKernelGGL(k_trsv_csr_level_multi<false>, dim3(grid), dim3(WG), 0, ctx->stream, L, Sm, nrhs, S.rows, S.lrp, S.cols, S.vals, S.dinv, D, ldd, X, ldx);
+  }
+}
 static void free_schedule(TriSchedule &S)
 {
   (void)hipFree(S.rows);
@@ -561,8 +727,20 @@ static int build_pipe_schedule(ddm_ctx *ctx, ddm_ilu0 *F);
 static int ilu0_build_engines(ddm_ctx *ctx, ddm_ilu0 *F, const ddm_csr *A, const std::vector<int64_t> &diag, int64_t nblocks, const int64_t *block_ptr,
                               bool multi_rhs_only = false)
 {
-  int rc = build_schedule(ctx, A, F->h_lu, diag, false, F->L);
-  if (!rc) rc = build_schedule(ctx, A, F->h_lu, diag, true, F->U);
+  int rc = DDM_OK;
+  if (F->direct) {
+    rc = build_csr_schedule(ctx, A, F->h_lu, diag, false, F->Lc);
+    if (!rc) rc = build_csr_schedule(ctx, A, F->h_lu, diag, true, F->Uc);
+    if (!rc && nblocks >= 4) { // enough independent blocks to fill CUs with one workgroup each
+      rc = build_csr_schedule(ctx, A, F->h_lu, diag, false, F->Lb, nblocks, block_ptr);
+      if (!rc) rc = build_csr_schedule(ctx, A, F->h_lu, diag, true, F->Ub, nblocks, block_ptr);
+    }
+    F->L.nlev = F->Lc.nlev;
+    F->U.nlev = F->Uc.nlev;
+  } else {
+    rc = build_schedule(ctx, A, F->h_lu, diag, false, F->L);
+    if (!rc) rc = build_schedule(ctx, A, F->h_lu, diag, true, F->U);
+  }
   if (const char *m = std::getenv("DDM_TRSV_MODE")) F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "xcd2") ? 4 : 8);
   if (multi_rhs_only) F->mode = 0; // only ddm_ilu0_solve_multi will be called (level kernels): no pipe schedule, no tile stream
   F->A = A;
@@ -775,7 +953,9 @@ extern "C" int ddm_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks
   P->h_rp = std::move(R.rp);
   P->h_ci = std::move(R.ci);
   F->own_pattern = P;
-  int rc = ilu0_build_engines(ctx, F, P, R.diag, nblocks, block_ptr);
+  // a direct factor has few, wide rows per level and thousands of levels: the level kernels (runs of small levels fused into one
+  // workgroup that splits wide rows over lanes) take it; the pipe / xcd2 engines are built for the narrow rows of ILU(0)
+  int rc = ilu0_build_engines(ctx, F, P, R.diag, nblocks, block_ptr, /*multi_rhs_only (= level kernels)=*/true);
   if (!rc) rc = upload(ctx, R.perm.data(), A->nrows, &F->perm);
   if (!rc && (hipMalloc((void **)&F->pd, sizeof(double) * (size_t)std::max<int64_t>(F->n, 1)) != hipSuccess ||
               hipMalloc((void **)&F->px, sizeof(double) * (size_t)std::max<int64_t>(F->n, 1)) != hipSuccess))
@@ -825,6 +1005,10 @@ extern "C" void ddm_ilu0_destroy(ddm_ilu0 *F)
   (void)hipFree(F->p_queue);
   free_schedule(F->L);
   free_schedule(F->U);
+  free_csr_schedule(F->Lc);
+  free_csr_schedule(F->Uc);
+  free_csr_schedule(F->Lb);
+  free_csr_schedule(F->Ub);
   delete F;
 }
 // 0 = ok, 1 = a wave of the persistent kernel gave up waiting (results invalid); synchronous
@@ -1160,6 +1344,9 @@ extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double
     hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, F->xlpos, F->xrows, d, F->xdperm);
     hipLaunchKernelGGL(k_trsv_xcd2, dim3(persistent_grid(ctx)), dim3(64 * (1 + TRSV_L_LOADERS)), sizeof(TrsvLds), ctx->stream, F->ngroups, F->xg, F->xdesc, F->xflag_off,
                        F->xrows, F->xcols, F->xvals, F->xdinv, F->xdperm, x, F->xflags, F->xstate, F->err, (unsigned long long *)nullptr);
+  } else if (F->direct) {
+    rc = enqueue_tri_csr(ctx, F->Lb.nblocks ? F->Lb : F->Lc, false, d, x);
+    if (!rc) rc = enqueue_tri_csr(ctx, F->Ub.nblocks ? F->Ub : F->Uc, true, d, x);
   } else {
     rc = enqueue_tri(ctx, F->L, false, d, x);
     if (!rc) rc = enqueue_tri(ctx, F->U, true, d, x);
@@ -1238,7 +1425,8 @@ static int ilu0_solve_multi_ld(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double
   HIPCHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
   if (F->perm) { // sparse direct factor: solve in the fill-reducing order on packed work blocks
     hipLaunchKernelGGL(k_perm_gather, dim3(grid_for(F->n * nrhs)), dim3(WG), 0, ctx->stream, F->n, nrhs, F->perm, D, ldd, F->pD);
-    enqueue_multi_levels(ctx, F, nrhs, F->pD, nrhs, F->pX, nrhs);
+    enqueue_multi_levels_csr(ctx, F->Lc, false, nrhs, F->pD, nrhs, F->pX, nrhs);
+    enqueue_multi_levels_csr(ctx, F->Uc, true, nrhs, F->pD, nrhs, F->pX, nrhs);
     hipLaunchKernelGGL(k_perm_scatter, dim3(grid_for(F->n * nrhs)), dim3(WG), 0, ctx->stream, F->n, nrhs, F->perm, (const double *)F->pX, X, ldx);
   } else {
     enqueue_multi_levels(ctx, F, nrhs, D, ldd, X, ldx);

@@ -265,12 +265,158 @@ __global__ __launch_bounds__(TRSV_SMALL_WG) void k_trsv_small_levels(int nlev, c
 {
   for (int l = 0; l < nlev; ++l) {
     const LevelDesc L = desc[l];
-    for (int r = threadIdx.x; r < L.m; r += TRSV_SMALL_WG) {
-      const int row = rows[L.row_off + r];
-      const double s = trsv_row_sum<int>(UPPER ? x[row] : d[row], L.w, L.m, r, cols + L.ent_off, vals + L.ent_off, x);
-      x[row] = UPPER ? s * dinv[L.row_off + r] : s;
+    if (L.w >= 32 && 2 * L.m <= TRSV_SMALL_WG) {
+      // few wide rows (separator rows of a sparse direct factor: thousands of entries, often one row per level): S lanes
+      // of one wavefront share a row, each sums every S-th product, a butterfly adds the S partial sums (fixed order)
+      int S = 64;
+      while (S * L.m > TRSV_SMALL_WG) S >>= 1;
+      const int r = threadIdx.x / S, sl = threadIdx.x - r * S;
+      const bool act = r < L.m;
+      double s = 0.0;
+      if (act) {
+        const int32_t *cl = cols + L.ent_off;
+        const double *vl = vals + L.ent_off;
+        for (int k = sl; k < L.w; k += S) s += vl[(int64_t)k * L.m + r] * x[cl[(int64_t)k * L.m + r]];
+      }
+      for (int o = S >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      if (act && sl == 0) {
+        const int row = rows[L.row_off + r];
+        const double t = (UPPER ? x[row] : d[row]) - s;
+        x[row] = UPPER ? t * dinv[L.row_off + r] : t;
+      }
+    } else {
+      for (int r = threadIdx.x; r < L.m; r += TRSV_SMALL_WG) {
+        const int row = rows[L.row_off + r];
+        const double s = trsv_row_sum<int>(UPPER ? x[row] : d[row], L.w, L.m, r, cols + L.ent_off, vals + L.ent_off, x);
+        x[row] = UPPER ? s * dinv[L.row_off + r] : s;
+      }
     }
     __syncthreads(); // workgroup-scope release/acquire of the x entries just written
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Level-scheduled triangular solves for factors of the SPARSE DIRECT solver (csrc/sparse_chol_host.hpp).  Their rows differ from
+// ILU(0) rows: a level near the root of the elimination tree holds a handful of rows with thousands of entries, a leaf level
+// thousands of short rows, and there are thousands of levels -- sliced ELL would pad every level to its longest row.  Layout:
+// rows sorted by level, entries of a row contiguous (CSR in level order: lrp); S lanes (a power of two <= 64, chosen per level
+// from its row count) share a row, each sums every S-th product, a butterfly adds the S partial sums in a fixed order.
+struct CsrLevel {
+  int32_t m, S;
+  int64_t row_off;
+};
+template <bool UPPER>
+__device__ __forceinline__ void trsv_csr_rows(const CsrLevel L, int first_group, int ngroups_step, int tid, const int32_t *__restrict__ rows,
+                                              const int64_t *__restrict__ lrp, const int32_t *__restrict__ cols, const double *__restrict__ vals,
+                                              const double *__restrict__ dinv, const double *__restrict__ d, double *x)
+{
+  const int S = L.S;
+  const int g = tid / S, sl = tid - g * S;
+  for (int base = first_group; base < L.m; base += ngroups_step) { // every lane of a wavefront runs the same number of rounds
+    const int r = base + g;
+    const bool act = r < L.m;
+    double s = 0.0;
+    if (act) {
+      const int64_t k1 = lrp[L.row_off + r + 1];
+      // eight entries of the lane in flight: all column and value loads, then all gathers, then the products (in order)
+      for (int64_t k = lrp[L.row_off + r] + sl; k < k1; k += 8 * (int64_t)S) {
+        int32_t c[8];
+        double v[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int64_t kk = k + (int64_t)u * S;
+          const bool ok = kk < k1;
+          c[u] = ok ? cols[kk] : -1;
+          v[u] = ok ? vals[kk] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xv[u] = c[u] >= 0 ? x[c[u]] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u] * xv[u];
+      }
+    }
+    for (int o = S >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (act && sl == 0) {
+      const int row = rows[L.row_off + r];
+      const double t = (UPPER ? x[row] : d[row]) - s;
+      x[row] = UPPER ? t * dinv[L.row_off + r] : t;
+    }
+  }
+}
+// a run of consecutive small levels in ONE workgroup (levels separated by workgroup barriers)
+template <bool UPPER>
+__global__ __launch_bounds__(TRSV_SMALL_WG) void k_trsv_csr_fused(int nlev, const CsrLevel *__restrict__ desc, const int32_t *__restrict__ rows,
+                                                                   const int64_t *__restrict__ lrp, const int32_t *__restrict__ cols,
+                                                                   const double *__restrict__ vals, const double *__restrict__ dinv,
+                                                                   const double *__restrict__ d, double *x)
+{
+  for (int l = 0; l < nlev; ++l) {
+    const CsrLevel L = desc[l];
+    trsv_csr_rows<UPPER>(L, 0, TRSV_SMALL_WG / L.S, threadIdx.x, rows, lrp, cols, vals, dinv, d, x);
+    __syncthreads();
+  }
+}
+// one workgroup per independent diagonal block (subdomain): the whole triangular solve of the block, level after level
+template <bool UPPER>
+__global__ __launch_bounds__(TRSV_SMALL_WG) void k_trsv_csr_blocks(const int32_t *__restrict__ blk_lev_ptr, const CsrLevel *__restrict__ desc,
+                                                                    const int32_t *__restrict__ rows, const int64_t *__restrict__ lrp,
+                                                                    const int32_t *__restrict__ cols, const double *__restrict__ vals,
+                                                                    const double *__restrict__ dinv, const double *__restrict__ d, double *x)
+{
+  const int l1 = blk_lev_ptr[blockIdx.x + 1];
+  for (int l = blk_lev_ptr[blockIdx.x]; l < l1; ++l) {
+    const CsrLevel L = desc[l];
+    trsv_csr_rows<UPPER>(L, 0, TRSV_SMALL_WG / L.S, threadIdx.x, rows, lrp, cols, vals, dinv, d, x);
+    __syncthreads();
+  }
+}
+// one large level over the whole grid
+template <bool UPPER>
+__global__ __launch_bounds__(WG) void k_trsv_csr_level(CsrLevel L, const int32_t *__restrict__ rows, const int64_t *__restrict__ lrp,
+                                                       const int32_t *__restrict__ cols, const double *__restrict__ vals,
+                                                       const double *__restrict__ dinv, const double *__restrict__ d, double *x)
+{
+  const int gpb = WG / L.S;
+  trsv_csr_rows<UPPER>(L, blockIdx.x * gpb, gridDim.x * gpb, threadIdx.x, rows, lrp, cols, vals, dinv, d, x);
+}
+// multi-right-hand-side level (row-major n x nrhs blocks): S slices x nrhs columns of threads per row, slice sums meet in LDS
+template <bool UPPER>
+__global__ __launch_bounds__(WG) void k_trsv_csr_level_multi(CsrLevel L, int S, int nrhs, const int32_t *__restrict__ rows, const int64_t *__restrict__ lrp,
+                                                             const int32_t *__restrict__ cols, const double *__restrict__ vals,
+                                                             const double *__restrict__ dinv, const double *__restrict__ d, int64_t ldd, double *x, int64_t ldx)
+{
+  __shared__ double part[WG];
+  const int per_row = S * nrhs, rpb = WG / per_row;
+  const int g = threadIdx.x / per_row, u = threadIdx.x - g * per_row;
+  const int sl = u / nrhs, j = u - sl * nrhs;
+  const int r = blockIdx.x * rpb + g;
+  const bool act = g < rpb && r < L.m;
+  double s = 0.0;
+  if (act) {
+    const int64_t k1 = lrp[L.row_off + r + 1];
+    for (int64_t k = lrp[L.row_off + r] + sl; k < k1; k += 8 * (int64_t)S) {
+      int32_t c[8];
+      double v[8], xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t kk = k + (int64_t)u * S;
+        const bool ok = kk < k1;
+        c[u] = ok ? cols[kk] : -1;
+        v[u] = ok ? vals[kk] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xv[u] = c[u] >= 0 ? x[(int64_t)c[u] * ldx + j] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u] * xv[u];
+    }
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (act && sl == 0) {
+    const int64_t o = (int64_t)rows[L.row_off + r] * ldx + j;
+    double t = UPPER ? x[o] : d[(int64_t)rows[L.row_off + r] * ldd + j];
+    for (int q = 0; q < S; ++q) t -= part[g * per_row + q * nrhs + j];
+    x[o] = UPPER ? t * dinv[L.row_off + r] : t;
   }
 }
 

