@@ -91,8 +91,10 @@ def main():
         from dune_ddm_amd.geneo import geneo_basis
         tl = TwoLevelSchwarz(dec, rank, world, local_rank, comm, schwarz_type="standard", mode="additive", coarse="none")
         basis = geneo_basis(tl, nev=args.nev, verbose=(rank == 0 and os.environ.get("DDM_VERBOSE") == "1"))
-        log(rank, f"GenEO: {tl.geneo_info['iterations']} block iterations, converged={tl.geneo_info['converged']}, "
-                  f"lambda range of subdomain {tl.rl.local[0]}: {tl.geneo_info['eigenvalues'][tl.rl.local[0]][[0, -1]]}")
+        gi = tl.geneo_info      # geneo_basis raises if the eigensolver did not converge
+        log(rank, f"GenEO: {gi['iterations']} block iterations, converged={gi['converged']} (worst residual {gi['worst_residual']:.2e}), "
+                  f"preconditioner {'sparse Cholesky' if gi['used_direct'] else 'ILU(0)'}, setup {gi['setup_s']:.1f} s + iterations {gi['iterate_s']:.1f} s, "
+                  f"lambda range of subdomain {tl.rl.local[0]}: {gi['eigenvalues'][tl.rl.local[0]][[0, -1]]}")
         tl.set_coarse_basis(basis)
         tl.rebuild_combined("additive")
     else:
@@ -213,6 +215,7 @@ def main():
             "dof_iters_per_sec": ndof * its_per_s,
             "solve": solve_info,
             "setup_s": {"host": t_host, "device": t_dev},
+            "geneo": None if getattr(tl, "geneo_info", None) is None else {k: tl.geneo_info[k] for k in ("iterations", "converged", "worst_residual", "used_direct", "setup_s", "iterate_s", "nev")},
             "roofline": roofline, "iteration_traffic": iteration, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -61,6 +61,8 @@ SYMBOLS = {
     "ddm_ctx_sync": (_I32, [_P]),
     "ddm_ctx_stream": (_P, [_P]),
     "ddm_ctx_set_comm": (_I32, [_P, _I32, _I32, A2A_FN, ALLREDUCE_FN, _P]),
+    "ddm_rccl_unique_id": (_I32, [_P]),
+    "ddm_ctx_set_rccl": (_I32, [_P, _I32, _I32, _P, _I32]),
     "ddm_malloc": (_I32, [_P, _I64, _PP]),
     "ddm_free": (_I32, [_P, _P]),
     "ddm_memcpy_h2d": (_I32, [_P, _P, _P, _I64]),
@@ -190,6 +192,20 @@ class Context:
         b = ALLREDUCE_FN(lambda user, p, n: int(allreduce(p, n)))
         self._keep += [a, b]
         self.check(self.lib.ddm_ctx_set_comm(self.h, rank, nranks, a, b, None))
+        self.rank, self.nranks = rank, nranks
+
+    def rccl_unique_id(self):
+        """128 bytes identifying a new RCCL communicator (call on ONE rank, distribute to all)"""
+        buf = ctypes.create_string_buffer(128)
+        rc = self.lib.ddm_rccl_unique_id(buf)
+        if rc != DDM_OK:
+            raise DdmError(rc, "ddm_rccl_unique_id failed (librccl not loadable?)")
+        return buf.raw
+
+    def set_rccl(self, rank, nranks, unique_id, self_test=False):
+        """in-library exchange over RCCL / xGMI (collective over all ranks: ncclCommInitRank)"""
+        assert len(unique_id) == 128
+        self.check(self.lib.ddm_ctx_set_rccl(self.h, int(rank), int(nranks), ctypes.c_char_p(unique_id), int(bool(self_test))))
         self.rank, self.nranks = rank, nranks
 
     def timing(self, on=True):

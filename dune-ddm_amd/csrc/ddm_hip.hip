@@ -5,6 +5,9 @@
 #include "trsv_pipe.hpp"
 #include "sparse_chol_host.hpp"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types and enums only: the library is opened with dlopen when ddm_ctx_set_rccl is called
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -36,6 +39,20 @@ struct ddm_ctx {
   ddm_alltoall_fn a2a = nullptr;
   ddm_allreduce_fn allreduce = nullptr;
   void *user = nullptr;
+  // in-library exchange over RCCL (xGMI): ddm_ctx_set_rccl
+  struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  } nccl;
+  ncclComm_t rccl_comm = nullptr;
+  bool rccl = false, rccl_self = false; // rccl_self: route the self segment through RCCL too (single-GPU self test)
   double *partial = nullptr; // RED_MAX_BLOCKS doubles
   double *scal = nullptr;    // 16 device scalars
   int num_cu = 256;           // compute units of the device: persistent kernels launch at most this many workgroups
@@ -170,6 +187,11 @@ extern "C" int ddm_ctx_create(int device, void *hip_stream, ddm_ctx **out)
 
 extern "C" void ddm_ctx_destroy(ddm_ctx *ctx)
 {
+  if (ctx && ctx->rccl_comm && ctx->nccl.CommDestroy) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)ctx->nccl.CommDestroy(ctx->rccl_comm);
+    ctx->rccl_comm = nullptr;
+  }
   if (!ctx) return;
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->partial);
@@ -197,6 +219,75 @@ extern "C" int ddm_ctx_set_comm(ddm_ctx *ctx, int rank, int nranks, ddm_alltoall
   ctx->user = user;
   return DDM_OK;
 }
+// ---- in-library exchange: RCCL over xGMI ------------------------------------------------------------
+static void *rccl_open()
+{
+  for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+    if (void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) return h; // an already loaded copy (e.g. the host program's) is reused
+  return nullptr;
+}
+extern "C" int ddm_rccl_unique_id(void *id128)
+{
+  if (!id128) return DDM_EINVAL;
+  void *h = rccl_open();
+  if (!h) return DDM_ECOMM;
+  auto get = (ncclResult_t(*)(ncclUniqueId *))dlsym(h, "ncclGetUniqueId");
+  ncclUniqueId id;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  if (!get || get(&id) != ncclSuccess) return DDM_ECOMM;
+  std::memcpy(id128, &id, 128);
+  return DDM_OK;
+}
+extern "C" int ddm_ctx_set_rccl(ddm_ctx *ctx, int rank, int nranks, const void *id128, int self_test)
+{
+  if (!ctx || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, DDM_EINVAL, "ddm_ctx_set_rccl: bad rank %d of %d", rank, nranks);
+  if (ctx->rccl_comm) return fail(ctx, DDM_EINVAL, "ddm_ctx_set_rccl: the context already has a communicator");
+  auto &N = ctx->nccl;
+  N.lib = rccl_open();
+  if (!N.lib) return fail(ctx, DDM_ECOMM, "librccl.so.1 cannot be loaded: %s", dlerror());
+  N.CommInitRank = (decltype(N.CommInitRank))dlsym(N.lib, "ncclCommInitRank");
+  N.CommDestroy = (decltype(N.CommDestroy))dlsym(N.lib, "ncclCommDestroy");
+  N.GroupStart = (decltype(N.GroupStart))dlsym(N.lib, "ncclGroupStart");
+  N.GroupEnd = (decltype(N.GroupEnd))dlsym(N.lib, "ncclGroupEnd");
+  N.Send = (decltype(N.Send))dlsym(N.lib, "ncclSend");
+  N.Recv = (decltype(N.Recv))dlsym(N.lib, "ncclRecv");
+  N.AllReduce = (decltype(N.AllReduce))dlsym(N.lib, "ncclAllReduce");
+  N.GetErrorString = (decltype(N.GetErrorString))dlsym(N.lib, "ncclGetErrorString");
+  if (!N.CommInitRank || !N.CommDestroy || !N.GroupStart || !N.GroupEnd || !N.Send || !N.Recv || !N.AllReduce)
+    return fail(ctx, DDM_ECOMM, "librccl lacks a required entry point");
+  HIPCHECK(ctx, hipSetDevice(ctx->device));
+  ncclUniqueId id;
+  std::memcpy(&id, id128, 128);
+  const ncclResult_t r = N.CommInitRank(&ctx->rccl_comm, nranks, id, rank);
+  if (r != ncclSuccess) {
+    ctx->rccl_comm = nullptr;
+    return fail(ctx, DDM_ECOMM, "ncclCommInitRank failed: %s", N.GetErrorString ? N.GetErrorString(r) : "?");
+  }
+  ctx->rank = rank;
+  ctx->nranks = nranks;
+  ctx->rccl = true;
+  ctx->rccl_self = self_test != 0;
+  ctx->a2a = nullptr;
+  ctx->allreduce = nullptr;
+  return DDM_OK;
+}
+#define NCCLCHECK(ctx, call)                                                                                                   \
+  do {                                                                                                                         \
+    const ncclResult_t r_ = (call);                                                                                            \
+    if (r_ != ncclSuccess) return fail(ctx, DDM_ECOMM, "%s failed: %s", #call, ctx->nccl.GetErrorString ? ctx->nccl.GetErrorString(r_) : "?"); \
+  } while (0)
+// in-place sum over all ranks of n doubles at a device pointer, enqueued on the context's stream
+static int ctx_allreduce(ddm_ctx *ctx, double *buf, int64_t n, const char *what)
+{
+  if (ctx->rccl) {
+    if (ctx->nranks > 1 || ctx->rccl_self) NCCLCHECK(ctx, ctx->nccl.AllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, ctx->rccl_comm, ctx->stream));
+    return DDM_OK;
+  }
+  if (ctx->nranks > 1)
+    if (ctx->allreduce(ctx->user, buf, n) != 0) return fail(ctx, DDM_ECOMM, "allreduce callback failed (%s)", what);
+  return DDM_OK;
+}
+
 extern "C" int ddm_malloc(ddm_ctx *ctx, int64_t bytes, void **dptr)
 {
   HIPCHECK(ctx, hipMalloc(dptr, (size_t)std::max<int64_t>(bytes, 8)));
@@ -1456,6 +1547,7 @@ struct ddm_halo {
   int64_t *send_idx = nullptr, *dst_idx = nullptr, *dst_ptr = nullptr, *src_pos = nullptr;
   double *sendbuf = nullptr, *recvbuf = nullptr;
   bool remote = false; // any traffic to/from other ranks
+  std::vector<int64_t> send_counts, recv_counts; // per peer (the layout of sendbuf / recvbuf)
 };
 
 extern "C" int ddm_halo_create(ddm_ctx *ctx, int tag, int mode, int64_t nsend, const int64_t *send_idx,
@@ -1468,6 +1560,8 @@ extern "C" int ddm_halo_create(ddm_ctx *ctx, int tag, int mode, int64_t nsend, c
   H->mode = mode;
   H->nsend = nsend;
   H->ndst = ndst;
+  H->send_counts.assign(send_counts, send_counts + ctx->nranks);
+  H->recv_counts.assign(recv_counts, recv_counts + ctx->nranks);
   int64_t ssum = 0, rsum = 0;
   for (int r = 0; r < ctx->nranks; ++r) {
     if (r == ctx->rank) {
@@ -1527,7 +1621,23 @@ extern "C" int ddm_halo_exchange(ddm_ctx *ctx, ddm_halo *H, double *v)
   if (H->nsend == 0 && H->ndst == 0 && !H->remote) return DDM_OK;
   if (H->nsend > 0) hipLaunchKernelGGL(k_pack, dim3(grid_for(H->nsend)), dim3(WG), 0, ctx->stream, H->nsend, H->send_idx, v, H->sendbuf);
   const double *rbuf = H->recvbuf;
-  if (ctx->nranks > 1) {
+  if (ctx->rccl && (ctx->nranks > 1 || ctx->rccl_self)) {
+    // one grouped point-to-point exchange on the context's stream (xGMI links are point-to-point: every peer pair is its own
+    // transfer); the self segment stays a device copy unless the single-GPU self test routes it through RCCL as well
+    if (H->self_count > 0 && !ctx->rccl_self)
+      HIPCHECK(ctx, hipMemcpyAsync(H->recvbuf + H->self_off_recv, H->sendbuf + H->self_off_send, sizeof(double) * (size_t)H->self_count, hipMemcpyDeviceToDevice, ctx->stream));
+    NCCLCHECK(ctx, ctx->nccl.GroupStart());
+    int64_t so = 0, ro = 0;
+    for (int r = 0; r < ctx->nranks; ++r) {
+      const bool self = r == ctx->rank;
+      if ((!self || ctx->rccl_self) && H->recv_counts[r] > 0) NCCLCHECK(ctx, ctx->nccl.Recv(H->recvbuf + ro, (size_t)H->recv_counts[r], ncclDouble, r, ctx->rccl_comm, ctx->stream));
+      if ((!self || ctx->rccl_self) && H->send_counts[r] > 0) NCCLCHECK(ctx, ctx->nccl.Send(H->sendbuf + so, (size_t)H->send_counts[r], ncclDouble, r, ctx->rccl_comm, ctx->stream));
+      so += H->send_counts[r];
+      ro += H->recv_counts[r];
+    }
+    NCCLCHECK(ctx, ctx->nccl.GroupEnd());
+  } else if (ctx->nranks > 1) {
+    if (!ctx->a2a) return fail(ctx, DDM_ECOMM, "multi-rank context without an exchange (ddm_ctx_set_rccl / ddm_ctx_set_comm)");
     if (ctx->a2a(ctx->user, H->tag, H->sendbuf, H->recvbuf) != 0) return fail(ctx, DDM_ECOMM, "alltoall callback failed (tag %d)", H->tag);
   } else {
     rbuf = H->sendbuf; // single rank: the self segment is the whole buffer
@@ -1553,8 +1663,7 @@ static int dot_device(ddm_ctx *ctx, int64_t n, const uint8_t *mask, const double
     hipLaunchKernelGGL(k_dot_partial<false>, dim3(nb), dim3(WG), 0, ctx->stream, n, mask, x, y, ctx->partial);
   hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(WG), 0, ctx->stream, nb, ctx->partial, result_dev);
   HIPCHECK(ctx, hipGetLastError());
-  if (ctx->nranks > 1)
-    if (ctx->allreduce(ctx->user, result_dev, 1) != 0) return fail(ctx, DDM_ECOMM, "allreduce callback failed");
+  DDMCHECK(ctx_allreduce(ctx, result_dev, 1, "scalar product"));
   return DDM_OK;
 }
 
@@ -1835,8 +1944,7 @@ static int galerkin_apply_impl(ddm_ctx *ctx, ddm_galerkin *G, double *x, const d
   hipLaunchKernelGGL(k_coarse_restrict_final, dim3(1), dim3(WG), 0, ctx->stream, (int)G->nsub, (int)G->kmax, G->sub_chunk_ptr, G->partial,
                      G->coarse_index, G->K, G->d0);
   HIPCHECK(ctx, hipGetLastError());
-  if (ctx->nranks > 1) // replaces MPI_Gatherv (:170-171): every rank obtains the full coarse defect
-    if (ctx->allreduce(ctx->user, G->d0, G->K) != 0) return fail(ctx, DDM_ECOMM, "allreduce callback failed (coarse defect)");
+  DDMCHECK(ctx_allreduce(ctx, G->d0, G->K, "coarse defect")); // replaces MPI_Gatherv (:170-171): every rank obtains the full coarse defect
   hipLaunchKernelGGL(k_dense_mv, dim3((unsigned)((G->K + 3) / 4)), dim3(WG), 0, ctx->stream, G->K, G->a0inv, G->d0, G->x0); // :174-179 (replicated)
   hipLaunchKernelGGL(k_coarse_prolong, dim3(G->nchunk), dim3(WG), 0, ctx->stream, (int)G->kmax, G->ld, G->basis, G->x0, G->coarse_index,
                      G->chunks, G->x_ovlp);       // :186-188

@@ -28,14 +28,17 @@ inline void check(ddm_ctx* ctx, int rc, const char* what)
 }
 
 // One context per process (= per MPI rank = per GPU), shared by all operators of the solve.
+// Multi-rank runs: call ddm_hip::install_mpi_exchange(ctx, MPI_Comm) (mpi_exchange.hh) -- or ddm_ctx_set_rccl /
+// ddm_ctx_set_comm yourself -- right after the first Context::get(); without an installed exchange every adaptor that
+// meets a communicator of size > 1 throws Dune::NotImplemented instead of computing rank-local nonsense.
 class Context {
 public:
-  static std::shared_ptr<Context> get(int device = 0)
+  static std::shared_ptr<Context> get(int device = -1)
   {
     static std::weak_ptr<Context> inst;
     auto p = inst.lock();
     if (!p) {
-      p = std::shared_ptr<Context>(new Context(device));
+      p = std::shared_ptr<Context>(new Context(device < 0 ? 0 : device));
       inst = p;
     }
     return p;
@@ -43,6 +46,23 @@ public:
   ~Context() { ddm_ctx_destroy(h_); }
   ddm_ctx* handle() const { return h_; }
   int rank = 0, nranks = 1;
+  bool exchange_installed = false;
+  // called by every adaptor with its DUNE communicator: rank / size must agree with the installed exchange
+  template <class Communicator>
+  void require(const Communicator& cc)
+  {
+    const int sz = cc.size(), rk = cc.rank();
+    if (sz == 1) return;
+    if (!exchange_installed)
+      DUNE_THROW(Dune::NotImplemented, "communicator of size " << sz << ": install the inter-rank exchange first (ddm_hip::install_mpi_exchange, dune/ddm/hip/mpi_exchange.hh)");
+    if (sz != nranks || rk != rank)
+      DUNE_THROW(Dune::InvalidStateException, "communicator rank/size (" << rk << "/" << sz << ") differ from the installed exchange (" << rank << "/" << nranks << ")");
+  }
+  // per-halo send/receive layout, kept for the MPI exchange (tag -> per-peer counts)
+  struct HaloCounts {
+    std::vector<int64_t> send_counts, recv_counts;
+  };
+  std::map<int, HaloCounts> halo_counts;
 
 private:
   explicit Context(int device)
@@ -131,6 +151,8 @@ public:
     std::vector<std::pair<int64_t, int64_t>> dst;   // (destination local index, position in recv buffer)
     int64_t pos = 0;
     for (const auto& [nbr, info] : iface.interfaces()) {   // std::map: ascending neighbour rank
+      if (nbr < 0 || nbr >= P)
+        DUNE_THROW(Dune::InvalidStateException, "interface names neighbour rank " << nbr << " but the context knows " << P << " rank(s): install the inter-rank exchange before building operators");
       for (std::size_t i = 0; i < info.first.size(); ++i) send_idx.push_back((int64_t)info.first[i]);
       send_counts[nbr] = (int64_t)info.first.size();
       for (std::size_t i = 0; i < info.second.size(); ++i) dst.emplace_back((int64_t)info.second[i], pos++);
@@ -151,6 +173,7 @@ public:
           ddm_halo_create(ctx_->handle(), tag, mode, (int64_t)send_idx.size(), send_idx.data(), send_counts.data(), recv_counts.data(),
                           (int64_t)dst_idx.size(), dst_idx.data(), dst_ptr.data(), src_pos.data(), &h_),
           "ddm_halo_create");
+    ctx_->halo_counts[tag] = Context::HaloCounts{send_counts, recv_counts};
   }
   Halo(const Halo&) = delete;
   ~Halo() { ddm_halo_destroy(h_); }

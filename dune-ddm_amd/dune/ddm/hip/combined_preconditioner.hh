@@ -67,6 +67,7 @@ public:
     if (!C) fuse(n_novlp);
     return C;
   }
+  std::shared_ptr<ddm_hip::Context> context() const { return ctx; }
 
 private:
   void fuse(std::size_t n_novlp)

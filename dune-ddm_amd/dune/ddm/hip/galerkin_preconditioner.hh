@@ -63,6 +63,7 @@ public:
                          const std::string& /*subtree_name*/ = "galerkin")
       : comm(std::move(comm)), n(A.N()), num_t((int)ts.size()), ctx(ddm_hip::Context::get())
   {
+    ctx->require(this->comm->communicator());
     if (ts.size() == 0) DUNE_THROW(Dune::Exception, "Must at least pass one template vector");              // :129
     if (ts[0].N() != A.N()) DUNE_THROW(Dune::Exception, "Template vectors must match size of matrix");      // :131
     const auto& cc = this->comm->communicator();

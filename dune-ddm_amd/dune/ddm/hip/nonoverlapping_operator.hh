@@ -26,6 +26,7 @@ public:
   NonOverlappingOperator(std::shared_ptr<Mat> A, std::shared_ptr<Communication> comm)
       : A(std::move(A)), comm(std::move(comm)), ctx(ddm_hip::Context::get())
   {
+    ctx->require(this->comm->communicator());
     dA = std::make_unique<ddm_hip::DeviceCsr>(ctx, *this->A);
     // addOwnerCopyToOwnerCopy: (owner|copy) -> (owner|copy) on the non-overlapping index set
     typename Communication::OwnerCopySet oc;   // Combine<OwnerSet, CopySet>

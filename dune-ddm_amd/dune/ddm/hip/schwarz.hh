@@ -36,9 +36,11 @@ public:
     const auto& solver_subtree = subtree.sub(solver_subtree_name);
     if (not solver_subtree.hasKey("type"))
       DUNE_THROW(Dune::Exception, "You must specify the solver in the subtree " << subtree_name << "." << solver_subtree_name << " using the key 'type'");   // :89-91
-    const auto solver = solver_subtree.get("type", std::string(""));
-    if (solver != "ilu0" && solver != "hip_ilu0")
-      DUNE_THROW(Dune::NotImplemented, "subdomain solver '" + solver + "' is not available on the device (ILU(0) only; direct solvers: SURVEY.md 8f-2)");
+    // the factory key of the reference (schwarz.hh:85-92; shipped: cholmod / umfpack, examples/poisson.ini:23): ILU(0) or the
+    // library's sparse direct solvers (host factorisation, device triangular solves) -- ddm_schwarz_create_ex validates the name
+    solver = solver_subtree.get("type", std::string(""));
+    if (solver == "hip_ilu0") solver = "ilu0";
+    ctx->require(this->comm->communicator());
     // size checks of init() (:186-193)
     if (this->comm->indexSet().size() != this->Aovlp->N())
       DUNE_THROW(Dune::InvalidStateException, "Remote indices size (" << this->comm->indexSet().size() << ") does not match overlapping matrix size (" << this->Aovlp->N() << ").");
@@ -58,7 +60,12 @@ public:
 
   Dune::SolverCategory::Category category() const override { return Dune::SolverCategory::nonoverlapping; }
   void pre(Vec&, Vec&) override {}
-  void post(Vec&) override {}
+  // apply() has no error return (the reference discards the local solver's InverseOperatorResult, schwarz.hh:131): a local solve
+  // that gave up (single-launch engine, GPU shared with another process) is reported here, at the end of the Krylov solve
+  void post(Vec&) override
+  {
+    if (S) ddm_hip::check(ctx->handle(), ddm_schwarz_status(ctx->handle(), S), "SchwarzPreconditioner::post");
+  }
 
   void apply(Vec& x, const Vec& d) override   // :115-149
   {
@@ -91,8 +98,8 @@ private:
     }
     const int64_t bp[2] = {0, (int64_t)n};
     ddm_hip::check(ctx->handle(),
-                   ddm_schwarz_create(ctx->handle(), dA->handle(), 1, bp, (int64_t)n_novlp, ext.data(), pou ? w.data() : nullptr,
-                                      type == SchwarzType::Restricted ? 1 : 0, h_copy->handle(), h_add->handle(), &S),
+                   ddm_schwarz_create_ex(ctx->handle(), dA->handle(), 1, bp, (int64_t)n_novlp, ext.data(), pou ? w.data() : nullptr,
+                                         type == SchwarzType::Restricted ? 1 : 0, solver.c_str(), h_copy->handle(), h_add->handle(), &S),
                    "ddm_schwarz_create");
     dd = std::make_unique<ddm_hip::DeviceVector>(ctx, n_novlp);
     dx = std::make_unique<ddm_hip::DeviceVector>(ctx, n_novlp);
@@ -103,6 +110,7 @@ private:
   std::shared_ptr<PartitionOfUnity> pou;
   std::shared_ptr<ddm_hip::Context> ctx;
   SchwarzType type;
+  std::string solver;
   std::unique_ptr<ddm_hip::DeviceCsr> dA;
   std::unique_ptr<ddm_hip::Halo> h_copy, h_add;
   std::unique_ptr<ddm_hip::DeviceVector> dd, dx;

@@ -60,6 +60,14 @@ typedef int (*ddm_alltoall_fn)(void *user, int tag, const double *sendbuf, doubl
 typedef int (*ddm_allreduce_fn)(void *user, double *buf, int64_t n);
 int ddm_ctx_set_comm(ddm_ctx *ctx, int rank, int nranks, ddm_alltoall_fn a2a, ddm_allreduce_fn allreduce, void *user);
 
+/* The same exchange INSIDE the library over RCCL (xGMI): grouped ncclSend / ncclRecv per halo and ncclAllReduce for the dots and the
+ * coarse defect, all enqueued on the context's stream -- no callback round trip through the host program.  librccl is opened with
+ * dlopen (a copy the host program already loaded is reused).  ddm_rccl_unique_id fills 128 bytes on ONE rank; the host program
+ * distributes them (MPI_Bcast / torch.distributed.broadcast) and every rank calls ddm_ctx_set_rccl (collective: ncclCommInitRank).
+ * self_test != 0: also route the rank's own halo segment and all reductions through RCCL (exercises the path on a single GPU). */
+int ddm_rccl_unique_id(void *id128);
+int ddm_ctx_set_rccl(ddm_ctx *ctx, int rank, int nranks, const void *id128, int self_test);
+
 /* raw device memory helpers for callers that do not bring their own allocator */
 int ddm_malloc(ddm_ctx *ctx, int64_t bytes, void **dptr);
 int ddm_free(ddm_ctx *ctx, void *dptr);

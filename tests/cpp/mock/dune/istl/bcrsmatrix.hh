@@ -55,6 +55,7 @@ public:
   std::size_t N() const { return n; }
   std::size_t M() const { return m; }
   std::size_t nonzeroes() const { return ci.size(); }
+  Row operator[](std::size_t i) const { return Row(this, i); }
   RowIterator begin() const { return RowIterator(this, 0); }
   RowIterator end() const { return RowIterator(this, n); }
 private:

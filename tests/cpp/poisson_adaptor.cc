@@ -3,6 +3,10 @@
 // CombinedPreconditioner + NonOverlappingOperator + its scalar product inside a CG loop written
 // against the abstract dune-istl interfaces.  Single rank (mock communication, see mock/).
 //   usage: poisson_adaptor <dir with n.txt rowptr.bin col.bin val.bin b.bin dirichlet.bin pou.bin> <mode>
+// mode = additive | multiplicative : dune-istl's CG written out on the abstract interfaces (two PCIe copies per virtual call)
+// mode = device | device_cholmod   : the factory-style path -- coarse space from a CoarseSpaceBuilder task, solver from
+//                                    Dune::getHipSolver (whole CG on the device: one upload, one download), subdomain solver
+//                                    ilu0 resp. cholmod; also exercises the Dune::InverseOperator plugin HipSubdomainSolver
 #include <cmath>
 #include <cstdio>
 #include <fstream>
@@ -19,6 +23,8 @@
 #include <dune/ddm/hip/galerkin_preconditioner.hh>
 #include <dune/ddm/hip/nonoverlapping_operator.hh>
 #include <dune/ddm/hip/schwarz.hh>
+#include <dune/ddm/hip/coarse_spaces.hh>
+#include <dune/ddm/hip/solvers.hh>
 
 template <class T>
 static std::vector<T> slurp(const std::string& f)
@@ -53,8 +59,64 @@ int main(int argc, char** argv)
 
     Dune::ParameterTree ptree;
     ptree.sub("schwarz")["type"] = "standard";
-    ptree.sub("schwarz").sub("subdomain_solver")["type"] = "ilu0";
-    ptree.sub("combined_preconditioner")["mode"] = mode;
+    ptree.sub("schwarz").sub("subdomain_solver")["type"] = mode == "device_cholmod" ? "cholmod" : "ilu0";
+    ptree.sub("combined_preconditioner")["mode"] = mode.rfind("device", 0) == 0 ? "additive" : mode;
+    if (mode.rfind("device", 0) == 0) {
+      // examples/poisson.cc:229-321 with the device-resident pieces
+      auto pou = std::make_shared<PartitionOfUnity>(pw);
+      auto schwarz = std::make_shared<SchwarzPreconditioner<Mat, Vec, Comm>>(A, comm, pou, ptree);
+      tf::Taskflow taskflow("Main taskflow");
+      auto coarse_space = std::make_unique<POUCoarseSpace<Vec>>(pou, taskflow);
+      std::shared_ptr<GalerkinPreconditioner<Vec, Comm>> coarse;
+      auto task = taskflow.emplace([&]() {
+        auto basis = coarse_space->get_basis();
+        for (auto& v : basis)
+          for (std::size_t i = 0; i < n; ++i)
+            if (dm[i]) v[i] = 0.0;   // zero_at_dirichlet (poisson.cc:235-238)
+        coarse = std::make_shared<GalerkinPreconditioner<Vec, Comm>>(*A, basis, comm, ptree, "coarse_solver");
+      });
+      task.name("Build coarse preconditioner").succeed(coarse_space->get_setup_task());
+      tf::Executor executor(1);
+      executor.run(taskflow).get();
+      auto op = std::make_shared<NonOverlappingOperator<Mat, Vec, Vec, Comm>>(A, comm);
+      auto prec = std::make_shared<CombinedPreconditioner<Vec>>(ptree);
+      prec->set_op(op);
+      prec->add(schwarz);
+      prec->add(coarse);
+      Dune::ParameterTree solver_subtree;
+      solver_subtree["type"] = "cgsolver";
+      solver_subtree["reduction"] = "1e-10";
+      solver_subtree["maxit"] = "500";
+      auto solver = Dune::getHipSolver<Vec>(op, solver_subtree, prec);
+      Dune::InverseOperatorResult res;
+      Vec v(n), b(n);
+      for (std::size_t i = 0; i < n; ++i) b[i] = bb[i];
+      v = 0;
+      solver->apply(v, b, res);   // poisson.cc:318-319
+      std::printf("device_solve iterations %d converged %d reduction %.17g\n", res.iterations, (int)res.converged, res.reduction);
+      std::ofstream out(dir + "/x_device.bin", std::ios::binary);
+      for (std::size_t i = 0; i < n; ++i) { const double xi = v[i][0]; out.write(reinterpret_cast<const char*>(&xi), 8); }
+      // the InverseOperator plugin on its own: exact solve A y = b with the sparse Cholesky, ILU(0) application
+      Dune::HipSubdomainSolver<Mat> chol(*A, "cholesky"), ilu(*A, "ilu0");
+      Vec y(n), rhs(n), z(n);
+      for (std::size_t i = 0; i < n; ++i) rhs[i] = bb[i];
+      Dune::InverseOperatorResult r2;
+      chol.apply(y, rhs, r2);
+      double rmax = 0, bmax = 0;
+      for (auto ri = A->begin(); ri != A->end(); ++ri) {
+        double s = 0;
+        for (auto c = ri->begin(); c != ri->end(); ++c) s += (*c)[0][0] * y[c.index()][0];
+        rmax = std::max(rmax, std::fabs(s - bb[ri.index()]));
+        bmax = std::max(bmax, std::fabs(bb[ri.index()]));
+      }
+      ilu.apply(z, rhs, r2);
+      std::printf("plugin cholesky_residual %.3e converged %d\n", rmax / bmax, (int)r2.converged);
+      int caught = 0;
+      try { Dune::HipSubdomainSolver<Mat> bad(*A, "bogus"); } catch (Dune::NotImplemented&) { ++caught; }
+      try { solver_subtree["type"] = "bicgstabsolver"; Dune::getHipSolver<Vec>(op, solver_subtree, prec); } catch (Dune::NotImplemented&) { ++caught; }
+      std::printf("errors_caught %d\n", caught);
+      return 0;
+    }
 
     auto pou = std::make_shared<PartitionOfUnity>(pw);
     auto schwarz = std::make_shared<SchwarzPreconditioner<Mat, Vec, Comm>>(A, comm, pou, ptree);
