@@ -111,15 +111,28 @@ class TwoLevelSchwarz:
         self.dec = dec
         self.comm = comm
         self.ctx = torch_context(device)
-        if nranks > 1:
-            assert comm is not None
-            self.ctx.set_comm(rank, nranks, comm.alltoall, comm.allreduce)
+        import os
+        self.exchange = "none"
+        if nranks > 1 or os.environ.get("DDM_RCCL_SELFTEST") == "1":
+            # inter-rank exchange: inside the library over RCCL / xGMI when the job runs on the nccl backend (one process per
+            # GPU), else the callbacks over torch.distributed (gloo rehearsal: staged through the host; DDM_EXCHANGE=callback
+            # forces them on nccl too).  torch.distributed only distributes the 128-byte communicator id.
+            in_library = (comm is not None and comm.backend == "nccl" and os.environ.get("DDM_EXCHANGE", "rccl") != "callback") or nranks == 1
+            if in_library:
+                uid = [self.ctx.rccl_unique_id() if rank == 0 else None]
+                if nranks > 1:
+                    comm.dist.broadcast_object_list(uid, src=0)
+                self.ctx.set_rccl(rank, nranks, uid[0], self_test=(nranks == 1))
+                self.exchange = "rccl"
+            else:
+                assert comm is not None
+                self.ctx.set_comm(rank, nranks, comm.alltoall, comm.allreduce)
+                self.exchange = "callback"
         rl = self.rl = RankLocal(dec, rank, nranks)
         ctx = self.ctx
         if comm is not None and comm.backend != "nccl":
             # gloo rehearsal: several ranks share one GPU.  The single-launch triangular solves need all
             # their workgroups co-resident (one process per GPU); fall back to one launch per level.
-            import os
             os.environ["DDM_TRSV_MODE"] = "levels"
         self.A = CsrMatrix(ctx, rl.A)
         self.A_dir = CsrMatrix(ctx, rl.A_dir)

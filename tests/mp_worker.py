@@ -62,6 +62,28 @@ def numpy_halo_exchange(plan, mode, v, rank, world):
 
 def main():
     mode = sys.argv[1]
+    if mode == "solve_nccl":
+        # one process per GPU, RCCL: the in-library exchange (ddm_ctx_set_rccl) -- or, with DDM_EXCHANGE=callback, the callbacks
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        rank, world = dist.get_rank(), dist.get_world_size()
+        from dune_ddm_amd.solver import TorchComm, TwoLevelSchwarz
+        grid = synth.StructuredPoisson((15, 14, 13), (2, 2, 2))
+        dec = build_structured(grid, overlap=2, pou_type="distance")
+        tl = TwoLevelSchwarz(dec, rank, world, local, TorchComm(), schwarz_type="standard", mode="additive", coarse="pou")
+        res, hist, x = tl.solve(reduction=1e-10, maxit=300)
+        tl.prec.check_status()
+        if rank == 0:
+            from tests.oracle_bridge import oracle_solve
+            it, conv, hist_o, xo = oracle_solve(dec, reduction=1e-10, maxit=300, coarse="pou", schwarz_type="standard", mode="additive")
+            ho = np.array(hist_o)
+            assert res.iterations == it and res.converged and conv, (res.iterations, it)
+            assert (np.abs(hist - ho) <= 1e-8 * ho + 1e-14 * ho[0]).all()
+            print("NCCL_SOLVE_OK", world, it, tl.exchange, tl.schwarz.engine())
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     if mode == "plans":
