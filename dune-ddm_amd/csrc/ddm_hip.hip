@@ -1934,12 +1934,18 @@ extern "C" void ddm_galerkin_destroy(ddm_galerkin *G)
   (void)hipFree(G->x_ovlp);
   delete G;
 }
-static int galerkin_apply_impl(ddm_ctx *ctx, ddm_galerkin *G, double *x, const double *d, bool acc)
+// d_ovlp_ready: the overlapping defect (extended + owner values copied to all holders) if the caller already has it -- in the
+// additive combination both levels start from the same defect (schwarz.hh:121-125 and galerkin_preconditioner.hh:159-162)
+static int galerkin_apply_impl(ddm_ctx *ctx, ddm_galerkin *G, double *x, const double *d, bool acc, const double *d_ovlp_ready = nullptr)
 {
   ScopedTimer t(ctx, "GalerkinPrec/apply");
-  hipLaunchKernelGGL(k_extend, dim3(grid_for(G->n)), dim3(WG), 0, ctx->stream, G->n, G->ext_map, d, G->d_ovlp); // :159
-  DDMCHECK(ddm_halo_exchange(ctx, G->copy, G->d_ovlp));                                                         // :162
-  hipLaunchKernelGGL(k_coarse_restrict_partial, dim3(G->nchunk), dim3(WG), 0, ctx->stream, (int)G->kmax, G->ld, G->basis, G->d_ovlp,
+  const double *dov = d_ovlp_ready;
+  if (!dov) {
+    hipLaunchKernelGGL(k_extend, dim3(grid_for(G->n)), dim3(WG), 0, ctx->stream, G->n, G->ext_map, d, G->d_ovlp); // :159
+    DDMCHECK(ddm_halo_exchange(ctx, G->copy, G->d_ovlp));                                                         // :162
+    dov = G->d_ovlp;
+  }
+  hipLaunchKernelGGL(k_coarse_restrict_partial, dim3(G->nchunk), dim3(WG), 0, ctx->stream, (int)G->kmax, G->ld, G->basis, dov,
                      G->chunks, G->partial); // :165-167
   hipLaunchKernelGGL(k_coarse_restrict_final, dim3(1), dim3(WG), 0, ctx->stream, (int)G->nsub, (int)G->kmax, G->sub_chunk_ptr, G->partial,
                      G->coarse_index, G->K, G->d0);
@@ -2048,7 +2054,10 @@ extern "C" int ddm_combined_apply(ddm_ctx *ctx, ddm_combined *C, double *x, cons
   DDMCHECK(schwarz_apply_impl(ctx, C->schwarz, x, d, false));
   if (!C->galerkin) return DDM_OK;
   if (C->mode == 0) { // additive: xnext = P1 d; x += xnext (:136-142) -- fused into the restrict of the coarse level
-    return galerkin_apply_impl(ctx, C->galerkin, x, d, true);
+    // both levels extend the same defect over the same interface: the Schwarz level's copy is reused (the local solves read it only)
+    static const bool no_share = std::getenv("DDM_NO_SHARED_DEFECT") != nullptr; // diagnostic switch
+    const bool share = !no_share && C->galerkin->copy == C->schwarz->copy && C->galerkin->n == C->schwarz->n && C->galerkin->n_novlp == C->schwarz->n_novlp;
+    return galerkin_apply_impl(ctx, C->galerkin, x, d, true, share ? C->schwarz->d_ovlp : nullptr);
   }
   // multiplicative: dnext = d - A x; x += P1 dnext (:149-158)
   HIPCHECK(ctx, hipMemcpyAsync(C->dnext, d, sizeof(double) * (size_t)C->n, hipMemcpyDeviceToDevice, ctx->stream));
