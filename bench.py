@@ -157,16 +157,20 @@ def main():
         engine = os.environ.get("DDM_TRSV_MODE", "pipe")
         kname = {"levels": "k_trsv_lower_level + k_trsv_upper_level + k_trsv_small_levels (one launch per level, HIP graph)",
                  "xcd2": "k_trsv_xcd2"}.get(engine, "k_trsv_pipe (+ k_pipe_permute_in/out)")
-        traffic = None
-        try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command (profiles/), gfx950-corrected
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_h_pmc_traffic_grid216_pipe.json" if engine == "pipe" else "r01_b_pmc_traffic_grid216.json")))
-            if G == 216 and engine in pmc.get("engine_kernels", {}):
-                traffic = pmc["kernels"][pmc["engine_kernels"][engine]]["hbm_bytes_per_dispatch_corrected"] / world if P == 2 else None
+        traffic, traffic_source = None, None
+        try:   # HBM bytes per launch: NOT measured in this run -- read from the committed rocprofv3 --pmc passes of this command
+            #    (profiles/, separate FETCH_SIZE / WRITE_SIZE runs, gfx950-corrected: 2 x FETCH_SIZE + WRITE_SIZE); the file is named in the line
+            traffic_source = "profiles/r02_pmc_traffic_grid216_geneo.json"
+            if not os.path.exists(os.path.join(ROOT, traffic_source)):
+                traffic_source = "profiles/r01_h_pmc_traffic_grid216_pipe.json"
+            pmc = json.load(open(os.path.join(ROOT, traffic_source)))
+            if G == 216 and P == 2 and engine in pmc.get("engine_kernels", {}):
+                traffic = pmc["kernels"][pmc["engine_kernels"][engine]]["hbm_bytes_per_dispatch_corrected"] / world
         except Exception:
             traffic = None
         roofline = {"bound": "hbm", "kernel": f"ILU(0) triangular solve: {kname}",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
+                    "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
                     "launches_timed": int(local_cnt)}
     # whole-iteration algorithmic traffic: 12(z_o+z) + 16 k n + 56 n + 170 n_o
     k = 0 if tl.galerkin is None else max(tl.k_all)
@@ -194,8 +198,9 @@ def main():
             dev = np.abs(gpu_hist[:len(ho)] - ho) / ho
             kcheck = min(30, len(ho) - 1)
             cpu["parity_first_iterations"] = {"iterations_checked": int(kcheck), "max_rel_dev_residual_norm": float(dev[:kcheck + 1].max()),
-                                              "tolerance": "| ||r_k||(hip) - ||r_k||(oracle) | <= 1e-8 * ||r_k|| for k <= 30; beyond that CG amplifies the "
-                                                           "rounding-level differences of the parallel reductions (DESIGN.md section 6); identical iteration counts",
+                                              "tolerance": "checked here: | ||r_k||(hip) - ||r_k||(oracle) | <= 1e-8 * ||r_k|| for k <= 30 of the iterations the oracle ran; the oracle "
+                                                           "gets the device-built GenEO basis; NOT checked here: the iteration count to 1e-10 and the late iterations, where CG "
+                                                           "amplifies rounding-level differences (full-length comparison: tests/test_gpu_fullsize.py at 96^3; DESIGN.md section 6)",
                                               "ok": bool(np.all(dev[:kcheck + 1] <= 1e-8)),
                                               "rel_dev_at": {str(k): float(dev[k]) for k in (1, 10, 20, 30, 40, 50, 60) if k < len(ho)}}
             prof = ", ".join(f"k={k}: {dev[k]:.1e} (r_k/r_0 {ho[k] / ho[0]:.1e})" for k in (1, 5, 10, 20, 30, 40, 50, len(ho) - 1) if k < len(ho))

@@ -26,9 +26,9 @@ for k, (v, n) in acc["FETCH_SIZE"].items():
     kern[k] = {"FETCH_SIZE_KiB_per_dispatch": v / n, "dispatches": n, "WRITE_SIZE_KiB_per_dispatch": w[0] / max(w[1], 1),
                "hbm_bytes_per_dispatch_corrected": (2.0 * v / n + w[0] / max(w[1], 1)) * 1024.0}
 match = [k for k in kern if k.startswith(kprefix)]
-doc = {"note": "rocprofv3 --pmc passes (separate runs, --kernel-trace only) of `python3 bench.py --grid 216 --steps 10 --warmup 3 --cpu-iters 0 "
-               "--no-solve --coarse pou`; FETCH_SIZE/WRITE_SIZE are KiB as reported; gfx950: read bytes = 2 x FETCH_SIZE.",
-       "kernels": dict(sorted(kern.items(), key=lambda kv: -kv[1]["hbm_bytes_per_dispatch_corrected"])[:16]),
+doc = {"note": "rocprofv3 --pmc passes (separate runs, --kernel-trace only) of the bench command named in the calling script (tools/gpu_prof*.sh); "
+               "FETCH_SIZE/WRITE_SIZE are KiB as reported; gfx950: read bytes = 2 x FETCH_SIZE.",
+       "kernels": dict(sorted(kern.items(), key=lambda kv: -kv[1]["hbm_bytes_per_dispatch_corrected"])[:24]),
        "engine_kernels": {engine: match[0]} if match else {}}
 json.dump(doc, open(out, "w"), indent=1)
 print(out, doc["engine_kernels"], {k: round(kern[k]["hbm_bytes_per_dispatch_corrected"] / 1e9, 3) for k in list(doc["kernels"])[:6]})
