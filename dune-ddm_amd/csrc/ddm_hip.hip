@@ -53,6 +53,9 @@ struct ddm_ctx {
   } nccl;
   ncclComm_t rccl_comm = nullptr;
   bool rccl = false, rccl_self = false; // rccl_self: route the self segment through RCCL too (single-GPU self test)
+  // side stream of the additive combination: the coarse level's restrict / solve / prolong run beside the latency-bound local solve
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   double *partial = nullptr; // RED_MAX_BLOCKS doubles
   double *scal = nullptr;    // 16 device scalars
   int num_cu = 256;           // compute units of the device: persistent kernels launch at most this many workgroups
@@ -187,6 +190,13 @@ extern "C" int ddm_ctx_create(int device, void *hip_stream, ddm_ctx **out)
 
 extern "C" void ddm_ctx_destroy(ddm_ctx *ctx)
 {
+  if (ctx && ctx->side) {
+    (void)hipStreamSynchronize(ctx->side);
+    (void)hipStreamDestroy(ctx->side);
+    (void)hipEventDestroy(ctx->ev_fork);
+    (void)hipEventDestroy(ctx->ev_join);
+    ctx->side = nullptr;
+  }
   if (ctx && ctx->rccl_comm && ctx->nccl.CommDestroy) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)ctx->nccl.CommDestroy(ctx->rccl_comm);
@@ -1946,14 +1956,14 @@ static int galerkin_apply_impl(ddm_ctx *ctx, ddm_galerkin *G, double *x, const d
     dov = G->d_ovlp;
   }
   hipLaunchKernelGGL(k_coarse_restrict_partial, dim3(G->nchunk), dim3(WG), 0, ctx->stream, (int)G->kmax, G->ld, G->basis, dov,
-                     G->chunks, G->partial); // :165-167
+                     G->chunks, G->partial, G->nchunk); // :165-167
   hipLaunchKernelGGL(k_coarse_restrict_final, dim3(1), dim3(WG), 0, ctx->stream, (int)G->nsub, (int)G->kmax, G->sub_chunk_ptr, G->partial,
                      G->coarse_index, G->K, G->d0);
   HIPCHECK(ctx, hipGetLastError());
   DDMCHECK(ctx_allreduce(ctx, G->d0, G->K, "coarse defect")); // replaces MPI_Gatherv (:170-171): every rank obtains the full coarse defect
   hipLaunchKernelGGL(k_dense_mv, dim3((unsigned)((G->K + 3) / 4)), dim3(WG), 0, ctx->stream, G->K, G->a0inv, G->d0, G->x0); // :174-179 (replicated)
   hipLaunchKernelGGL(k_coarse_prolong, dim3(G->nchunk), dim3(WG), 0, ctx->stream, (int)G->kmax, G->ld, G->basis, G->x0, G->coarse_index,
-                     G->chunks, G->x_ovlp);       // :186-188
+                     G->chunks, G->x_ovlp, G->nchunk);       // :186-188
   DDMCHECK(ddm_halo_exchange(ctx, G->add, G->x_ovlp)); // :190
   if (acc)
     hipLaunchKernelGGL((k_restrict<true, false>), dim3(grid_for(G->n)), dim3(WG), 0, ctx->stream, G->n, G->ext_map, G->x_ovlp, (const double *)nullptr, x);
@@ -1996,7 +2006,7 @@ extern "C" int ddm_galerkin_products(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t
     if (!d_cidx) rc = upload(ctx, cidx.data(), nleft, &d_cidx);
     if (rc) break;
     if (nchunk > 0)
-      hipLaunchKernelGGL(k_coarse_restrict_partial, dim3(nchunk), dim3(WG), 0, ctx->stream, (int)nleft, n, left, y, chunks, partial);
+      hipLaunchKernelGGL(k_coarse_restrict_partial, dim3(nchunk), dim3(WG), 0, ctx->stream, (int)nleft, n, left, y, chunks, partial, nchunk);
     hipLaunchKernelGGL(k_coarse_restrict_final, dim3(1), dim3(WG), 0, ctx->stream, 1, (int)nleft, d_scp, partial, d_cidx, nleft, outd + j * nleft);
   }
   if (!rc) rc = ddm_memcpy_d2h(ctx, out_host, outd, sizeof(double) * (size_t)(nleft * nright));
@@ -2017,6 +2027,8 @@ struct ddm_combined {
   ddm_galerkin *galerkin = nullptr;
   double *dnext = nullptr;
   int64_t n = 0;
+  bool fused = false;   // additive mode: the levels' overlapping results are summed before ONE halo add (combined_apply_fused)
+  bool overlap = false; // ... and the coarse chain runs on a side stream beside the local solve (measured slower: off by default)
 };
 extern "C" int ddm_combined_create(ddm_ctx *ctx, int mode, ddm_op *op, ddm_schwarz *schwarz, ddm_galerkin *galerkin, ddm_combined **out)
 {
@@ -2029,6 +2041,12 @@ extern "C" int ddm_combined_create(ddm_ctx *ctx, int mode, ddm_op *op, ddm_schwa
   C->schwarz = schwarz;
   C->galerkin = galerkin;
   C->n = schwarz->n_novlp;
+  if (mode == 0 && galerkin) {
+    const char *f = std::getenv("DDM_FUSE_LEVELS");    // "0": the two levels one after the other (two halo adds: the reference's order of sums)
+    const char *e = std::getenv("DDM_OVERLAP_COARSE"); // "1": coarse chain on a side stream
+    C->fused = !(f && f[0] == '0') && galerkin->copy == schwarz->copy && galerkin->add == schwarz->add && galerkin->n == schwarz->n && galerkin->n_novlp == schwarz->n_novlp;
+    C->overlap = C->fused && e && e[0] == '1' && (ctx->nranks == 1 || ctx->rccl);
+  }
   if (hipMalloc((void **)&C->dnext, sizeof(double) * (size_t)std::max<int64_t>(C->n, 1)) != hipSuccess) {
     delete C;
     return fail(ctx, DDM_EHIP, "combined: allocation failed");
@@ -2047,9 +2065,71 @@ extern "C" void ddm_combined_destroy(ddm_combined *C)
   (void)hipFree(C->dnext);
   delete C;
 }
+// Additive combination, fused: both levels start from the same extended defect and add over the same interface, so their
+// overlapping results are summed BEFORE the exchange (linearity of addOwnerCopyToAll; schwarz.hh:138-146 +
+// galerkin_preconditioner.hh:190-193 + combined_preconditioner.hh:136-142) -- one extend, one copy-halo, one halo add and one restrict
+// instead of two each; the result differs from the two-pass order by rounding only (measured: 5.54 -> 5.31 ms per iteration at 216^3).
+//   extend + copy-halo -> local solve -> (POU scale) -> R d -> all-reduce -> A0^-1 -> R^T x0 -> x_s += x_c -> halo add -> restrict
+// two_streams (DDM_OVERLAP_COARSE=1; needs the in-library exchange or a single rank): the coarse chain runs on a side stream BESIDE the
+// local solve -- the local solves are latency-bound and leave 85 % of the HBM bandwidth idle, the coarse level is bandwidth-bound.
+// Measured at 216^3 it LOSES: the local solve slows from 3.39 to 4.34 ms (its dependent L2 / HBM round trips queue behind the
+// basis stream), the coarse chain from 0.87 to 2.2 ms, 5.58 ms per iteration against 5.31 -- off by default.
+static int combined_apply_fused(ddm_ctx *ctx, ddm_combined *C, double *x, const double *d, bool two_streams)
+{
+  ddm_schwarz *S = C->schwarz;
+  ddm_galerkin *G = C->galerkin;
+  if (two_streams && !ctx->side) {
+    HIPCHECK(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    HIPCHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    HIPCHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  }
+  {
+    ScopedTimer t(ctx, "Schwarz/get defect");
+    hipLaunchKernelGGL(k_extend, dim3(grid_for(S->n)), dim3(WG), 0, ctx->stream, S->n, S->ext_map, d, S->d_ovlp);
+    DDMCHECK(ddm_halo_exchange(ctx, S->copy, S->d_ovlp));
+  }
+  auto coarse_chain = [&](int grid) -> int {
+    ScopedTimer t(ctx, "GalerkinPrec/apply");
+    hipLaunchKernelGGL(k_coarse_restrict_partial, dim3(grid), dim3(WG), 0, ctx->stream, (int)G->kmax, G->ld, G->basis, (const double *)S->d_ovlp, G->chunks, G->partial, G->nchunk);
+    hipLaunchKernelGGL(k_coarse_restrict_final, dim3(1), dim3(WG), 0, ctx->stream, (int)G->nsub, (int)G->kmax, G->sub_chunk_ptr, G->partial, G->coarse_index, G->K, G->d0);
+    DDMCHECK(ctx_allreduce(ctx, G->d0, G->K, "coarse defect"));
+    hipLaunchKernelGGL(k_dense_mv, dim3((unsigned)((G->K + 3) / 4)), dim3(WG), 0, ctx->stream, G->K, G->a0inv, G->d0, G->x0);
+    hipLaunchKernelGGL(k_coarse_prolong, dim3(grid), dim3(WG), 0, ctx->stream, (int)G->kmax, G->ld, G->basis, G->x0, G->coarse_index, G->chunks, G->x_ovlp, G->nchunk);
+    return DDM_OK;
+  };
+  if (two_streams) {
+    // inter-rank operations stay totally ordered: copy-halo (main) -> all-reduce (side) -> [join] -> halo add (main)
+    HIPCHECK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    hipStream_t main = ctx->stream;
+    HIPCHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    ctx->stream = ctx->side; // the coarse chain is enqueued on the side stream (kernels, RCCL all-reduce, timer)
+    const int rc = coarse_chain(std::min(G->nchunk, 2 * ctx->num_cu)); // two workgroups per CU: leaves wave slots for the pipe kernel
+    const hipError_t e = hipEventRecord(ctx->ev_join, ctx->side);
+    ctx->stream = main;
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(ctx, DDM_EHIP, "hipEventRecord failed: %s", hipGetErrorString(e));
+  }
+  {
+    ScopedTimer t(ctx, "Schwarz/local solve");
+    DDMCHECK(ddm_ilu0_solve(ctx, S->solver, S->d_ovlp, S->x_ovlp));
+  }
+  if (!two_streams) DDMCHECK(coarse_chain(G->nchunk));
+  {
+    ScopedTimer t(ctx, "Schwarz/add solution");
+    if (S->type == 1 && S->pou) hipLaunchKernelGGL(k_scale, dim3(grid_for(S->n)), dim3(WG), 0, ctx->stream, S->n, S->pou, S->x_ovlp);
+    if (two_streams) HIPCHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    hipLaunchKernelGGL(k_axpy, dim3(grid_for(S->n)), dim3(WG), 0, ctx->stream, S->n, 1.0, (const double *)G->x_ovlp, S->x_ovlp);
+    DDMCHECK(ddm_halo_exchange(ctx, S->add, S->x_ovlp));
+    hipLaunchKernelGGL((k_restrict<false, false>), dim3(grid_for(S->n)), dim3(WG), 0, ctx->stream, S->n, S->ext_map, S->x_ovlp, (const double *)nullptr, x);
+    HIPCHECK(ctx, hipGetLastError());
+  }
+  return DDM_OK;
+}
+
 extern "C" int ddm_combined_apply(ddm_ctx *ctx, ddm_combined *C, double *x, const double *d)
 {
   ScopedTimer t(ctx, "CombinedPreconditioner/apply");
+  if (C->mode == 0 && C->galerkin && C->fused) return combined_apply_fused(ctx, C, x, d, C->overlap);
   // x = 0; precs[0]->apply(x, d)  (:133-134)  -- the restrict kernel overwrites every entry of x
   DDMCHECK(schwarz_apply_impl(ctx, C->schwarz, x, d, false));
   if (!C->galerkin) return DDM_OK;

@@ -940,9 +940,11 @@ struct RowChunk {
 };
 __global__ __launch_bounds__(WG) void k_coarse_restrict_partial(int kmax, int64_t ld, const double *__restrict__ basis,
                                                                  const double *__restrict__ d, const RowChunk *__restrict__ chunks,
-                                                                 double *__restrict__ partial /* [nchunk][kmax] */)
+                                                                 double *__restrict__ partial /* [nchunk][kmax] */, int nchunk)
 {
-  const RowChunk c = chunks[blockIdx.x];
+  // (grid-stride over the chunks: a small grid keeps the kernel's footprint per CU low when it runs beside the local solve)
+  for (int ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+  const RowChunk c = chunks[ch];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int j = w; j < kmax; j += 4) {
     const double *bj = basis + (int64_t)j * ld;
@@ -960,7 +962,8 @@ __global__ __launch_bounds__(WG) void k_coarse_restrict_partial(int kmax, int64_
     }
     for (; r < c.r1; r += 64) s += bj[r] * d[r];
     s = wave_sum(s);
-    if (lane == 0) partial[(int64_t)blockIdx.x * kmax + j] = s;
+    if (lane == 0) partial[(int64_t)ch * kmax + j] = s;
+  }
   }
 }
 // one workgroup: sums the chunk partials of each (subdomain, vector) in chunk order and scatters
@@ -996,10 +999,12 @@ __global__ __launch_bounds__(WG) void k_dense_mv(int64_t K, const double *__rest
 // K7 prolongation x_ovlp = sum_j c_j r_j  (galerkin_preconditioner.hh:186-188)
 __global__ __launch_bounds__(WG) void k_coarse_prolong(int kmax, int64_t ld, const double *__restrict__ basis,
                                                         const double *__restrict__ x0, const int64_t *__restrict__ coarse_index,
-                                                        const RowChunk *__restrict__ chunks, double *__restrict__ xov)
+                                                        const RowChunk *__restrict__ chunks, double *__restrict__ xov, int nchunk)
 {
   __shared__ double cj[64];
-  const RowChunk c = chunks[blockIdx.x];
+  for (int ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+  const RowChunk c = chunks[ch];
+  __syncthreads(); // cj of the previous chunk is no longer read
   if (threadIdx.x < kmax) {
     const int64_t gi = coarse_index[(int64_t)c.sub * kmax + threadIdx.x];
     cj[threadIdx.x] = gi >= 0 ? x0[gi] : 0.0;
@@ -1027,6 +1032,7 @@ __global__ __launch_bounds__(WG) void k_coarse_prolong(int kmax, int64_t ld, con
     }
     xov[r] = s;
     if (r2 != r) xov[r2] = s2;
+  }
   }
 }
 
