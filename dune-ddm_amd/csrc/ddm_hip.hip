@@ -9,6 +9,7 @@
 #include <rccl/rccl.h> // types and enums only: the library is opened with dlopen when ddm_ctx_set_rccl is called
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -502,7 +503,9 @@ struct TriSchedule { // one triangular factor, level by level in sliced ELL
 struct TriCsr { // one triangular factor of the sparse direct solver: rows in level order, CSR entries (kernels.hpp: CsrLevel)
   int64_t nlev = 0;
   std::vector<CsrLevel> desc;
-  int32_t *rows = nullptr;
+  int64_t nrows = 0, entries = 0; // transformed rows (real + virtual unknowns of the supernodes), stored entries
+  int32_t *rows = nullptr;        // destination unknown of a row
+  int32_t *rhs = nullptr;         // index of its right-hand side (lower: in d, upper: in x) or -1 (none)
   int64_t *lrp = nullptr;
   int32_t *cols = nullptr;
   double *vals = nullptr;
@@ -559,6 +562,7 @@ struct ddm_ilu0 {
   int pm_nrhs = 0;
   int direct = 0;
   double direct_flops = 0.0;
+  int64_t nvirt = 0; // virtual unknowns of the supernodal transformation: the permuted work vectors hold n + nvirt entries
   std::vector<double> h_lu; // factor values in the pattern of A
   TriSchedule L, U;
   TriCsr Lc, Uc;   // direct factors use these instead of L / U (global levels: multi-RHS solves, one launch per level)
@@ -669,77 +673,240 @@ static int build_schedule(ddm_ctx *ctx, const ddm_csr *A, const std::vector<doub
   return DDM_OK;
 }
 
-// block_ptr != nullptr: rows ordered by (block, level), levels numbered per block (blk_lev_ptr), for k_trsv_csr_blocks
-static int build_csr_schedule(ddm_ctx *ctx, const ddm_csr *A, const std::vector<double> &lu, const std::vector<int64_t> &diag, bool upper, TriCsr &S,
-                              int64_t nblocks = 0, const int64_t *block_ptr = nullptr)
+// Supernodes of a direct factor: maximal runs J = [j0, j1) of consecutive eliminated indices whose diagonal block L[J, J] is a
+// dense triangle (row i of J holds all columns j0 .. i-1; by the symmetric pattern of the factor U[J, J] is dense as well) -- the
+// separators of the nested dissection.  Solving through such a block row by row costs |J| dependency levels; with the diagonal
+// blocks INVERTED once on the host (dense triangular inverses, |J|^3 / 3 flops) it costs two:
+//   t_J = rhs_J - F[J, outside J] x      (|J| independent rows; results in virtual unknowns n + q)
+//   x_J = T_J^-1 t_J                     (|J| independent rows of the inverted block)
+// which is how sparse triangular solves are usually made parallel on GPUs.  The inverse has as many entries as the triangle it
+// replaces.  min_size: smaller runs stay row by row.
+struct Supernodes {
+  std::vector<int64_t> j0, j1;
+  std::vector<int32_t> sn_of;   // supernode of a row or -1
+  std::vector<int32_t> virt_of; // virtual unknown (>= n) of a supernode row
+  int64_t nvirt = 0;
+  std::vector<std::vector<double>> Linv, Uinv; // inverted diagonal blocks (dense s x s, row-major), filled by invert_supernodes
+};
+// T^-1 of the unit lower / M^-1 of the upper (pivots on the diagonal) diagonal block of every supernode; row-oriented substitution
+// (row i of the inverse is a combination of the finished rows: contiguous updates), supernodes in parallel on the host threads
+static void invert_supernodes(const std::vector<double> &lu, const std::vector<int64_t> &diag, Supernodes &SN)
+{
+  const size_t ns = SN.j0.size();
+  SN.Linv.assign(ns, {});
+  SN.Uinv.assign(ns, {});
+  std::vector<size_t> order(ns);
+  for (size_t q = 0; q < ns; ++q) order[q] = q;
+  std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return SN.j1[a] - SN.j0[a] > SN.j1[b] - SN.j0[b]; }); // largest first
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const int nth = (int)std::min<size_t>(hw, std::max<size_t>(ns, 1));
+  std::atomic<size_t> next{0};
+  std::vector<std::thread> th;
+  for (int t = 0; t < nth; ++t)
+    th.emplace_back([&]() {
+      for (;;) {
+        const size_t w = next.fetch_add(1);
+        if (w >= ns) break;
+        const size_t id = order[w];
+        const int64_t j0 = SN.j0[id], j1 = SN.j1[id], sz = j1 - j0;
+        std::vector<double> &Li = SN.Linv[id], &Ui = SN.Uinv[id];
+        Li.assign((size_t)(sz * sz), 0.0);
+        Ui.assign((size_t)(sz * sz), 0.0);
+        for (int64_t i = 0; i < sz; ++i) { // Linv[i, :] = e_i - sum_{k < i} L[i, k] Linv[k, :]
+          double *ri = Li.data() + i * sz;
+          ri[i] = 1.0;
+          const int64_t gi = j0 + i;
+          for (int64_t k = 0; k < i; ++k) {
+            const double l = lu[diag[gi] - (i - k)];
+            if (l == 0.0) continue;
+            const double *rk = Li.data() + k * sz;
+            for (int64_t c = 0; c <= k; ++c) ri[c] -= l * rk[c];
+          }
+        }
+        for (int64_t i = sz - 1; i >= 0; --i) { // Uinv[i, :] = dinv_i (e_i - sum_{k > i} U[i, k] Uinv[k, :])
+          double *ri = Ui.data() + i * sz;
+          ri[i] = 1.0;
+          const int64_t gi = j0 + i;
+          for (int64_t k = i + 1; k < sz; ++k) {
+            const double u = lu[diag[gi] + (k - i)];
+            if (u == 0.0) continue;
+            const double *rk = Ui.data() + k * sz;
+            for (int64_t c = k; c < sz; ++c) ri[c] -= u * rk[c];
+          }
+          const double dv = lu[diag[gi]]; // stored inverse pivot
+          for (int64_t c = i; c < sz; ++c) ri[c] *= dv;
+        }
+      }
+    });
+  for (auto &t : th) t.join();
+}
+static Supernodes detect_supernodes(const ddm_csr *A, const std::vector<int64_t> &diag, int min_size)
 {
   const int64_t n = A->nrows;
   const int64_t *rp = A->h_rp.data();
   const int32_t *ci = A->h_ci.data();
-  std::vector<int32_t> level(n, 0);
-  int32_t maxlev = -1;
-  if (!upper)
+  Supernodes SN;
+  SN.sn_of.assign((size_t)n, -1);
+  SN.virt_of.assign((size_t)n, -1);
+  int64_t j0 = 0;
+  while (j0 < n) {
+    int64_t j1 = j0 + 1;
+    while (j1 < n) {
+      const int64_t w = j1 - j0;
+      if (diag[j1] - rp[j1] < w || ci[diag[j1] - w] != j0) break;                 // row j1 holds columns j0 .. j1-1
+      if (rp[j0 + 1] - diag[j0] - 1 < w || ci[diag[j0] + w] != j1) break;         // row j0 holds column j1 (upper part)
+      ++j1;
+    }
+    bool ok = j1 - j0 >= min_size;
+    for (int64_t i = j0; ok && i < j1; ++i) // every row of the run holds i+1 .. j1-1 right behind its diagonal
+      ok = (rp[i + 1] - diag[i] - 1 >= j1 - 1 - i) && (i == j1 - 1 || ci[diag[i] + (j1 - 1 - i)] == j1 - 1);
+    if (ok) {
+      const int32_t id = (int32_t)SN.j0.size();
+      SN.j0.push_back(j0);
+      SN.j1.push_back(j1);
+      for (int64_t i = j0; i < j1; ++i) {
+        SN.sn_of[(size_t)i] = id;
+        SN.virt_of[(size_t)i] = (int32_t)(n + SN.nvirt++);
+      }
+    }
+    j0 = ok ? j1 : j0 + 1;
+  }
+  return SN;
+}
+
+// block_ptr != nullptr: rows ordered by (block, level), levels numbered per block (blk_lev_ptr), for k_trsv_csr_blocks
+static int build_csr_schedule(ddm_ctx *ctx, const ddm_csr *A, const std::vector<double> &lu, const std::vector<int64_t> &diag, bool upper, TriCsr &S,
+                              const Supernodes &SN, int64_t nblocks = 0, const int64_t *block_ptr = nullptr)
+{
+  const int64_t n = A->nrows;
+  const int64_t *rp = A->h_rp.data();
+  const int32_t *ci = A->h_ci.data();
+  const int64_t nunk = n + SN.nvirt;
+  // ---- transformed rows: dst <- (rhs >= 0 ? rhsvec[rhs] : 0) - sum val * x[col], times dinv ----
+  std::vector<int64_t> rptr(1, 0);
+  std::vector<int32_t> rcol, rdst, rrhs, rown; // rown: original row the transformed row belongs to (for the block id)
+  std::vector<double> rval, rdinv;
+  rdst.reserve((size_t)nunk);
+  std::vector<int32_t> level((size_t)nunk, 0);
+  auto finish_row = [&](int32_t dst, int32_t rhs, double dv, int32_t owner) {
+    int32_t l = 0;
+    for (int64_t k = rptr.back(); k < (int64_t)rcol.size(); ++k) l = std::max(l, level[(size_t)rcol[(size_t)k]] + 1);
+    level[(size_t)dst] = l;
+    rptr.push_back((int64_t)rcol.size());
+    rdst.push_back(dst);
+    rrhs.push_back(rhs);
+    rdinv.push_back(dv);
+    rown.push_back(owner);
+  };
+  auto do_supernode = [&](int32_t id) {
+    const int64_t j0 = SN.j0[(size_t)id], j1 = SN.j1[(size_t)id], s = j1 - j0;
+    const std::vector<double> &Ti = upper ? SN.Uinv[(size_t)id] : SN.Linv[(size_t)id];
+    if (!upper) {
+      for (int64_t i = j0; i < j1; ++i) { // phase 1: t_i = d_i - F[i, < j0] x
+        rcol.insert(rcol.end(), ci + rp[i], ci + (diag[i] - (i - j0)));
+        rval.insert(rval.end(), lu.begin() + rp[i], lu.begin() + (diag[i] - (i - j0)));
+        finish_row(SN.virt_of[(size_t)i], (int32_t)i, 1.0, (int32_t)i);
+      }
+      for (int64_t i = j0; i < j1; ++i) { // phase 2: x_i = sum_{c <= i} Tinv[i, c] t_c
+        for (int64_t c = j0; c <= i; ++c) {
+          rcol.push_back(SN.virt_of[(size_t)c]);
+          rval.push_back(-Ti[(size_t)((i - j0) * s + (c - j0))]);
+        }
+        finish_row((int32_t)i, -1, 1.0, (int32_t)i);
+      }
+    } else {
+      for (int64_t i = j1 - 1; i >= j0; --i) { // phase 1: t_i = y_i - F[i, >= j1] x   (y_i is read from x[i])
+        rcol.insert(rcol.end(), ci + (diag[i] + (j1 - i)), ci + rp[i + 1]);
+        rval.insert(rval.end(), lu.begin() + (diag[i] + (j1 - i)), lu.begin() + rp[i + 1]);
+        finish_row(SN.virt_of[(size_t)i], (int32_t)i, 1.0, (int32_t)i);
+      }
+      for (int64_t i = j1 - 1; i >= j0; --i) { // phase 2: x_i = sum_{c >= i} Minv[i, c] t_c
+        for (int64_t c = i; c < j1; ++c) {
+          rcol.push_back(SN.virt_of[(size_t)c]);
+          rval.push_back(-Ti[(size_t)((i - j0) * s + (c - j0))]);
+        }
+        finish_row((int32_t)i, -1, 1.0, (int32_t)i);
+      }
+    }
+  };
+  if (!upper) {
     for (int64_t i = 0; i < n; ++i) {
-      int32_t l = 0;
-      for (int64_t k = rp[i]; k < diag[i]; ++k) l = std::max(l, level[ci[k]] + 1);
-      level[i] = l;
-      maxlev = std::max(maxlev, l);
+      const int32_t id = SN.sn_of[(size_t)i];
+      if (id >= 0) {
+        if (i == SN.j0[(size_t)id]) do_supernode(id);
+        continue;
+      }
+      rcol.insert(rcol.end(), ci + rp[i], ci + diag[i]);
+      rval.insert(rval.end(), lu.begin() + rp[i], lu.begin() + diag[i]);
+      finish_row((int32_t)i, (int32_t)i, 1.0, (int32_t)i);
     }
-  else
+  } else {
     for (int64_t i = n - 1; i >= 0; --i) {
-      int32_t l = 0;
-      for (int64_t k = diag[i] + 1; k < rp[i + 1]; ++k) l = std::max(l, level[ci[k]] + 1);
-      level[i] = l;
-      maxlev = std::max(maxlev, l);
+      const int32_t id = SN.sn_of[(size_t)i];
+      if (id >= 0) {
+        if (i == SN.j1[(size_t)id] - 1) do_supernode(id);
+        continue;
+      }
+      rcol.insert(rcol.end(), ci + diag[i] + 1, ci + rp[i + 1]);
+      rval.insert(rval.end(), lu.begin() + diag[i] + 1, lu.begin() + rp[i + 1]);
+      finish_row((int32_t)i, (int32_t)i, lu[diag[i]], (int32_t)i);
     }
+  }
+  const int64_t nr = (int64_t)rdst.size();
+  // ---- levels (per block when block_ptr is given) ----
+  std::vector<int32_t> rlev((size_t)nr);
+  int32_t maxlev = -1;
+  for (int64_t q = 0; q < nr; ++q) {
+    rlev[(size_t)q] = level[(size_t)rdst[(size_t)q]];
+    maxlev = std::max(maxlev, rlev[(size_t)q]);
+  }
   int64_t nlev = (int64_t)maxlev + 1;
   std::vector<int32_t> blp;
-  if (block_ptr) { // renumber: level of block b -> (levels of the blocks before) + level
+  if (block_ptr) {
+    std::vector<int32_t> blk_of((size_t)n);
+    for (int64_t b = 0; b < nblocks; ++b)
+      for (int64_t i = block_ptr[b]; i < block_ptr[b + 1]; ++i) blk_of[(size_t)i] = (int32_t)b;
+    std::vector<int32_t> mx((size_t)nblocks, -1);
+    for (int64_t q = 0; q < nr; ++q) mx[(size_t)blk_of[(size_t)rown[(size_t)q]]] = std::max(mx[(size_t)blk_of[(size_t)rown[(size_t)q]]], rlev[(size_t)q]);
     blp.assign(1, 0);
-    for (int64_t b = 0; b < nblocks; ++b) {
-      int32_t mx = -1;
-      for (int64_t i = block_ptr[b]; i < block_ptr[b + 1]; ++i) mx = std::max(mx, level[i]);
-      for (int64_t i = block_ptr[b]; i < block_ptr[b + 1]; ++i) level[i] += blp.back();
-      blp.push_back(blp.back() + mx + 1);
-    }
+    for (int64_t b = 0; b < nblocks; ++b) blp.push_back(blp.back() + mx[(size_t)b] + 1);
+    for (int64_t q = 0; q < nr; ++q) rlev[(size_t)q] += blp[(size_t)blk_of[(size_t)rown[(size_t)q]]];
     nlev = blp.back();
     S.nblocks = (int)nblocks;
   }
   S.nlev = nlev;
-  std::vector<int64_t> lptr(nlev + 1, 0);
-  for (int64_t i = 0; i < n; ++i) lptr[level[i] + 1]++;
-  for (int64_t l = 0; l < nlev; ++l) lptr[l + 1] += lptr[l];
-  std::vector<int32_t> rows(n);
+  std::vector<int64_t> lptr((size_t)nlev + 1, 0);
+  for (int64_t q = 0; q < nr; ++q) lptr[(size_t)rlev[(size_t)q] + 1]++;
+  for (int64_t l = 0; l < nlev; ++l) lptr[(size_t)l + 1] += lptr[(size_t)l];
+  std::vector<int64_t> order((size_t)nr);
   {
     std::vector<int64_t> pos(lptr.begin(), lptr.end() - 1);
-    for (int64_t i = 0; i < n; ++i) rows[pos[level[i]]++] = (int32_t)i;
+    for (int64_t q = 0; q < nr; ++q) order[(size_t)pos[(size_t)rlev[(size_t)q]]++] = q; // stable inside a level
   }
-  std::vector<int64_t> lrp(n + 1, 0);
-  for (int64_t q = 0; q < n; ++q) {
-    const int64_t i = rows[q];
-    lrp[q + 1] = lrp[q] + (upper ? rp[i + 1] - diag[i] - 1 : diag[i] - rp[i]);
+  std::vector<int32_t> rows((size_t)nr), rhs((size_t)nr), cols((size_t)std::max<int64_t>((int64_t)rcol.size(), 1));
+  std::vector<int64_t> lrp((size_t)nr + 1, 0);
+  std::vector<double> vals((size_t)std::max<int64_t>((int64_t)rval.size(), 1)), dinv((size_t)nr);
+  for (int64_t t = 0; t < nr; ++t) {
+    const int64_t q = order[(size_t)t];
+    rows[(size_t)t] = rdst[(size_t)q];
+    rhs[(size_t)t] = rrhs[(size_t)q];
+    dinv[(size_t)t] = rdinv[(size_t)q];
+    const int64_t len = rptr[(size_t)q + 1] - rptr[(size_t)q];
+    lrp[(size_t)t + 1] = lrp[(size_t)t] + len;
+    std::copy(rcol.begin() + rptr[(size_t)q], rcol.begin() + rptr[(size_t)q + 1], cols.begin() + lrp[(size_t)t]);
+    std::copy(rval.begin() + rptr[(size_t)q], rval.begin() + rptr[(size_t)q + 1], vals.begin() + lrp[(size_t)t]);
   }
-  std::vector<int32_t> cols((size_t)std::max<int64_t>(lrp[n], 1));
-  std::vector<double> vals((size_t)std::max<int64_t>(lrp[n], 1)), dinv;
-  if (upper) dinv.resize(n);
-  for (int64_t q = 0; q < n; ++q) {
-    const int64_t i = rows[q];
-    const int64_t k0 = upper ? diag[i] + 1 : rp[i], k1 = upper ? rp[i + 1] : diag[i];
-    std::copy(ci + k0, ci + k1, cols.begin() + lrp[q]);
-    std::copy(lu.begin() + k0, lu.begin() + k1, vals.begin() + lrp[q]);
-    if (upper) dinv[q] = lu[diag[i]];
-  }
-  S.desc.resize(nlev);
+  S.desc.resize((size_t)nlev);
   for (int64_t l = 0; l < nlev; ++l) {
-    const int64_t m = lptr[l + 1] - lptr[l];
-    const int64_t ent = lrp[lptr[l + 1]] - lrp[lptr[l]];
-    int Sl = 1; // lanes per row: about a quarter of the average row length, and in a fused level no more than the workgroup holds
+    const int64_t m = lptr[(size_t)l + 1] - lptr[(size_t)l];
+    const int64_t ent = lrp[(size_t)lptr[(size_t)l + 1]] - lrp[(size_t)lptr[(size_t)l]];
+    int Sl = 1; // lanes per row: about a quarter of the average row length
     while (Sl < 64 && 4 * Sl * m < ent) Sl <<= 1;
-    S.desc[l] = CsrLevel{(int32_t)m, Sl, lptr[l]};
+    S.desc[(size_t)l] = CsrLevel{(int32_t)m, Sl, lptr[(size_t)l]};
   }
   int l = 0;
   while (l < nlev) { // runs of levels whose rows x lanes fit a few rounds of one workgroup are fused
-    auto small = [&](int q) { return (int64_t)S.desc[q].m * S.desc[q].S <= 4 * TRSV_SMALL_WG; };
+    auto small = [&](int q) { return (int64_t)S.desc[(size_t)q].m * S.desc[(size_t)q].S <= 4 * TRSV_SMALL_WG; };
     if (small(l)) {
       int c = 0;
       while (l + c < nlev && c < 4096 && small(l + c)) ++c;
@@ -750,11 +917,14 @@ static int build_csr_schedule(ddm_ctx *ctx, const ddm_csr *A, const std::vector<
       l += 1;
     }
   }
-  DDMCHECK(upload(ctx, rows.data(), n, &S.rows));
-  DDMCHECK(upload(ctx, lrp.data(), n + 1, &S.lrp));
-  DDMCHECK(upload(ctx, cols.data(), lrp[n], &S.cols));
-  DDMCHECK(upload(ctx, vals.data(), lrp[n], &S.vals));
-  if (upper) DDMCHECK(upload(ctx, dinv.data(), n, &S.dinv));
+  S.nrows = nr;
+  S.entries = (int64_t)rcol.size();
+  DDMCHECK(upload(ctx, rows.data(), nr, &S.rows));
+  DDMCHECK(upload(ctx, rhs.data(), nr, &S.rhs));
+  DDMCHECK(upload(ctx, lrp.data(), nr + 1, &S.lrp));
+  DDMCHECK(upload(ctx, cols.data(), (int64_t)rcol.size(), &S.cols));
+  DDMCHECK(upload(ctx, vals.data(), (int64_t)rval.size(), &S.vals));
+  if (upper) DDMCHECK(upload(ctx, dinv.data(), nr, &S.dinv));
   DDMCHECK(upload(ctx, S.desc.data(), nlev, &S.d_desc));
   if (block_ptr) DDMCHECK(upload(ctx, blp.data(), (int64_t)blp.size(), &S.blk_lev_ptr));
   return DDM_OK;
@@ -762,6 +932,7 @@ static int build_csr_schedule(ddm_ctx *ctx, const ddm_csr *A, const std::vector<
 static void free_csr_schedule(TriCsr &S)
 {
   (void)hipFree(S.blk_lev_ptr);
+  (void)hipFree(S.rhs);
   (void)hipFree(S.rows);
   (void)hipFree(S.lrp);
   (void)hipFree(S.cols);
@@ -773,26 +944,26 @@ static int enqueue_tri_csr(ddm_ctx *ctx, const TriCsr &S, bool upper, const doub
 {
   if (S.nblocks > 0) { // one workgroup per independent block
     if (upper)
-      hipLaunchKernelGGL(k_trsv_csr_blocks<true>, dim3(S.nblocks), dim3(TRSV_SMALL_WG), 0, ctx->stream, S.blk_lev_ptr, S.d_desc, S.rows, S.lrp, S.cols, S.vals, S.dinv, d, x);
+      hipLaunchKernelGGL(k_trsv_csr_blocks<true>, dim3(S.nblocks), dim3(TRSV_SMALL_WG), 0, ctx->stream, S.blk_lev_ptr, S.d_desc, S.rows, S.rhs, S.lrp, S.cols, S.vals, S.dinv, d, x);
     else
-      hipLaunchKernelGGL(k_trsv_csr_blocks<false>, dim3(S.nblocks), dim3(TRSV_SMALL_WG), 0, ctx->stream, S.blk_lev_ptr, S.d_desc, S.rows, S.lrp, S.cols, S.vals, S.dinv, d, x);
+      hipLaunchKernelGGL(k_trsv_csr_blocks<false>, dim3(S.nblocks), dim3(TRSV_SMALL_WG), 0, ctx->stream, S.blk_lev_ptr, S.d_desc, S.rows, S.rhs, S.lrp, S.cols, S.vals, S.dinv, d, x);
     HIPCHECK(ctx, hipGetLastError());
     return DDM_OK;
   }
   for (const auto &p : S.plan) {
     if (p.fused) {
       if (upper)
-        hipLaunchKernelGGL(k_trsv_csr_fused<true>, dim3(1), dim3(TRSV_SMALL_WG), 0, ctx->stream, p.count, S.d_desc + p.first, S.rows, S.lrp, S.cols, S.vals, S.dinv, d, x);
+        hipLaunchKernelGGL(k_trsv_csr_fused<true>, dim3(1), dim3(TRSV_SMALL_WG), 0, ctx->stream, p.count, S.d_desc + p.first, S.rows, S.rhs, S.lrp, S.cols, S.vals, S.dinv, d, x);
       else
-        hipLaunchKernelGGL(k_trsv_csr_fused<false>, dim3(1), dim3(TRSV_SMALL_WG), 0, ctx->stream, p.count, S.d_desc + p.first, S.rows, S.lrp, S.cols, S.vals, S.dinv, d, x);
+        hipLaunchKernelGGL(k_trsv_csr_fused<false>, dim3(1), dim3(TRSV_SMALL_WG), 0, ctx->stream, p.count, S.d_desc + p.first, S.rows, S.rhs, S.lrp, S.cols, S.vals, S.dinv, d, x);
     } else {
       const CsrLevel &L = S.desc[p.first];
       const int gpb = WG / L.S;
       const int grid = (int)std::min<int64_t>(((int64_t)L.m + gpb - 1) / gpb, 8192);
       if (upper)
-        hipLaunchKernelGGL(k_trsv_csr_level<true>, dim3(grid), dim3(WG), 0, ctx->stream, L, S.rows, S.lrp, S.cols, S.vals, S.dinv, d, x);
+        hipLaunchKernelGGL(k_trsv_csr_level<true>, dim3(grid), dim3(WG), 0, ctx->stream, L, S.rows, S.rhs, S.lrp, S.cols, S.vals, S.dinv, d, x);
       else
-        hipLaunchKernelGGL(k_trsv_csr_level<false>, dim3(grid), dim3(WG), 0, ctx->stream, L, S.rows, S.lrp, S.cols, S.vals, S.dinv, d, x);
+        hipLaunchKernelGGL(k_trsv_csr_level<false>, dim3(grid), dim3(WG), 0, ctx->stream, L, S.rows, S.rhs, S.lrp, S.cols, S.vals, S.dinv, d, x);
     }
   }
   HIPCHECK(ctx, hipGetLastError());
@@ -809,9 +980,9 @@ static void enqueue_multi_levels_csr(ddm_ctx *ctx, const TriCsr &S, bool upper, 
     const int rpb = WG / (Sm * nrhs);
     const unsigned grid = (unsigned)((L.m + rpb - 1) / rpb);
     if (upper)
-      hipLaunchKernelGGL(k_trsv_csr_level_multi<true>, dim3(grid), dim3(WG), 0, ctx->stream, L, Sm, nrhs, S.rows, S.lrp, S.cols, S.vals, S.dinv, D, ldd, X, ldx);
+      hipLaunchKernelGGL(k_trsv_csr_level_multi<true>, dim3(grid), dim3(WG), 0, ctx->stream, L, Sm, nrhs, S.rows, S.rhs, S.lrp, S.cols, S.vals, S.dinv, D, ldd, X, ldx);
     else
-      hipLaunchKernelGGL(k_trsv_csr_level_multi<false>, dim3(grid), dim3(WG), 0, ctx->stream, L, Sm, nrhs, S.rows, S.lrp, S.cols, S.vals, S.dinv, D, ldd, X, ldx);
+      hipLaunchKernelGGL(k_trsv_csr_level_multi<false>, dim3(grid), dim3(WG), 0, ctx->stream, L, Sm, nrhs, S.rows, S.rhs, S.lrp, S.cols, S.vals, S.dinv, D, ldd, X, ldx);
   }
 }
 static void free_schedule(TriSchedule &S)
@@ -830,12 +1001,22 @@ static int ilu0_build_engines(ddm_ctx *ctx, ddm_ilu0 *F, const ddm_csr *A, const
 {
   int rc = DDM_OK;
   if (F->direct) {
-    rc = build_csr_schedule(ctx, A, F->h_lu, diag, false, F->Lc);
-    if (!rc) rc = build_csr_schedule(ctx, A, F->h_lu, diag, true, F->Uc);
-    if (!rc && nblocks >= 4) { // enough independent blocks to fill CUs with one workgroup each
-      rc = build_csr_schedule(ctx, A, F->h_lu, diag, false, F->Lb, nblocks, block_ptr);
-      if (!rc) rc = build_csr_schedule(ctx, A, F->h_lu, diag, true, F->Ub, nblocks, block_ptr);
+    int min_sn = 8;
+    if (const char *e = std::getenv("DDM_DIRECT_SUPERNODE_MIN")) min_sn = std::max(2, std::atoi(e)); // a huge value switches the transformation off
+    Supernodes SN = detect_supernodes(A, diag, min_sn);
+    invert_supernodes(F->h_lu, diag, SN);
+    F->nvirt = SN.nvirt;
+    rc = build_csr_schedule(ctx, A, F->h_lu, diag, false, F->Lc, SN);
+    if (!rc) rc = build_csr_schedule(ctx, A, F->h_lu, diag, true, F->Uc, SN);
+    // Few, large levels (the supernodal transformation worked): one grid-wide launch per level.  Thousands of small levels and
+    // enough independent blocks: one workgroup per block walks its levels with workgroup barriers instead.
+    if (!rc && nblocks >= 4 && F->Lc.nlev + F->Uc.nlev > 600) {
+      rc = build_csr_schedule(ctx, A, F->h_lu, diag, false, F->Lb, SN, nblocks, block_ptr);
+      if (!rc) rc = build_csr_schedule(ctx, A, F->h_lu, diag, true, F->Ub, SN, nblocks, block_ptr);
     }
+    if (std::getenv("DDM_PIPE_VERBOSE"))
+      std::fprintf(stderr, "[ddm] direct factor: %lld rows, %lld stored entries; %zu supernodes (>= %d rows) with %lld rows; levels L/U %lld/%lld (transformed rows %lld)\n",
+                   (long long)F->n, (long long)F->nnz, SN.j0.size(), min_sn, (long long)SN.nvirt, (long long)F->Lc.nlev, (long long)F->Uc.nlev, (long long)F->Lc.nrows);
     F->L.nlev = F->Lc.nlev;
     F->U.nlev = F->Uc.nlev;
   } else {
@@ -1059,7 +1240,7 @@ extern "C" int ddm_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks
   int rc = ilu0_build_engines(ctx, F, P, R.diag, nblocks, block_ptr, /*multi_rhs_only (= level kernels)=*/true);
   if (!rc) rc = upload(ctx, R.perm.data(), A->nrows, &F->perm);
   if (!rc && (hipMalloc((void **)&F->pd, sizeof(double) * (size_t)std::max<int64_t>(F->n, 1)) != hipSuccess ||
-              hipMalloc((void **)&F->px, sizeof(double) * (size_t)std::max<int64_t>(F->n, 1)) != hipSuccess))
+              hipMalloc((void **)&F->px, sizeof(double) * (size_t)std::max<int64_t>(F->n + F->nvirt, 1)) != hipSuccess))
     rc = fail(ctx, DDM_EHIP, "ddm_chol_create: allocation failed");
   if (rc) {
     ddm_ilu0_destroy(F);
@@ -1519,7 +1700,7 @@ static int ilu0_solve_multi_ld(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double
     F->pD = F->pX = nullptr;
     F->pm_nrhs = 0;
     HIPCHECK(ctx, hipMalloc((void **)&F->pD, sizeof(double) * (size_t)F->n * (size_t)nrhs));
-    HIPCHECK(ctx, hipMalloc((void **)&F->pX, sizeof(double) * (size_t)F->n * (size_t)nrhs));
+    HIPCHECK(ctx, hipMalloc((void **)&F->pX, sizeof(double) * (size_t)(F->n + F->nvirt) * (size_t)nrhs));
     F->pm_nrhs = nrhs;
   }
   hipGraph_t g = nullptr;

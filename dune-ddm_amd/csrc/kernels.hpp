@@ -307,7 +307,7 @@ struct CsrLevel {
 };
 template <bool UPPER>
 __device__ __forceinline__ void trsv_csr_rows(const CsrLevel L, int first_group, int ngroups_step, int tid, const int32_t *__restrict__ rows,
-                                              const int64_t *__restrict__ lrp, const int32_t *__restrict__ cols, const double *__restrict__ vals,
+                                              const int32_t *__restrict__ rhs, const int64_t *__restrict__ lrp, const int32_t *__restrict__ cols, const double *__restrict__ vals,
                                               const double *__restrict__ dinv, const double *__restrict__ d, double *x)
 {
   const int S = L.S;
@@ -336,52 +336,52 @@ __device__ __forceinline__ void trsv_csr_rows(const CsrLevel L, int first_group,
       }
     }
     for (int o = S >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (act && sl == 0) {
-      const int row = rows[L.row_off + r];
-      const double t = (UPPER ? x[row] : d[row]) - s;
-      x[row] = UPPER ? t * dinv[L.row_off + r] : t;
+    if (act && sl == 0) { // rhs: index of the right-hand side (lower sweep: in d; upper sweep: in x, the forward result) or -1
+      const int ri = rhs[L.row_off + r];
+      const double t = (ri >= 0 ? (UPPER ? x[ri] : d[ri]) : 0.0) - s;
+      x[rows[L.row_off + r]] = UPPER ? t * dinv[L.row_off + r] : t;
     }
   }
 }
 // a run of consecutive small levels in ONE workgroup (levels separated by workgroup barriers)
 template <bool UPPER>
 __global__ __launch_bounds__(TRSV_SMALL_WG) void k_trsv_csr_fused(int nlev, const CsrLevel *__restrict__ desc, const int32_t *__restrict__ rows,
-                                                                   const int64_t *__restrict__ lrp, const int32_t *__restrict__ cols,
+                                                                   const int32_t *__restrict__ rhs, const int64_t *__restrict__ lrp, const int32_t *__restrict__ cols,
                                                                    const double *__restrict__ vals, const double *__restrict__ dinv,
                                                                    const double *__restrict__ d, double *x)
 {
   for (int l = 0; l < nlev; ++l) {
     const CsrLevel L = desc[l];
-    trsv_csr_rows<UPPER>(L, 0, TRSV_SMALL_WG / L.S, threadIdx.x, rows, lrp, cols, vals, dinv, d, x);
+    trsv_csr_rows<UPPER>(L, 0, TRSV_SMALL_WG / L.S, threadIdx.x, rows, rhs, lrp, cols, vals, dinv, d, x);
     __syncthreads();
   }
 }
 // one workgroup per independent diagonal block (subdomain): the whole triangular solve of the block, level after level
 template <bool UPPER>
 __global__ __launch_bounds__(TRSV_SMALL_WG) void k_trsv_csr_blocks(const int32_t *__restrict__ blk_lev_ptr, const CsrLevel *__restrict__ desc,
-                                                                    const int32_t *__restrict__ rows, const int64_t *__restrict__ lrp,
+                                                                    const int32_t *__restrict__ rows, const int32_t *__restrict__ rhs, const int64_t *__restrict__ lrp,
                                                                     const int32_t *__restrict__ cols, const double *__restrict__ vals,
                                                                     const double *__restrict__ dinv, const double *__restrict__ d, double *x)
 {
   const int l1 = blk_lev_ptr[blockIdx.x + 1];
   for (int l = blk_lev_ptr[blockIdx.x]; l < l1; ++l) {
     const CsrLevel L = desc[l];
-    trsv_csr_rows<UPPER>(L, 0, TRSV_SMALL_WG / L.S, threadIdx.x, rows, lrp, cols, vals, dinv, d, x);
+    trsv_csr_rows<UPPER>(L, 0, TRSV_SMALL_WG / L.S, threadIdx.x, rows, rhs, lrp, cols, vals, dinv, d, x);
     __syncthreads();
   }
 }
 // one large level over the whole grid
 template <bool UPPER>
-__global__ __launch_bounds__(WG) void k_trsv_csr_level(CsrLevel L, const int32_t *__restrict__ rows, const int64_t *__restrict__ lrp,
+__global__ __launch_bounds__(WG) void k_trsv_csr_level(CsrLevel L, const int32_t *__restrict__ rows, const int32_t *__restrict__ rhs, const int64_t *__restrict__ lrp,
                                                        const int32_t *__restrict__ cols, const double *__restrict__ vals,
                                                        const double *__restrict__ dinv, const double *__restrict__ d, double *x)
 {
   const int gpb = WG / L.S;
-  trsv_csr_rows<UPPER>(L, blockIdx.x * gpb, gridDim.x * gpb, threadIdx.x, rows, lrp, cols, vals, dinv, d, x);
+  trsv_csr_rows<UPPER>(L, blockIdx.x * gpb, gridDim.x * gpb, threadIdx.x, rows, rhs, lrp, cols, vals, dinv, d, x);
 }
 // multi-right-hand-side level (row-major n x nrhs blocks): S slices x nrhs columns of threads per row, slice sums meet in LDS
 template <bool UPPER>
-__global__ __launch_bounds__(WG) void k_trsv_csr_level_multi(CsrLevel L, int S, int nrhs, const int32_t *__restrict__ rows, const int64_t *__restrict__ lrp,
+__global__ __launch_bounds__(WG) void k_trsv_csr_level_multi(CsrLevel L, int S, int nrhs, const int32_t *__restrict__ rows, const int32_t *__restrict__ rhs, const int64_t *__restrict__ lrp,
                                                              const int32_t *__restrict__ cols, const double *__restrict__ vals,
                                                              const double *__restrict__ dinv, const double *__restrict__ d, int64_t ldd, double *x, int64_t ldx)
 {
@@ -413,10 +413,10 @@ __global__ __launch_bounds__(WG) void k_trsv_csr_level_multi(CsrLevel L, int S, 
   part[threadIdx.x] = s;
   __syncthreads();
   if (act && sl == 0) {
-    const int64_t o = (int64_t)rows[L.row_off + r] * ldx + j;
-    double t = UPPER ? x[o] : d[(int64_t)rows[L.row_off + r] * ldd + j];
+    const int ri = rhs[L.row_off + r];
+    double t = ri >= 0 ? (UPPER ? x[(int64_t)ri * ldx + j] : d[(int64_t)ri * ldd + j]) : 0.0;
     for (int q = 0; q < S; ++q) t -= part[g * per_row + q * nrhs + j];
-    x[o] = UPPER ? t * dinv[L.row_off + r] : t;
+    x[(int64_t)rows[L.row_off + r] * ldx + j] = UPPER ? t * dinv[L.row_off + r] : t;
   }
 }
 
