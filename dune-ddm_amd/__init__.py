@@ -129,6 +129,7 @@ SYMBOLS = {
     "ddm_combined_apply": (_I32, [_P, _P, _P, _P]),
     "ddm_cg_solve": (_I32, [_P, _P, _P, _P, _P, _D, _I32, _I32, _P, ctypes.POINTER(SolveResult)]),
     "ddm_gmres_solve": (_I32, [_P, _P, _P, _P, _P, _D, _I32, _I32, _P, ctypes.POINTER(SolveResult)]),
+    "ddm_bicgstab_solve": (_I32, [_P, _P, _P, _P, _P, _D, _I32, _P, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(SolveResult)]),
     "ddm_cg_begin": (_I32, [_P, _P, _P, _P, _P, _PP]),
     "ddm_cg_steps": (_I32, [_P, _P, _I32]),
     "ddm_cg_defect": (_I32, [_P, _P, ctypes.POINTER(ctypes.c_double)]),
@@ -535,6 +536,15 @@ def gmres_solve(ctx: Context, op: NonOverlappingOperator, prec: CombinedPrecondi
     ctx.check(ctx.lib.ddm_gmres_solve(ctx.h, op.h, prec.h, _ptr(x), _ptr(b), float(reduction), int(maxit), int(restart), _hp(hist),
                                       ctypes.byref(res)))
     return res, (hist[:res.iterations + 1] if history else None)
+
+
+def bicgstab_solve(ctx: Context, op: NonOverlappingOperator, prec: CombinedPreconditioner, x, b, reduction=1e-10, maxit=1000, history=True):
+    """dune-istl BiCGSTABSolver::apply ([solver] type = bicgstabsolver); history: one entry per HALF step"""
+    res = SolveResult()
+    hist = np.zeros(2 * maxit + 2, dtype=np.float64)
+    nh = ctypes.c_int32(0)
+    ctx.check(ctx.lib.ddm_bicgstab_solve(ctx.h, op.h, prec.h, _ptr(x), _ptr(b), float(reduction), int(maxit), _hp(hist), ctypes.byref(nh), ctypes.byref(res)))
+    return res, (hist[:nh.value] if history else None)
 
 
 class CgIteration:

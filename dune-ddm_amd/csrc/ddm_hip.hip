@@ -2616,6 +2616,106 @@ extern "C" int ddm_gmres_solve(ddm_ctx *ctx, ddm_op *op, ddm_combined *prec, dou
   return cleanup(rc);
 }
 
+// ---- BiCGSTAB ------------------------------------------------------------------------------------
+// dune-istl BiCGSTABSolver::apply ([solver] type = bicgstabsolver; DUNE 2.10 solvers.hh, not in the snapshot -- restated in
+// oracle/apply_oracle.py::bicgstab_solve): right-preconditioned, two half steps per iteration, the defect norm is tested after each
+// half step (hist_host receives both: up to 2 maxit + 1 entries); result.iterations = ceil of the half-step counter, as dune-istl reports.
+extern "C" int ddm_bicgstab_solve(ddm_ctx *ctx, ddm_op *op, ddm_combined *prec, double *x, double *b, double reduction, int maxit, double *hist_host,
+                                  int32_t *nhist, ddm_solve_result *res)
+{
+  if (!ctx || !op || !prec || !x || !b || !res) return fail(ctx, DDM_EINVAL, "ddm_bicgstab_solve: bad arguments");
+  const int64_t n = op->n;
+  const int G = grid_for(n);
+  const size_t bytes = sizeof(double) * (size_t)std::max<int64_t>(n, 1);
+  double *buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // rt, p, v, y, t
+  auto cleanup = [&](int rc) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (double *q : buf) (void)hipFree(q);
+    return rc;
+  };
+  for (auto &q : buf)
+    if (hipMalloc((void **)&q, bytes) != hipSuccess) return cleanup(fail(ctx, DDM_EHIP, "ddm_bicgstab_solve: allocation failed"));
+  double *rt = buf[0], *p = buf[1], *v = buf[2], *y = buf[3], *t = buf[4], *r = b;
+  const double EPS = 1e-80;
+  const bool verbose = std::getenv("DDM_KRYLOV_VERBOSE") != nullptr;
+  int rc = ddm_op_applyscaleadd(ctx, op, -1.0, x, r); // r = b - A x (b is overwritten by the defect, as in dune-istl)
+  if (rc) return cleanup(rc);
+  HIPCHECK(ctx, hipMemcpyAsync(rt, r, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  double norm = 0.0;
+  if ((rc = ddm_norm(ctx, op, r, &norm))) return cleanup(rc);
+  const double def0 = norm;
+  res->def0 = def0;
+  res->iterations = 0;
+  res->converged = 0;
+  res->reduction = 1.0;
+  res->elapsed_s = 0.0;
+  int nh = 0;
+  if (hist_host) hist_host[nh] = def0;
+  ++nh;
+  if (!(def0 == def0)) return cleanup(fail(ctx, DDM_ENUMERIC, "initial defect is NaN"));
+  if (def0 < 1e-30) {
+    res->converged = 1;
+    if (nhist) *nhist = nh;
+    return cleanup(DDM_OK);
+  }
+  HIPCHECK(ctx, hipMemsetAsync(p, 0, bytes, ctx->stream));
+  HIPCHECK(ctx, hipMemsetAsync(v, 0, bytes, ctx->stream));
+  double rho = 1.0, alpha = 1.0, omega = 1.0, rho_new = 0.0, h = 0.0;
+  const auto t0 = std::chrono::steady_clock::now();
+  double it = 0.5;
+  bool conv = false;
+  auto record = [&](double nrm) {
+    if (hist_host) hist_host[nh] = nrm;
+    ++nh;
+    res->reduction = nrm / def0;
+    return nrm <= def0 * reduction;
+  };
+  for (; it < maxit && !rc; it += 0.5) {
+    if ((rc = ddm_dot(ctx, op, rt, r, &rho_new))) break;
+    if (verbose) std::fprintf(stderr, "[ddm bicgstab] it %.1f rho_new %.17g rho %.17g alpha %.17g omega %.17g norm %.17g\n", it, rho_new, rho, alpha, omega, norm);
+    if (std::fabs(rho) <= EPS) { rc = fail(ctx, DDM_ENUMERIC, "breakdown in BiCGSTAB - rho %g <= EPSILON after %g iterations", rho, it); break; }
+    if (std::fabs(omega) <= EPS) { rc = fail(ctx, DDM_ENUMERIC, "breakdown in BiCGSTAB - omega %g <= EPSILON after %g iterations", omega, it); break; }
+    if (it < 1) {
+      HIPCHECK(ctx, hipMemcpyAsync(p, r, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+      const double beta = (rho_new / rho) * (alpha / omega);
+      hipLaunchKernelGGL(k_axpy, dim3(G), dim3(WG), 0, ctx->stream, n, -omega, (const double *)v, p); // p = r + beta (p - omega v)
+      hipLaunchKernelGGL(k_scal, dim3(G), dim3(WG), 0, ctx->stream, n, beta, p);
+      hipLaunchKernelGGL(k_axpy, dim3(G), dim3(WG), 0, ctx->stream, n, 1.0, (const double *)r, p);
+    }
+    if ((rc = ddm_combined_apply(ctx, prec, y, p))) break;  // y = W^-1 p
+    if ((rc = ddm_op_apply(ctx, op, y, v))) break;           // v = A y
+    if ((rc = ddm_dot(ctx, op, rt, v, &h))) break;
+    if (std::fabs(h) < EPS) { rc = fail(ctx, DDM_ENUMERIC, "abs(h) < EPSILON in BiCGSTAB - abort"); break; }
+    alpha = rho_new / h;
+    hipLaunchKernelGGL(k_axpy, dim3(G), dim3(WG), 0, ctx->stream, n, alpha, (const double *)y, x);
+    hipLaunchKernelGGL(k_axpy, dim3(G), dim3(WG), 0, ctx->stream, n, -alpha, (const double *)v, r);
+    if ((rc = ddm_norm(ctx, op, r, &norm))) break;
+    if (record(norm)) { conv = true; break; }
+    it += 0.5;
+    if ((rc = ddm_combined_apply(ctx, prec, y, r))) break;  // y = W^-1 r
+    if ((rc = ddm_op_apply(ctx, op, y, t))) break;           // t = A y
+    double tt = 0.0, tr = 0.0;
+    if ((rc = ddm_dot(ctx, op, t, t, &tt))) break;
+    if ((rc = ddm_dot(ctx, op, t, r, &tr))) break;
+    omega = tr / tt;
+    hipLaunchKernelGGL(k_axpy, dim3(G), dim3(WG), 0, ctx->stream, n, omega, (const double *)y, x);
+    hipLaunchKernelGGL(k_axpy, dim3(G), dim3(WG), 0, ctx->stream, n, -omega, (const double *)t, r);
+    rho = rho_new;
+    if ((rc = ddm_norm(ctx, op, r, &norm))) break;
+    if (record(norm)) { conv = true; break; }
+  }
+  if (rc) return cleanup(rc);
+  (void)hipStreamSynchronize(ctx->stream);
+  res->elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  res->iterations = (int32_t)std::ceil(std::min(it, (double)maxit));
+  res->converged = conv ? 1 : 0;
+  if (nhist) *nhist = nh;
+  int st = 0;
+  if (prec->schwarz && !ddm_ilu0_status(ctx, prec->schwarz->solver, &st) && st) return cleanup(fail(ctx, DDM_ENUMERIC, "local triangular solve timed out (code %d)", st));
+  return cleanup(DDM_OK);
+}
+
 #include "geneo.hpp"
 
 // ---- dense host helpers exposed for the CPU tests (host logic of the GenEO Rayleigh-Ritz step) -------------------------

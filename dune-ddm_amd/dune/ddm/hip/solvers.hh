@@ -168,14 +168,31 @@ protected:
   int restart_;
 };
 
-// getSolverFromFactory(op, solver_subtree, prec) for the two device solvers (examples/poisson.cc:311-316)
+// [solver] type = bicgstabsolver: dune-istl BiCGSTABSolver::apply
+template <class X>
+class HipBiCGSTABSolver : public HipKrylovSolverBase<X> {
+public:
+  HipBiCGSTABSolver(std::shared_ptr<LinearOperator<X, X>> op, std::shared_ptr<Preconditioner<X, X>> prec, double reduction, int maxit, int verbose = 0)
+      : HipKrylovSolverBase<X>(std::move(op), std::move(prec), reduction, maxit, verbose) {}
+  HipBiCGSTABSolver(std::shared_ptr<LinearOperator<X, X>> op, std::shared_ptr<Preconditioner<X, X>> prec, const ParameterTree& cfg)
+      : HipBiCGSTABSolver(std::move(op), std::move(prec), cfg.get("reduction", 1e-8), cfg.get("maxit", 1000), cfg.get("verbose", 0)) {}
+
+protected:
+  int solve(ddm_ctx* ctx, ddm_op* o, ddm_combined* p, double* x, double* b, double reduction, ddm_solve_result* r) override
+  {
+    return ddm_bicgstab_solve(ctx, o, p, x, b, reduction, this->maxit_, nullptr, nullptr, r);
+  }
+};
+
+// getSolverFromFactory(op, solver_subtree, prec) for the device solvers (examples/poisson.cc:311-316)
 template <class X>
 std::shared_ptr<InverseOperator<X, X>> getHipSolver(std::shared_ptr<LinearOperator<X, X>> op, const ParameterTree& cfg, std::shared_ptr<Preconditioner<X, X>> prec)
 {
   const auto type = cfg.get("type", std::string("cgsolver"));
   if (type == "cgsolver") return std::make_shared<HipCGSolver<X>>(std::move(op), std::move(prec), cfg);
   if (type == "restartedgmressolver") return std::make_shared<HipRestartedGMResSolver<X>>(std::move(op), std::move(prec), cfg);
-  DUNE_THROW(NotImplemented, "solver type '" + type + "' has no device implementation (cgsolver, restartedgmressolver)");
+  if (type == "bicgstabsolver") return std::make_shared<HipBiCGSTABSolver<X>>(std::move(op), std::move(prec), cfg);
+  DUNE_THROW(NotImplemented, "solver type '" + type + "' has no device implementation (cgsolver, restartedgmressolver, bicgstabsolver)");
 }
 
 }  // namespace Dune

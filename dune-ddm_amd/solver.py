@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import (CombinedPreconditioner, Context, torch_context, gmres_solve, CsrMatrix, GalerkinPreconditioner, Halo, NonOverlappingOperator,
+from . import (CombinedPreconditioner, Context, torch_context, gmres_solve, bicgstab_solve, CsrMatrix, GalerkinPreconditioner, Halo, NonOverlappingOperator,
                SchwarzPreconditioner, cg_solve, galerkin_products)
 from .problem import Decomposition, RankLocal
 
@@ -267,7 +267,61 @@ class TwoLevelSchwarz:
         if solver == "restartedgmressolver":
             res, hist = gmres_solve(self.ctx, self.op, self.prec, x, bd, reduction, maxit, restart, history)
             return res, hist, x
+        if solver == "bicgstabsolver":
+            res, hist = bicgstab_solve(self.ctx, self.op, self.prec, x, bd, reduction, maxit, history)
+            return res, hist, x
         if solver != "cgsolver":
-            raise NotImplementedError("solver type '" + str(solver) + "' (cgsolver and restartedgmressolver are available on the device)")
+            raise NotImplementedError("solver type '" + str(solver) + "' (cgsolver, restartedgmressolver and bicgstabsolver are available on the device)")
         res, hist = cg_solve(self.ctx, self.op, self.prec, x, bd, reduction, maxit, fixed_iterations, history)
         return res, hist, x
+
+
+class TwoLevelSchwarzSolver:
+    """Host mirror of the PDELab linear-solver backend ``TwoLevelSchwarzSolver`` (dune/ddm/twolevel_schwarz.hh:27-174), the class
+    examples/convectiondiffusiondg.cc:75-78 and nonlinearpoisson.cc:151-154 hand to StationaryLinearProblemSolver / Newton:
+
+      ctor   : non-overlapping communication + the four template vectors 1, x, y, xy with constrained DoFs zeroed (:58-81)
+      apply  : (first call) overlap extension by ``overlap`` layers, overlapping matrix, PartitionOfUnity from the ``pou`` sub-tree,
+               template vectors extended by copyOwnerToAll (:93-128); (every call) POUCoarseSpace(template vectors, pou) ->
+               SchwarzPreconditioner (sub-tree "fine") + GalerkinPreconditioner ("coarse") in a CombinedPreconditioner whose mode
+               key sits in the sub-tree itself (:131-142), solver from the "solver" sub-tree or restarted GMRES(30), maxit 1000
+               (:146-160), right-hand side made consistent (:163-164), solve (:167-168).
+
+    ``problem`` is one of the synth problems (it plays the role of the grid function space + assembled matrix); ``ptree`` the
+    ``twolevelschwarz`` sub-tree as a nested dict (the keys of examples/convectiondiffusiondg.ini)."""
+
+    def __init__(self, problem, ptree=None, coords=None, device=0):
+        from .problem import build_structured
+        self.ptree = dict(ptree or {})
+        self.problem = problem
+        overlap = int(self.ptree.get("overlap", 1))                                                    # :95
+        pou = dict(self.ptree.get("pou", {}))
+        self.dec = build_structured(problem, overlap=overlap, pou_type=pou.get("type", "distance"), shrink=int(pou.get("shrink", 0)))
+        fine = dict(self.ptree.get("fine", {}))
+        solver_type = dict(fine.get("subdomain_solver", {})).get("type")
+        if solver_type is None:
+            raise ValueError("You must specify the solver in the subtree fine.subdomain_solver using the key 'type'")   # schwarz.hh:89-91
+        self.tl = TwoLevelSchwarz(self.dec, device=device, coarse="none", schwarz_type=fine.get("type", "restricted"),
+                                  mode=self.ptree.get("mode", "additive"), subdomain_solver=solver_type)
+        # template vectors 1, x, y, xy on the overlapping index sets (interpolation at the DoF positions, constrained DoFs zeroed)
+        coords = coords if coords is not None else problem.dof_coords
+        basis = {}
+        for sd in self.tl.rl.subs:
+            X = coords(sd.glob)
+            T = np.stack([np.ones(sd.n), X[:, 0], X[:, 1], X[:, 0] * X[:, 1]])
+            T[:, sd.dirichlet_ovlp > 0] = 0.0                                                          # set_constrained_dofs(cc, 0., v) (:75)
+            V = T * sd.pou[None, :]                                                                    # POUCoarseSpace (coarse_spaces.hh:1226-1230)
+            basis[sd.id] = V / np.linalg.norm(V, axis=1)[:, None]
+        self.template_basis = basis
+        self.tl.set_coarse_basis(basis)
+        self.tl.rebuild_combined(self.ptree.get("mode", "additive"))
+        self.result = None
+
+    def apply(self, reduction, b=None):
+        """solve A z = r to the given reduction (twolevel_schwarz.hh:84-169); returns (SolveResult, history, z)"""
+        sol = dict(self.ptree.get("solver", {"type": "restartedgmressolver", "restart": 30, "maxit": 1000}))   # :146-153
+        res, hist, z = self.tl.solve(reduction=reduction, maxit=int(sol.get("maxit", 1000)), solver=sol.get("type", "restartedgmressolver"),
+                                     restart=int(sol.get("restart", 30)), b=b)
+        self.tl.prec.check_status()
+        self.result = res                                                                              # LinearResultStorage (:170-174)
+        return res, hist, z

@@ -719,6 +719,14 @@ class StructuredDG2D:
     def subdomains(self):
         return [self.subdomain(r) for r in range(self.nranks)]
 
+    def dof_coords(self, glob):
+        """(len, 2) coordinates of the Lagrange nodes of the DoFs (cell corners): what Dune::PDELab::interpolate evaluates the
+        template functions 1, x, y, xy at (dune/ddm/twolevel_schwarz.hh:68-75)"""
+        glob = np.asarray(glob, dtype=np.int64)
+        cells = self.cell_of_gid[glob]
+        a = (glob - self.cell_gid0[cells]).astype(np.int64)
+        return np.stack([((cells % self.nx) + (a & 1)) * self.h, ((cells // self.nx) + (a >> 1)) * self.h], axis=1)
+
     # ---- overlapping matrices ------------------------------------------------------------------------
     def dirichlet_of(self, glob):
         return np.zeros(len(glob), dtype=np.uint8)                      # NoConstraints: Dirichlet data enter weakly

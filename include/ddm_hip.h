@@ -296,6 +296,12 @@ int ddm_cg_solve(ddm_ctx *ctx, ddm_op *op, ddm_combined *prec, double *x, double
 int ddm_gmres_solve(ddm_ctx *ctx, ddm_op *op, ddm_combined *prec, double *x, double *b, double reduction, int maxit,
                     int restart, double *hist_host, ddm_solve_result *res);
 
+/* dune-istl BiCGSTABSolver::apply ([solver] type = bicgstabsolver): right-preconditioned, two half steps per iteration, the defect norm
+ * is tested after each half step.  hist_host (may be NULL): up to 2 maxit + 1 doubles (one per half step), *nhist receives the count;
+ * res->iterations = ceil of the half-step counter (what dune-istl reports).  DDM_ENUMERIC on the breakdowns dune-istl aborts on. */
+int ddm_bicgstab_solve(ddm_ctx *ctx, ddm_op *op, ddm_combined *prec, double *x, double *b, double reduction, int maxit, double *hist_host,
+                       int32_t *nhist, ddm_solve_result *res);
+
 /* The same loop in pieces, so that a caller can bracket an exact number of iterations
  * (bench.py): begin = "b -= A x; def0 = ||b||" (synchronous); steps = k iterations enqueued
  * without host synchronisation; defect = ||b|| of the last enqueued iteration (synchronous). */

@@ -542,3 +542,75 @@ def gmres_solve(op, sp_, prec, x, b, reduction=1e-10, maxit=1000, restart=100):
             prec.apply(V[0], b)
             norm = sp_.norm(V[0])
     return j, conv, hist
+
+
+def bicgstab_solve(op, sp_, prec, x, b, reduction=1e-10, maxit=1000):
+    """dune-istl BiCGSTABSolver::apply (DUNE 2.10 solvers.hh, not in the snapshot; selectable through the same solver factory as
+    examples/poisson.ini:12-17): right preconditioning, two half steps per iteration, the defect norm is tested after each half
+    step.  Returns (iterations = ceil of the half-step counter, converged, [norm after every half step, starting with norm_0])."""
+    P = len(x)
+    EPS = 1e-80
+
+    def zeros():
+        return [np.zeros(len(v)) for v in x]
+
+    def axpy(a, u, w):
+        for r in range(P):
+            lib().orc_axpy(len(w[r]), float(a), _p(u[r]), _p(w[r]))
+
+    r = b
+    op.applyscaleadd(-1.0, x, r)
+    rt = [v.copy() for v in r]
+    norm = sp_.norm(r)
+    def0 = norm
+    hist = [def0]
+    if def0 < 1e-30:
+        return 0, True, hist
+    p, v, y, t = zeros(), zeros(), zeros(), zeros()
+    rho = alpha = omega = 1.0
+    it = 0.5
+    conv = False
+    while it < maxit:
+        rho_new = sp_.dot(rt, r)
+        if abs(rho) <= EPS or abs(omega) <= EPS:
+            raise ArithmeticError("breakdown in BiCGSTAB")
+        if it < 1:
+            for q in range(P):
+                p[q][:] = r[q]
+        else:
+            beta = (rho_new / rho) * (alpha / omega)
+            axpy(-omega, v, p)
+            for q in range(P):
+                p[q] *= beta
+            axpy(1.0, r, p)
+        for q in range(P):
+            y[q][:] = 0.0
+        prec.apply(y, p)
+        op.apply(y, v)
+        h = sp_.dot(rt, v)
+        if abs(h) < EPS:
+            raise ArithmeticError("abs(h) < EPSILON in BiCGSTAB - abort")
+        alpha = rho_new / h
+        axpy(alpha, y, x)
+        axpy(-alpha, v, r)
+        norm = sp_.norm(r)
+        hist.append(norm)
+        if norm <= def0 * reduction:
+            conv = True
+            break
+        it += 0.5
+        for q in range(P):
+            y[q][:] = 0.0
+        prec.apply(y, r)
+        op.apply(y, t)
+        omega = sp_.dot(t, r) / sp_.dot(t, t)
+        axpy(omega, y, x)
+        axpy(-omega, t, r)
+        rho = rho_new
+        norm = sp_.norm(r)
+        hist.append(norm)
+        if norm <= def0 * reduction:
+            conv = True
+            break
+        it += 0.5
+    return int(np.ceil(min(it, maxit))), conv, hist

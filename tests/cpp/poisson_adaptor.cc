@@ -113,7 +113,7 @@ int main(int argc, char** argv)
       std::printf("plugin cholesky_residual %.3e converged %d\n", rmax / bmax, (int)r2.converged);
       int caught = 0;
       try { Dune::HipSubdomainSolver<Mat> bad(*A, "bogus"); } catch (Dune::NotImplemented&) { ++caught; }
-      try { solver_subtree["type"] = "bicgstabsolver"; Dune::getHipSolver<Vec>(op, solver_subtree, prec); } catch (Dune::NotImplemented&) { ++caught; }
+      try { solver_subtree["type"] = "minressolver"; Dune::getHipSolver<Vec>(op, solver_subtree, prec); } catch (Dune::NotImplemented&) { ++caught; }
       std::printf("errors_caught %d\n", caught);
       return 0;
     }

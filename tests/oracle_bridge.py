@@ -40,7 +40,9 @@ def oracle_solve(dec, reduction=1e-10, maxit=1000, solver="cgsolver", restart=10
     op, sp_, prec, sch, gal = oracle_objects(dec, **kw)
     x = [np.zeros(sd.n_o) for sd in dec.subs]
     b = [sd.b.copy() for sd in dec.subs]
-    if solver == "restartedgmressolver":
+    if solver == "bicgstabsolver":
+        it, conv, hist = ao.bicgstab_solve(op, sp_, prec, x, b, reduction, maxit)
+    elif solver == "restartedgmressolver":
         it, conv, hist = ao.gmres_solve(op, sp_, prec, x, b, reduction, maxit, restart)
     else:
         it, conv, hist = ao.cg_solve(op, sp_, prec, x, b, reduction, maxit)
