@@ -39,7 +39,7 @@ class GeneoParams(ctypes.Structure):
     """ddm_geneo_params: the keys of `<prefix>.eigensolver` (dune/ddm/eigensolvers/eigensolver_params.hh:8-62)"""
     _fields_ = [("nev", ctypes.c_int32), ("nev_max", ctypes.c_int32), ("tolerance", ctypes.c_double), ("shift", ctypes.c_double),
                 ("threshold", ctypes.c_double), ("maxit", ctypes.c_int32), ("extra", ctypes.c_int32), ("seed", ctypes.c_int32),
-                ("preconditioner", ctypes.c_int32), ("max_direct_flops", ctypes.c_double), ("verbose", ctypes.c_int32)]
+                ("preconditioner", ctypes.c_int32), ("max_direct_flops", ctypes.c_double), ("verbose", ctypes.c_int32), ("raw", ctypes.c_int32)]
 
 
 class GeneoInfo(ctypes.Structure):
@@ -120,6 +120,10 @@ SYMBOLS = {
     "ddm_galerkin_products": (_I32, [_P, _P, _I64, _P, _I64, _P, _I64, _I64, _P]),
     "ddm_geneo_params_default": (_I32, [ctypes.POINTER(GeneoParams)]),
     "ddm_geneo_basis": (_I32, [_P, _P, _P, _I64, _P, _P, _P, ctypes.POINTER(GeneoParams), _I64, _P, _P, _P, ctypes.POINTER(GeneoInfo)]),
+    "ddm_msgfem_basis": (_I32, [_P, _P, _P, _I64, _P, _P, _P, _P, ctypes.POINTER(GeneoParams), _I64, _P, _P, _P, ctypes.POINTER(GeneoInfo)]),
+    "ddm_harmonic_create": (_I32, [_P, _P, _I64, _P, _I64, _P, _I64, _P, _PP]),
+    "ddm_harmonic_destroy": (None, [_P]),
+    "ddm_harmonic_extend": (_I32, [_P, _P, _I32, _P, _I64]),
     "ddm_blockvec_gram": (_I32, [_P, _I64, _P, _P, _I64, _I32, _P, _I64, _I32, _P]),
     "ddm_blockvec_rotate": (_I32, [_P, _I64, _P, _P, _I64, _I32, _P, _I32, _P, _I64, _P, _I64]),
     "ddm_dense_sym_eig_host": (_I32, [_I32, _P, _P]),
@@ -570,6 +574,31 @@ class CgIteration:
         if self.h:
             self.ctx.lib.ddm_cg_end(self.ctx.h, self.h)
             self.h = None
+
+
+class HarmonicExtension:
+    """ddm_harmonic: EnergyMinimalExtension (dune/ddm/coarsespaces/energy_minimal_extension.hh:36-229) on the device."""
+
+    def __init__(self, ctx: Context, A: "CsrMatrix", interior, boundary, block_ptr=None):
+        self.ctx = ctx
+        ii, bb = _np(interior, np.int64), _np(boundary, np.int64)
+        bp = _np(block_ptr if block_ptr is not None else [0, A.shape[0]], np.int64)
+        h = ctypes.c_void_p()
+        ctx.check(ctx.lib.ddm_harmonic_create(ctx.h, A.h, len(bp) - 1, _hp(bp), len(ii), _hp(ii), len(bb), _hp(bb), ctypes.byref(h)))
+        self.h = h
+
+    def extend(self, X):
+        """in place on a row-major device tensor (n, nrhs) holding the boundary values: interior rows are overwritten"""
+        assert X.dim() == 2 and X.stride(1) == 1
+        self.ctx.check(self.ctx.lib.ddm_harmonic_extend(self.ctx.h, self.h, X.shape[1], _ptr(X), X.stride(0)))
+        return X
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.ddm_harmonic_destroy(self.h)
+            self.h = None
+
+    __del__ = close
 
 
 def blockvec_gram(ctx: Context, sub_ptr, U, V):

@@ -577,6 +577,7 @@ struct ddm_ilu0 {
   hipGraphExec_t graph = nullptr;
   const double *g_d = nullptr;
   double *g_x = nullptr;
+  const double *g_scale = nullptr, *g_add = nullptr; // epilogue operands the captured graph was built with
 };
 
 static constexpr int SMALL_LEVEL_ROWS = 2048;
@@ -1496,7 +1497,8 @@ static int build_pipe_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
   return DDM_OK;
 }
 
-static void enqueue_pipe(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, unsigned long long *stamps)
+static void enqueue_pipe(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, unsigned long long *stamps, const double *scale = nullptr,
+                         const double *add = nullptr)
 {
   PipeParams P;
   P.ngroups = F->ngroups;
@@ -1517,7 +1519,7 @@ static void enqueue_pipe(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, 
   hipLaunchKernelGGL(k_pipe_permute_in, dim3(grid_for(F->p_nposL)), dim3(WG), 0, ctx->stream, F->p_nposL, F->p_rowL, d, F->p_dperm);
   if (stamps) hipLaunchKernelGGL((k_trsv_pipe<true>), dim3(F->p_grid), dim3(64 * (PIPE_NC + PIPE_NL)), PIPE_LDS_BYTES, ctx->stream, P);
   else hipLaunchKernelGGL((k_trsv_pipe<false>), dim3(F->p_grid), dim3(64 * (PIPE_NC + PIPE_NL)), PIPE_LDS_BYTES, ctx->stream, P);
-  hipLaunchKernelGGL(k_pipe_permute_out, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, F->p_posU, F->p_xpos, x);
+  hipLaunchKernelGGL(k_pipe_permute_out, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, F->p_posU, F->p_xpos, x, scale, add);
 }
 
 static int enqueue_tri(ddm_ctx *ctx, const TriSchedule &S, bool upper, const double *d, double *x)
@@ -1593,11 +1595,13 @@ extern "C" int ddm_ilu0_pipe_trace(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, d
   return rc;
 }
 
-extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x)
+// x = (LU)^-1 d, then optionally x *= scale and x += add (the tail of the Schwarz level: partition of unity of the restricted
+// variant and the coarse correction); the pipe engine folds both into its output permutation, the others append the two kernels.
+static int ilu0_solve_epilogue(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, const double *scale, const double *add)
 {
   if (F && F->n == 0) return DDM_OK;
   if (!F || !d || !x || d == x) return fail(ctx, DDM_EINVAL, "ddm_ilu0_solve: bad arguments (d and x must not alias)");
-  if (F->graph && F->g_d == d && F->g_x == x) {
+  if (F->graph && F->g_d == d && F->g_x == x && F->g_scale == scale && F->g_add == add) {
     HIPCHECK(ctx, hipGraphLaunch(F->graph, ctx->stream));
     return DDM_OK;
   }
@@ -1619,8 +1623,10 @@ extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double
     d = F->pd;
     x = F->px;
   }
+  bool epilogue_done = false;
   if (F->mode == 8) {
-    enqueue_pipe(ctx, F, d, x, nullptr);
+    epilogue_done = !F->perm;
+    enqueue_pipe(ctx, F, d, x, nullptr, epilogue_done ? scale : nullptr, epilogue_done ? add : nullptr);
   } else if (F->mode == 4) {
     hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
     hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, F->xlpos, F->xrows, d, F->xdperm);
@@ -1636,6 +1642,10 @@ extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double
   if (F->perm) hipLaunchKernelGGL(k_perm_scatter, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, 1, F->perm, (const double *)F->px, x_user, (int64_t)1);
   d = d_user;
   x = x_user;
+  if (!epilogue_done) {
+    if (scale) hipLaunchKernelGGL(k_scale, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, scale, x);
+    if (add) hipLaunchKernelGGL(k_axpy, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, 1.0, add, x);
+  }
   hipError_t e = hipStreamEndCapture(ctx->stream, &g);
   if (rc) return rc;
   if (e != hipSuccess) return fail(ctx, DDM_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
@@ -1647,9 +1657,13 @@ extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double
   }
   F->g_d = d;
   F->g_x = x;
+  F->g_scale = scale;
+  F->g_add = add;
   HIPCHECK(ctx, hipGraphLaunch(F->graph, ctx->stream));
   return DDM_OK;
 }
+
+extern "C" int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x) { return ilu0_solve_epilogue(ctx, F, d, x, nullptr, nullptr); }
 
 // Multi-RHS solve X = (LU)^-1 D for row-major n x nrhs block vectors with leading dimensions ldd / ldx (GenEO setup path).
 // One launch per level (wide levels of direct factors: one workgroup per row); the launches of one (D, X, nrhs) combination are
@@ -2290,16 +2304,20 @@ static int combined_apply_fused(ddm_ctx *ctx, ddm_combined *C, double *x, const 
     if (rc) return rc;
     if (e != hipSuccess) return fail(ctx, DDM_EHIP, "hipEventRecord failed: %s", hipGetErrorString(e));
   }
-  {
-    ScopedTimer t(ctx, "Schwarz/local solve");
-    DDMCHECK(ddm_ilu0_solve(ctx, S->solver, S->d_ovlp, S->x_ovlp));
-  }
+  const double *pou = S->type == 1 ? S->pou : nullptr;
+  // one stream: the coarse chain runs first, so that the local solve's last kernel can also apply "x *= pou; x += x_coarse"
   if (!two_streams) DDMCHECK(coarse_chain(G->nchunk));
   {
+    ScopedTimer t(ctx, "Schwarz/local solve");
+    DDMCHECK(ilu0_solve_epilogue(ctx, S->solver, S->d_ovlp, S->x_ovlp, two_streams ? nullptr : pou, two_streams ? nullptr : (const double *)G->x_ovlp));
+  }
+  {
     ScopedTimer t(ctx, "Schwarz/add solution");
-    if (S->type == 1 && S->pou) hipLaunchKernelGGL(k_scale, dim3(grid_for(S->n)), dim3(WG), 0, ctx->stream, S->n, S->pou, S->x_ovlp);
-    if (two_streams) HIPCHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-    hipLaunchKernelGGL(k_axpy, dim3(grid_for(S->n)), dim3(WG), 0, ctx->stream, S->n, 1.0, (const double *)G->x_ovlp, S->x_ovlp);
+    if (two_streams) {
+      if (pou) hipLaunchKernelGGL(k_scale, dim3(grid_for(S->n)), dim3(WG), 0, ctx->stream, S->n, pou, S->x_ovlp);
+      HIPCHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+      hipLaunchKernelGGL(k_axpy, dim3(grid_for(S->n)), dim3(WG), 0, ctx->stream, S->n, 1.0, (const double *)G->x_ovlp, S->x_ovlp);
+    }
     DDMCHECK(ddm_halo_exchange(ctx, S->add, S->x_ovlp));
     hipLaunchKernelGGL((k_restrict<false, false>), dim3(grid_for(S->n)), dim3(WG), 0, ctx->stream, S->n, S->ext_map, S->x_ovlp, (const double *)nullptr, x);
     HIPCHECK(ctx, hipGetLastError());
@@ -2393,8 +2411,15 @@ extern "C" int ddm_cg_steps(ddm_ctx *ctx, ddm_cg *S, int k)
     DDMCHECK(ddm_op_apply(ctx, S->op, S->p, S->q));                                          // q = A p
     DDMCHECK(dot_device(ctx, S->n, S->op->owner, S->p, S->q, scal + 1));                     // alpha = <p, q>
     hipLaunchKernelGGL(k_cg_lambda, dim3(1), dim3(1), 0, ctx->stream, scal);                 // lambda = rholast / alpha
-    hipLaunchKernelGGL(k_cg_update, dim3(G), dim3(WG), 0, ctx->stream, S->n, scal, S->p, S->q, S->x, S->b); // x += lambda p; b -= lambda q
-    DDMCHECK(dot_device(ctx, S->n, S->op->owner, S->b, S->b, scal + 5));                     // def^2 = <b, b>
+    { // x += lambda p; b -= lambda q; def^2 = <b, b> (partial sums in the same kernel)
+      const int nb = grid_for(S->n, WG * 4, RED_MAX_BLOCKS);
+      if (S->op->owner)
+        hipLaunchKernelGGL(k_cg_update_norm<true>, dim3(nb), dim3(WG), 0, ctx->stream, S->n, scal, S->op->owner, S->p, S->q, S->x, S->b, ctx->partial);
+      else
+        hipLaunchKernelGGL(k_cg_update_norm<false>, dim3(nb), dim3(WG), 0, ctx->stream, S->n, scal, S->op->owner, S->p, S->q, S->x, S->b, ctx->partial);
+      hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(WG), 0, ctx->stream, nb, ctx->partial, scal + 5);
+      DDMCHECK(ctx_allreduce(ctx, scal + 5, 1, "scalar product"));
+    }
     S->it += 1;
   }
   HIPCHECK(ctx, hipGetLastError());

@@ -43,6 +43,7 @@ extern "C" int ddm_geneo_params_default(ddm_geneo_params *p)
   p->preconditioner = 0;
   p->max_direct_flops = 3e11;
   p->verbose = 0;
+  p->raw = 0;
   return DDM_OK;
 }
 
@@ -161,11 +162,209 @@ static void build_pencil_host(const ddm_csr *A, const ddm_csr *B, const double *
   for (auto &t : th) t.join();
 }
 
+// X = keep .* X - Y  (rows: keep = 0 / 1): tail of the harmonic projection / extension
+__global__ void k_geneo_project(int64_t n, int m, const double *__restrict__ keep, const double *__restrict__ Y, int64_t ldy, double *__restrict__ X, int64_t ldx)
+{
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= n * m) return;
+  const int64_t i = t / m;
+  const int j = (int)(t - i * m);
+  X[i * ldx + j] = keep[i] * X[i * ldx + j] - Y[i * ldy + j];
+}
+// Y = w .* X
+__global__ void k_geneo_rowscale_to(int64_t n, int m, const double *__restrict__ w, const double *__restrict__ X, int64_t ldx, double *__restrict__ Y, int64_t ldy)
+{
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= n * m) return;
+  const int64_t i = t / m;
+  const int j = (int)(t - i * m);
+  Y[i * ldy + j] = w[i] * X[i * ldx + j];
+}
+
+static bool csr_values_symmetric(const ddm_csr *A)
+{
+  const int64_t n = A->nrows;
+  for (int64_t i = 0; i < n; ++i)
+    for (int64_t k = A->h_rp[i]; k < A->h_rp[i + 1]; ++k) {
+      const int64_t j = A->h_ci[k];
+      if (j <= i) continue;
+      const auto b = A->h_ci.begin() + A->h_rp[j], e = A->h_ci.begin() + A->h_rp[j + 1];
+      const auto it = std::lower_bound(b, e, (int32_t)i);
+      const double vt = (it != e && *it == i) ? A->h_va[(size_t)(it - A->h_ci.begin())] : 0.0;
+      if (std::fabs(vt - A->h_va[k]) > 1e-12 * (std::fabs(vt) + std::fabs(A->h_va[k]))) return false;
+    }
+  return true;
+}
+
 } // namespace
+
+// Energy-minimal (a-harmonic) extension u_i = -A_ii^-1 A_ib u_b (EnergyMinimalExtension, energy_minimal_extension.hh:36-229) for
+// row-major device blocks: the interior block is factorised once by the sparse direct solver, as part of the n x n matrix
+//     A^ = [A_ii 0; 0 I]   (rows / columns outside the interior replaced by the identity),
+// so that every operand is a full-length block and no index gathers are needed:  X <- keep .* X - A^^-1 (G_ib X)  with G_ib the
+// interior rows x boundary columns of A.  The same object projects onto the a-harmonic subspace in the constrained eigensolver
+// (MsGFEMCoarseSpace): P X = keep_b .* X - A^^-1 G_ib X,  P^T R = keep_b .* R - G_bi A^^-T (interior .* R).
+struct ddm_harmonic {
+  int64_t n = 0;
+  ddm_csr *Gib = nullptr, *Gbi = nullptr;
+  ddm_ilu0 *F = nullptr;
+  double *keep = nullptr;   // 1 outside the interior (rows the extension leaves alone)
+  double *keep_b = nullptr; // 1 on boundary rows only (projection: rows that are neither interior nor boundary are zeroed)
+  double *isint = nullptr;  // 1 on interior rows
+  double *t1 = nullptr, *t2 = nullptr;
+  int tcols = 0;
+  bool symmetric = true;
+};
+extern "C" void ddm_harmonic_destroy(ddm_harmonic *H)
+{
+  if (!H) return;
+  ddm_csr_destroy(H->Gib);
+  ddm_csr_destroy(H->Gbi);
+  ddm_ilu0_destroy(H->F);
+  (void)hipFree(H->keep);
+  (void)hipFree(H->keep_b);
+  (void)hipFree(H->isint);
+  (void)hipFree(H->t1);
+  (void)hipFree(H->t2);
+  delete H;
+}
+// cls[i]: 0 = interior, 1 = boundary, anything else = neither (its values count as zero in the right-hand side, :109-118)
+static int harmonic_create_impl(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, const uint8_t *cls, bool want_transpose, ddm_harmonic **out)
+{
+  const int64_t n = A->nrows;
+  std::vector<int64_t> rpI((size_t)n + 1, 0), rpG((size_t)n + 1, 0), rpT((size_t)n + 1, 0);
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t ci = 0, cg = 0;
+    if (cls[i] == 0) {
+      for (int64_t k = A->h_rp[i]; k < A->h_rp[i + 1]; ++k) {
+        const uint8_t c = cls[A->h_ci[k]];
+        ci += c == 0;
+        cg += c == 1;
+        if (c == 1) rpT[(size_t)A->h_ci[k] + 1] += 1;
+      }
+      if (ci == 0) return fail(ctx, DDM_ENUMERIC, "harmonic extension: interior row %lld has no interior entries", (long long)i);
+    } else ci = 1;
+    rpI[(size_t)i + 1] = rpI[(size_t)i] + ci;
+    rpG[(size_t)i + 1] = rpG[(size_t)i] + cg;
+  }
+  for (int64_t i = 0; i < n; ++i) rpT[(size_t)i + 1] += rpT[(size_t)i];
+  std::vector<int32_t> ciI((size_t)rpI[n]), ciG((size_t)rpG[n]), ciT((size_t)rpT[n]);
+  std::vector<double> vaI((size_t)rpI[n]), vaG((size_t)rpG[n]), vaT((size_t)rpT[n]);
+  std::vector<int64_t> fill(rpT.begin(), rpT.end() - 1);
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t qi = rpI[(size_t)i], qg = rpG[(size_t)i];
+    if (cls[i] != 0) {
+      ciI[(size_t)qi] = (int32_t)i;
+      vaI[(size_t)qi] = 1.0;
+      continue;
+    }
+    for (int64_t k = A->h_rp[i]; k < A->h_rp[i + 1]; ++k) {
+      const int32_t j = A->h_ci[k];
+      if (cls[j] == 0) {
+        ciI[(size_t)qi] = j;
+        vaI[(size_t)qi++] = A->h_va[k];
+      } else if (cls[j] == 1) {
+        ciG[(size_t)qg] = j;
+        vaG[(size_t)qg++] = A->h_va[k];
+        const int64_t q = fill[(size_t)j]++; // rows i ascending => sorted columns in the transpose
+        ciT[(size_t)q] = (int32_t)i;
+        vaT[(size_t)q] = A->h_va[k];
+      }
+    }
+  }
+  ddm_harmonic *H = new ddm_harmonic;
+  H->n = n;
+  ddm_csr *Ahat = nullptr;
+  int rc = ddm_csr_create(ctx, n, n, rpI.data(), ciI.data(), vaI.data(), &Ahat);
+  if (!rc) {
+    H->symmetric = csr_values_symmetric(Ahat);
+    rc = ddm_direct_create(ctx, Ahat, nblocks, block_ptr, H->symmetric ? 0 : 1, 0.0, &H->F);
+  }
+  ddm_csr_destroy(Ahat);
+  if (!rc) rc = ddm_csr_create(ctx, n, n, rpG.data(), ciG.data(), vaG.data(), &H->Gib);
+  if (!rc && want_transpose) rc = ddm_csr_create(ctx, n, n, rpT.data(), ciT.data(), vaT.data(), &H->Gbi);
+  if (!rc) {
+    std::vector<double> k0((size_t)n), k1((size_t)n), k2((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+      k0[(size_t)i] = cls[i] == 0 ? 0.0 : 1.0;
+      k1[(size_t)i] = cls[i] == 1 ? 1.0 : 0.0;
+      k2[(size_t)i] = cls[i] == 0 ? 1.0 : 0.0;
+    }
+    rc = upload(ctx, k0.data(), n, &H->keep);
+    if (!rc) rc = upload(ctx, k1.data(), n, &H->keep_b);
+    if (!rc) rc = upload(ctx, k2.data(), n, &H->isint);
+  }
+  if (rc) {
+    ddm_harmonic_destroy(H);
+    return rc;
+  }
+  *out = H;
+  return DDM_OK;
+}
+static int harmonic_reserve(ddm_ctx *ctx, ddm_harmonic *H, int m)
+{
+  if (m <= H->tcols) return DDM_OK;
+  (void)hipFree(H->t1);
+  (void)hipFree(H->t2);
+  H->t1 = H->t2 = nullptr;
+  H->tcols = 0;
+  HIPCHECK(ctx, hipMalloc((void **)&H->t1, sizeof(double) * (size_t)std::max<int64_t>(H->n, 1) * m));
+  HIPCHECK(ctx, hipMalloc((void **)&H->t2, sizeof(double) * (size_t)std::max<int64_t>(H->n, 1) * m));
+  H->tcols = m;
+  return DDM_OK;
+}
+// X <- keep .* X - A^^-1 G_ib X  (keep = rows outside the interior, or boundary rows only)
+static int harmonic_apply(ddm_ctx *ctx, ddm_harmonic *H, int m, double *X, int64_t ldx, bool boundary_only)
+{
+  DDMCHECK(harmonic_reserve(ctx, H, m));
+  DDMCHECK(csr_mm_ld(ctx, H->Gib, m, X, ldx, H->t1, m));
+  DDMCHECK(ilu0_solve_multi_ld(ctx, H->F, m, H->t1, m, H->t2, m));
+  hipLaunchKernelGGL(k_geneo_project, dim3((unsigned)((H->n * (int64_t)m + 255) / 256)), dim3(256), 0, ctx->stream, H->n, m, boundary_only ? H->keep_b : H->keep,
+                     (const double *)H->t2, (int64_t)m, X, ldx);
+  HIPCHECK(ctx, hipGetLastError());
+  return DDM_OK;
+}
+// R <- keep_b .* R - G_bi A^^-1 (interior .* R)   (transpose of the projection; symmetric A only)
+static int harmonic_apply_transposed(ddm_ctx *ctx, ddm_harmonic *H, int m, double *R, int64_t ldr)
+{
+  DDMCHECK(harmonic_reserve(ctx, H, m));
+  const unsigned g = (unsigned)((H->n * (int64_t)m + 255) / 256);
+  hipLaunchKernelGGL(k_geneo_rowscale_to, dim3(g), dim3(256), 0, ctx->stream, H->n, m, H->isint, (const double *)R, ldr, H->t1, (int64_t)m);
+  DDMCHECK(ilu0_solve_multi_ld(ctx, H->F, m, H->t1, m, H->t2, m));
+  DDMCHECK(csr_mm_ld(ctx, H->Gbi, m, H->t2, m, H->t1, m));
+  hipLaunchKernelGGL(k_geneo_project, dim3(g), dim3(256), 0, ctx->stream, H->n, m, H->keep_b, (const double *)H->t1, (int64_t)m, R, ldr);
+  HIPCHECK(ctx, hipGetLastError());
+  return DDM_OK;
+}
+extern "C" int ddm_harmonic_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, int64_t n_interior, const int64_t *interior_host,
+                                   int64_t n_boundary, const int64_t *boundary_host, ddm_harmonic **out)
+{
+  if (!ctx || !A || !out || nblocks < 1 || !block_ptr || n_interior < 0 || n_boundary < 0 || (n_interior && !interior_host) || (n_boundary && !boundary_host))
+    return fail(ctx, DDM_EINVAL, "ddm_harmonic_create: bad arguments");
+  if (A->nrows != A->ncols) return fail(ctx, DDM_EINVAL, "ddm_harmonic_create: square matrix expected");
+  const int64_t n = A->nrows;
+  std::vector<uint8_t> cls((size_t)n, 2);
+  for (int64_t k = 0; k < n_boundary; ++k) {
+    if (boundary_host[k] < 0 || boundary_host[k] >= n) return fail(ctx, DDM_EINVAL, "ddm_harmonic_create: boundary index out of range");
+    cls[(size_t)boundary_host[k]] = 1; // listed twice is fine (coarse_spaces.hh:582-589 produces duplicates)
+  }
+  for (int64_t k = 0; k < n_interior; ++k) {
+    if (interior_host[k] < 0 || interior_host[k] >= n) return fail(ctx, DDM_EINVAL, "ddm_harmonic_create: interior index out of range");
+    if (cls[(size_t)interior_host[k]] == 1) return fail(ctx, DDM_EINVAL, "ddm_harmonic_create: index %lld is both interior and boundary", (long long)interior_host[k]);
+    cls[(size_t)interior_host[k]] = 0;
+  }
+  return harmonic_create_impl(ctx, A, nblocks, block_ptr, cls.data(), false, out);
+}
+extern "C" int ddm_harmonic_extend(ddm_ctx *ctx, ddm_harmonic *H, int nrhs, double *X, int64_t ldx)
+{
+  if (!ctx || !H || !X || nrhs < 1 || ldx < nrhs) return fail(ctx, DDM_EINVAL, "ddm_harmonic_extend: bad arguments");
+  for (int c0 = 0; c0 < nrhs; c0 += 48) DDMCHECK(harmonic_apply(ctx, H, std::min(48, nrhs - c0), X + c0, ldx, false));
+  return DDM_OK;
+}
 
 static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, int64_t nsub, const int64_t *sub_ptr, const double *pou_host,
                      const uint8_t *dirichlet_host, const ddm_geneo_params &P, int nev, double *basis_dev /* nev x n */, double *eig_host /* nsub x nev */,
-                     ddm_geneo_info *info)
+                     ddm_geneo_info *info, ddm_harmonic *con = nullptr /* iterate in the a-harmonic subspace */, const double *pou_pencil_host = nullptr)
 {
   const int64_t n = A_neu->nrows;
   const int m = nev + std::max(P.extra, 1);
@@ -179,7 +378,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
   std::vector<int64_t> rpT;
   std::vector<int32_t> ciT;
   std::vector<double> vaT, vaC;
-  build_pencil_host(A_neu, B_neu, pou_host, dirichlet_host, P.shift, rpT, ciT, vaT, vaC);
+  build_pencil_host(A_neu, B_neu, pou_pencil_host ? pou_pencil_host : pou_host, dirichlet_host, P.shift, rpT, ciT, vaT, vaC);
   struct Owned {
     ddm_csr *At = nullptr, *C = nullptr;
     ddm_ilu0 *T = nullptr;
@@ -257,6 +456,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
   const int64_t ld = p;
   // ---- initial block: random on the free DoFs, Rayleigh-Ritz on span X ----
   hipLaunchKernelGGL(k_geneo_random, dim3(gnm), dim3(256), 0, ctx->stream, n, m, ld, 0x5DEECE66Dull + (unsigned long long)P.seed, maskd, S[0]);
+  if (con) DDMCHECK(harmonic_apply(ctx, con, m, S[0], ld, true));
   DDMCHECK(csr_mm_ld(ctx, own.At, m, S[0], ld, AS[0], ld));
   DDMCHECK(csr_mm_ld(ctx, own.C, m, S[0], ld, CS[0], ld));
   int cur = 0, it = 0, converged = 0, rank_min = p;
@@ -269,6 +469,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
     if (it > 0) {
       // R = C X - mu A~ X ; column norms ; W = T (R / ||R||)
       hipLaunchKernelGGL(k_geneo_residual, dim3(gnm), dim3(256), 0, ctx->stream, n, m, W.sub_of_row, mud, AS[cur], ld, CS[cur], ld, R, (int64_t)m);
+      if (con) DDMCHECK(harmonic_apply_transposed(ctx, con, m, R, m)); // residual of the constrained problem: P^T r
       DDMCHECK(W.gram(R, m, m, R, m, m, gmm[0]));
       HIPCHECK(ctx, hipMemcpyAsync(h_rr.data(), gmm[0], sizeof(double) * h_rr.size(), hipMemcpyDeviceToHost, ctx->stream));
       hipLaunchKernelGGL(k_geneo_invsqrt_diag, dim3((unsigned)((nsub * m + 255) / 256)), dim3(256), 0, ctx->stream, (int)nsub, m, gmm[0], svec[0]);
@@ -277,6 +478,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
       DDMCHECK(ilu0_solve_multi_ld(ctx, own.T, m, R, m, Wb, ld));
       DDMCHECK(W.gram(R, m, m, Wb, ld, m, gmm[1]));   // r^T T r per column (diagonal)
       HIPCHECK(ctx, hipMemcpyAsync(h_rw.data(), gmm[1], sizeof(double) * h_rw.size(), hipMemcpyDeviceToHost, ctx->stream));
+      if (con) DDMCHECK(harmonic_apply(ctx, con, m, Wb, ld, true));    // W = P T P^T r stays in the subspace
       DDMCHECK(W.gram(AS[cur], ld, m, AS[cur], ld, m, gmm[2]));
       HIPCHECK(ctx, hipMemcpyAsync(h_aa.data(), gmm[2], sizeof(double) * h_aa.size(), hipMemcpyDeviceToHost, ctx->stream));
       // W <- W - X (A~X)^T W   (twice), then A~-normalise the columns of W
@@ -371,6 +573,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
       cur = nxt;
     }
     if (it > 0 && it % 8 == 0) { // refresh A~X, C X from X: the recursions drift
+      if (con) DDMCHECK(harmonic_apply(ctx, con, m, S[cur], ld, true));
       DDMCHECK(csr_mm_ld(ctx, own.At, m, S[cur], ld, AS[cur], ld));
       DDMCHECK(csr_mm_ld(ctx, own.C, m, S[cur], ld, CS[cur], ld));
     }
@@ -380,9 +583,9 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
   for (int64_t s = 0; s < nsub; ++s)
     for (int j = 0; j < nev; ++j) eig_host[(size_t)s * nev + j] = 1.0 / hmu[(size_t)s * m + j] - P.shift;
   hipLaunchKernelGGL(k_geneo_copy_cols, dim3(gnm), dim3(256), 0, ctx->stream, n, m, (const double *)S[cur], ld, R, (int64_t)m);
-  hipLaunchKernelGGL(k_geneo_rowscale, dim3(gnm), dim3(256), 0, ctx->stream, n, m, poud, R, (int64_t)m);       // v <- D v
+  if (!P.raw) hipLaunchKernelGGL(k_geneo_rowscale, dim3(gnm), dim3(256), 0, ctx->stream, n, m, poud, R, (int64_t)m); // v <- D v
   DDMCHECK(W.gram(R, m, m, R, m, m, gmm[0]));
-  hipLaunchKernelGGL(k_geneo_invsqrt_diag, dim3((unsigned)((nsub * m + 255) / 256)), dim3(256), 0, ctx->stream, (int)nsub, m, gmm[0], svec[0]); // 1 / ||D v||_2
+  hipLaunchKernelGGL(k_geneo_invsqrt_diag, dim3((unsigned)((nsub * m + 255) / 256)), dim3(256), 0, ctx->stream, (int)nsub, m, gmm[0], svec[0]); // 1 / ||D v||_2  (raw: 1 / ||v||_2)
   hipLaunchKernelGGL(k_geneo_rowscale, dim3(gnm), dim3(256), 0, ctx->stream, n, m, maskd, R, (int64_t)m);      // zero_at_dirichlet
   hipLaunchKernelGGL(k_geneo_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, nev, W.sub_of_row, svec[0], m, R, (int64_t)m, basis_dev);
   HIPCHECK(ctx, hipGetLastError());
@@ -400,28 +603,28 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
   return DDM_OK;
 }
 
-extern "C" int ddm_geneo_basis(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, int64_t nsub, const int64_t *sub_ptr, const double *pou_host,
-                               const uint8_t *dirichlet_host, const ddm_geneo_params *params, int64_t kmax, double *basis_host, int32_t *nconv,
-                               double *eigenvalues_host, ddm_geneo_info *info)
+static int geneo_basis_impl(ddm_ctx *ctx, const char *who, const ddm_csr *A_neu, const ddm_csr *B_neu, int64_t nsub, const int64_t *sub_ptr, const double *pou_host,
+                            const uint8_t *dirichlet_host, const ddm_geneo_params *params, int64_t kmax, double *basis_host, int32_t *nconv,
+                            double *eigenvalues_host, ddm_geneo_info *info, ddm_harmonic *con, const double *pou_pencil_host)
 {
   if (!ctx || !A_neu || !B_neu || !sub_ptr || !pou_host || !params || !basis_host || !nconv || !eigenvalues_host || nsub < 1)
-    return fail(ctx, DDM_EINVAL, "ddm_geneo_basis: bad arguments");
+    return fail(ctx, DDM_EINVAL, "%s: bad arguments", who);
   if (A_neu->nrows != A_neu->ncols || B_neu->nrows != A_neu->nrows || B_neu->ncols != A_neu->ncols)
     return fail(ctx, DDM_EINVAL, "The matrix and the partition of unity must have the same size"); // coarse_spaces.hh:323
   if (sub_ptr[0] != 0 || sub_ptr[nsub] != A_neu->nrows) return fail(ctx, DDM_EINVAL, "sub_ptr does not cover the matrix");
   const ddm_geneo_params &P = *params;
-  if (P.nev < 1 || P.extra < 1 || !(P.tolerance > 0.0)) return fail(ctx, DDM_EINVAL, "ddm_geneo_basis: bad eigensolver parameters");
+  if (P.nev < 1 || P.extra < 1 || !(P.tolerance > 0.0)) return fail(ctx, DDM_EINVAL, "%s: bad eigensolver parameters", who);
   const int64_t n = A_neu->nrows;
   int nev = P.nev;
   // threshold mode of spectra_gevp_op (eigensolvers/spectra.hh:157-163, 186-189): keep the eigenvalues below the threshold (at least
   // one), double nev until the largest computed one exceeds it or nev >= nev_max
   for (;;) {
-    if (nev > kmax) return fail(ctx, DDM_EINVAL, "ddm_geneo_basis: kmax = %lld is smaller than nev = %d", (long long)kmax, nev);
+    if (nev > kmax) return fail(ctx, DDM_EINVAL, "%s: kmax = %lld is smaller than nev = %d", who, (long long)kmax, nev);
     double *basis_dev = nullptr;
     HIPCHECK(ctx, hipMalloc((void **)&basis_dev, sizeof(double) * (size_t)nev * (size_t)std::max<int64_t>(n, 1)));
     std::vector<double> eig((size_t)nsub * nev);
-    int rc = geneo_run(ctx, A_neu, B_neu, nsub, sub_ptr, pou_host, dirichlet_host, P, nev, basis_dev, eig.data(), info);
-    if (!rc && hipMemcpy(basis_host, basis_dev, sizeof(double) * (size_t)nev * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, DDM_EHIP, "GenEO: basis download failed");
+    int rc = geneo_run(ctx, A_neu, B_neu, nsub, sub_ptr, pou_host, dirichlet_host, P, nev, basis_dev, eig.data(), info, con, pou_pencil_host);
+    if (!rc && hipMemcpy(basis_host, basis_dev, sizeof(double) * (size_t)nev * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, DDM_EHIP, "%s: basis download failed", who);
     (void)hipFree(basis_dev);
     if (rc) return rc;
     bool done = true;
@@ -445,6 +648,46 @@ extern "C" int ddm_geneo_basis(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr
     }
     nev *= 2;
   }
+}
+
+extern "C" int ddm_geneo_basis(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, int64_t nsub, const int64_t *sub_ptr, const double *pou_host,
+                               const uint8_t *dirichlet_host, const ddm_geneo_params *params, int64_t kmax, double *basis_host, int32_t *nconv,
+                               double *eigenvalues_host, ddm_geneo_info *info)
+{
+  return geneo_basis_impl(ctx, "ddm_geneo_basis", A_neu, B_neu, nsub, sub_ptr, pou_host, dirichlet_host, params, kmax, basis_host, nconv, eigenvalues_host, info, nullptr,
+                          nullptr);
+}
+
+// MsGFEMCoarseSpace::setup_msgfem_impl (coarse_spaces.hh:712-826).  The reference assembles the saddle-point pencil
+//     [A_nn  G^T; G  0] [u; p] = lambda [D A_ii D  0; 0  0] [u; p],      G = interior rows of A_dir (a-harmonicity),
+// on the non-Dirichlet DoFs and hands it to the shift-invert Lanczos with an LU of the indefinite matrix.  Here the multipliers are
+// eliminated instead: the same eigenpairs are the stationary points of the Rayleigh quotient of (A_neu, D A_ii D) on the
+// a-harmonic subspace {u : G u = 0, u = 0 on Dirichlet DoFs}, and the block iteration of geneo_run stays inside that subspace
+// with the projection P = [0 -A_ii^-1 A_ib; 0 I] (ddm_harmonic: one sparse Cholesky of the interior block, multi-RHS solves):
+// start block P X0, search directions P T P^T r.  With the exact T = (A_neu + sigma C)^-1 the preconditioned operator is the
+// inverse of the Schur complement onto the boundary unknowns, i.e. the iteration is the device analogue of the shift-invert.
+extern "C" int ddm_msgfem_basis(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *A_dir, int64_t nsub, const int64_t *sub_ptr, const double *pou_host,
+                                const uint8_t *dirichlet_host, const uint8_t *boundary_host, const ddm_geneo_params *params, int64_t kmax, double *basis_host,
+                                int32_t *nconv, double *eigenvalues_host, ddm_geneo_info *info)
+{
+  if (!ctx || !A_neu || !A_dir || !sub_ptr || !pou_host || !boundary_host || !params || nsub < 1) return fail(ctx, DDM_EINVAL, "ddm_msgfem_basis: bad arguments");
+  if (A_dir->nrows != A_neu->nrows || A_dir->ncols != A_dir->nrows) return fail(ctx, DDM_EINVAL, "The two matrices must have the same size"); // :714
+  const int64_t n = A_dir->nrows;
+  std::vector<uint8_t> cls((size_t)n);
+  std::vector<double> pou_int((size_t)n);
+  for (int64_t i = 0; i < n; ++i) { // :722-740
+    cls[(size_t)i] = (dirichlet_host && dirichlet_host[i]) ? 2 : boundary_host[i] ? 1 : 0;
+    pou_int[(size_t)i] = cls[(size_t)i] == 0 ? pou_host[i] : 0.0; // the right-hand side has interior x interior entries only (:801-811)
+  }
+  ddm_harmonic *H = nullptr;
+  DDMCHECK(harmonic_create_impl(ctx, A_dir, nsub, sub_ptr, cls.data(), true, &H));
+  int rc = DDM_OK;
+  if (!H->symmetric) rc = fail(ctx, DDM_ENOTIMPL, "ddm_msgfem_basis: the interior block of A_dir is not symmetric");
+  if (!rc)
+    rc = geneo_basis_impl(ctx, "ddm_msgfem_basis", A_neu, A_neu, nsub, sub_ptr, pou_host, dirichlet_host, params, kmax, basis_host, nconv, eigenvalues_host, info, H,
+                          pou_int.data());
+  ddm_harmonic_destroy(H);
+  return rc;
 }
 
 // ---- the two dense block kernels on their own (parity tests against an FP64 host reference; also usable by callers that keep

@@ -923,6 +923,25 @@ __global__ void k_cg_update(int64_t n, const double *__restrict__ scal, const do
     b[i] -= lam * q[i];
   }
 }
+// the same update followed by the owner-masked partial sums of <b, b> (same grid and summation order as k_dot_partial,
+// so the norm is bit-identical to the separate dot product; saves its pass over b)
+template <bool MASKED>
+__global__ __launch_bounds__(WG) void k_cg_update_norm(int64_t n, const double *__restrict__ scal, const uint8_t *__restrict__ mask,
+                                                        const double *__restrict__ p, const double *__restrict__ q, double *__restrict__ x,
+                                                        double *__restrict__ b, double *__restrict__ partial)
+{
+  __shared__ double red[4];
+  const double lam = scal[2];
+  double s = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG) {
+    x[i] += lam * p[i];
+    const double bi = b[i] - lam * q[i];
+    b[i] = bi;
+    if (!MASKED || mask[i]) s += bi * bi;
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
 // p = beta p + q
 __global__ void k_cg_direction(int64_t n, const double *__restrict__ scal, const double *__restrict__ q, double *__restrict__ p)
 {

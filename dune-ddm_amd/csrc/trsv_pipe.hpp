@@ -203,9 +203,17 @@ __global__ void k_pipe_permute_in(int64_t npos, const int32_t *__restrict__ rowL
     dperm[p] = r >= 0 ? d[r] : 0.0;
   }
 }
-__global__ void k_pipe_permute_out(int64_t n, const int32_t *__restrict__ posU, const double *__restrict__ xpos, double *__restrict__ x)
+// x = P^T xpos, optionally followed by the Schwarz level's "x *= pou" and "x += coarse correction" (same operations in the same
+// order as the separate kernels, so the result is bit-identical; saves their passes over the overlapping vector)
+__global__ void k_pipe_permute_out(int64_t n, const int32_t *__restrict__ posU, const double *__restrict__ xpos, double *__restrict__ x,
+                                   const double *__restrict__ scale, const double *__restrict__ add)
 {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] = xpos[posU[i]];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double v = xpos[posU[i]];
+    if (scale) v *= scale[i];
+    if (add) v += add[i];
+    x[i] = v;
+  }
 }
 
 __device__ __forceinline__ void pipe_glds16(const unsigned char *gsrc, unsigned char *lds_dst)

@@ -33,6 +33,8 @@ class SubdomainData:
     pou: np.ndarray | None      # f64[n]
     A_neu: sp.csr_matrix | None = None
     B_neu: sp.csr_matrix | None = None
+    boundary: np.ndarray | None = None     # bool[n]: subdomain boundary mask (IdentifyBoundaryDataHandle)
+    boundary_dist: np.ndarray | None = None  # graph distance to the subdomain boundary (exact up to 4 * overlap)
 
 
 @dataclass
@@ -77,8 +79,11 @@ def build_structured(grid, overlap=2, pou_type="distance", shrink=0, neumann=Fal
     subs = []
     for r, (s, i) in enumerate(zip(nov, idx)):
         sd = SubdomainData(r, i.n_o, len(i.glob), i.glob, s.A, s.owner, s.b, A_dir[r], i.owner, dmask[r], pou[r])
+        if bmask is not None:
+            sd.boundary = np.asarray(bmask[r], dtype=bool)
         if neumann:
             d = dist[r] if dist is not None else sh.bfs_distance(A_dir[r], bmask[r], 4 * overlap + 1)
+            sd.boundary_dist = d
             sd.A_neu = grid.neumann_matrix(i.glob, None, dmask[r])
             sd.B_neu = sd.A_neu if second_region == "all" else grid.neumann_matrix(i.glob, d <= 2 * overlap, dmask[r])
         subs.append(sd)

@@ -241,6 +241,8 @@ typedef struct {
   int32_t preconditioner;  /* 0 = sparse Cholesky of A + shift C if its flop count <= max_direct_flops, else ILU(0); 1 = ILU(0); 2 = Cholesky */
   double max_direct_flops; /* 3e11: about 10-20 s on 8 host threads */
   int32_t verbose;
+  int32_t raw;             /* 1: return the eigenvectors normalised to ||v||_2 = 1 without the "v <- D v" of finalize_eigenvectors
+                            * (the ring coarse spaces extend the ring eigenvectors first, coarse_spaces.hh:612-627) */
 } ddm_geneo_params;
 typedef struct {
   int32_t iterations, converged, used_direct, nev;
@@ -250,6 +252,26 @@ int ddm_geneo_params_default(ddm_geneo_params *p);
 int ddm_geneo_basis(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, int64_t nsub, const int64_t *sub_ptr, const double *pou_host,
                     const uint8_t *dirichlet_host, const ddm_geneo_params *params, int64_t kmax, double *basis_host, int32_t *nconv,
                     double *eigenvalues_host, ddm_geneo_info *info);
+/* MsGFEMCoarseSpace(A_neu, A_dir, pou, dirichlet_mask, subdomain_boundary_mask, ptree, taskflow, prefix = "msgfem")
+ * (coarse_spaces.hh:663-831; the default coarse space of examples/poisson.ini:36): GenEO's eigenproblem with right-hand side
+ * D A_neu D on the interior DoFs, restricted to the a-harmonic functions (A_dir u = 0 in interior rows); Dirichlet DoFs are left
+ * out and get zero entries.  Arguments as ddm_geneo_basis plus boundary_host[n] (the subdomain boundary mask); A_dir must be
+ * symmetric in its interior block (DDM_ENOTIMPL otherwise).  csrc/geneo.hpp describes how the saddle-point pencil of the
+ * reference is replaced by an iteration inside the constrained subspace. */
+int ddm_msgfem_basis(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *A_dir, int64_t nsub, const int64_t *sub_ptr, const double *pou_host,
+                     const uint8_t *dirichlet_host, const uint8_t *boundary_host, const ddm_geneo_params *params, int64_t kmax, double *basis_host,
+                     int32_t *nconv, double *eigenvalues_host, ddm_geneo_info *info);
+/* EnergyMinimalExtension(A, interior_indices, boundary_indices) (coarsespaces/energy_minimal_extension.hh:36-229), the building
+ * block of the ring and harmonic-extension coarse spaces (coarse_spaces.hh:598, 1097, 1250): u_i = -A_ii^-1 (A [0; u_b])_i.
+ * A may be block diagonal (block_ptr[nblocks+1]: one sparse direct factor per block; Cholesky if the interior block is symmetric,
+ * LU without pivoting otherwise).  extend works IN PLACE on a row-major DEVICE block X (n x nrhs, leading dimension ldx) that
+ * holds the boundary values: interior rows are overwritten, every other row is left alone; values in rows that are neither
+ * interior nor boundary do not enter (they count as zero, :109-118). */
+typedef struct ddm_harmonic ddm_harmonic;
+int ddm_harmonic_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, int64_t n_interior, const int64_t *interior_host,
+                        int64_t n_boundary, const int64_t *boundary_host, ddm_harmonic **out);
+void ddm_harmonic_destroy(ddm_harmonic *H);
+int ddm_harmonic_extend(ddm_ctx *ctx, ddm_harmonic *H, int nrhs, double *X, int64_t ldx);
 /* The two dense contractions of the block eigensolver on their own (FP64 MFMA, csrc/geneo_kernels.hpp), for row-major DEVICE
  * blocks split into subdomain row ranges sub_ptr[nsub+1]:
  *   gram  : G_host[s] = U[rows of s]^T V[rows of s]   (nsub matrices pu x pv, row-major; split-K over 2048-row chunks, summed in

@@ -1,0 +1,160 @@
+"""Device coarse-space builders of SURVEY.md 8f row 3 (dune_ddm_amd.coarse_spaces over ddm_msgfem_basis / ddm_harmonic_* /
+ddm_geneo_basis) against the oracle's literal restatements (oracle/coarse_oracle.py; the reference holds no fixtures for these
+spaces: parity unpinned by reference data, tests/test_oracle_coarse.py pins the oracle by properties).
+
+Tolerances: eigenvalues 1e-6 relative (eigenvalue error ~ residual^2 at the eigensolver tolerance 1e-5 of both sides); every
+oracle vector whose eigenvalue lies strictly below the cut is contained in the device span with sine < 2e-3 (vector error ~
+tol / gap); harmonic extensions 1e-10 relative (two direct solves of the same system)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+def _orth(V):
+    Q, _ = np.linalg.qr(np.asarray(V).T)
+    return Q
+
+
+def _span_check(device_rows, oracle_vecs, lam, tol=2e-3, slack=1e-3):
+    Q = _orth(device_rows)
+    below = [v / np.linalg.norm(v) for v, l in zip(oracle_vecs, lam) if l < lam[-1] * (1 - slack)]
+    assert len(below) >= len(lam) - 2
+    for u in below:
+        assert np.linalg.norm(u - Q @ (Q.T @ u)) < tol
+
+
+def _ring_of(grid, sd, width):
+    ring = np.nonzero(sd.boundary_dist <= width)[0]
+    M = grid.neumann_matrix(sd.glob, sd.boundary_dist <= width, sd.dirichlet_ovlp)
+    return sp.csr_matrix(M)[ring][:, ring].tocsr(), ring
+
+
+def test_harmonic_extension_matches_oracle(ddm):
+    import torch
+    from dune_ddm_amd import synth
+    from dune_ddm_amd.problem import RankLocal, build_structured
+    from oracle import coarse_oracle as co
+    dec = build_structured(synth.StructuredPoisson((17, 15, 13), (2, 2, 1)), overlap=2, pou_type="distance", neumann=True)
+    rl = RankLocal(dec)
+    ctx = ddm.torch_context(0)
+    A = ddm.CsrMatrix(ctx, rl.A_dir)
+    ints, bnds, X = [], [], np.zeros((rl.n, 5))
+    rng = np.random.default_rng(3)
+    for i, sd in enumerate(rl.subs):
+        a = int(rl.block_ptr[i])
+        b = np.nonzero(sd.boundary)[0]
+        ints.append(a + np.nonzero(~sd.boundary)[0])
+        bnds.append(a + b)
+        X[a + b] = rng.standard_normal((len(b), 5))
+    H = ddm.HarmonicExtension(ctx, A, np.concatenate(ints), np.concatenate(bnds), rl.block_ptr)
+    Xd = torch.as_tensor(X).cuda()
+    H.extend(Xd)
+    ctx.sync()
+    Xh = Xd.cpu().numpy()
+    for i, sd in enumerate(rl.subs):
+        a, e = int(rl.block_ptr[i]), int(rl.block_ptr[i + 1])
+        b, ii = np.nonzero(sd.boundary)[0], np.nonzero(~sd.boundary)[0]
+        ext = co.EnergyMinimalExtension(sd.A_dir, ii, b)
+        for j in range(5):
+            ref = ext.extend(X[a + b, j])
+            assert np.abs(Xh[a + ii, j] - ref).max() <= 1e-10 * np.abs(ref).max()
+            assert np.array_equal(Xh[a + b, j], X[a + b, j])          # boundary rows untouched
+    H.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("contrast", [None, 1e4])
+def test_msgfem_matches_oracle_and_iteration_count(ddm, contrast):
+    from dune_ddm_amd import synth
+    from dune_ddm_amd.coarse_spaces import msgfem_basis
+    from dune_ddm_amd.problem import build_structured
+    from dune_ddm_amd.solver import TwoLevelSchwarz
+    from oracle import coarse_oracle as co
+    from tests.oracle_bridge import oracle_solve
+    N, nev = (25, 23, 21), 4
+    kappa = None if contrast is None else synth.islands_kappa(tuple(n - 1 for n in N), contrast=contrast, period=6, width=2)
+    # examples/poisson.cc:207: msgfem assembles both Neumann matrices on NeumannRegion::All
+    dec = build_structured(synth.StructuredPoisson(N, (2, 2, 2), kappa), overlap=2, pou_type="distance", neumann=True, second_region="all")
+    tl = TwoLevelSchwarz(dec, coarse="none")
+    basis, info = msgfem_basis(tl, nev=nev, tol=1e-5, return_info=True)
+    assert info["converged"]
+    obasis = {}
+    for sd in dec.subs:
+        vecs, lam = co.msgfem_basis(sd.A_neu, sd.A_dir, sd.pou, sd.dirichlet_ovlp, sd.boundary, {"nev": nev})
+        assert np.allclose(info["eigenvalues"][sd.id], lam, rtol=1e-6, atol=1e-9), (sd.id, info["eigenvalues"][sd.id], lam)
+        _span_check(basis[sd.id], vecs, lam)
+        assert np.all(basis[sd.id][:, sd.dirichlet_ovlp > 0] == 0)
+        assert np.abs(np.linalg.norm(basis[sd.id], axis=1) - 1.0).max() < 1e-12
+        obasis[sd.id] = list(vecs)
+    tl.set_coarse_basis(basis)
+    tl.rebuild_combined("additive")
+    res, hist, x = tl.solve(reduction=1e-10, maxit=500)
+    it, conv, hist_o, xo = oracle_solve(dec, reduction=1e-10, maxit=500, coarse=obasis, schwarz_type="standard", mode="additive")
+    assert res.converged and conv and abs(res.iterations - it) <= 1, (res.iterations, it)
+    it2, conv2, hist2, _ = oracle_solve(dec, reduction=1e-10, maxit=500, coarse={s: list(basis[s]) for s in basis}, schwarz_type="standard", mode="additive")
+    h2 = np.array(hist2)
+    assert it2 == res.iterations and (np.abs(hist - h2) <= 1e-8 * h2 + 1e-12 * h2[0]).all()
+    tl.ctx.close()
+
+
+def test_ring_coarse_spaces_match_oracle(ddm):
+    from dune_ddm_amd import synth
+    from dune_ddm_amd.coarse_spaces import geneo_ring_basis, msgfem_ring_basis
+    from dune_ddm_amd.problem import build_structured
+    from dune_ddm_amd.solver import TwoLevelSchwarz
+    from oracle import coarse_oracle as co
+    overlap, nev = 2, 4
+    grid = synth.StructuredPoisson((29, 27, 25), (2, 2, 2))
+    dec = build_structured(grid, overlap=overlap, pou_type="distance", neumann=True, second_region="all")
+    tl = TwoLevelSchwarz(dec, coarse="none")
+    # geneo_ring: NeumannRegion::ExtendedOverlap (examples/poisson.cc:210); msgfem_ring: NeumannRegion::Overlap (:211)
+    rg = [_ring_of(grid, sd, 2 * overlap + 1) for sd in tl.rl.subs]
+    basis, info = geneo_ring_basis(tl, [r[0] for r in rg], [r[1] for r in rg], nev=nev, return_info=True)
+    rm = [_ring_of(grid, sd, 2 * overlap) for sd in tl.rl.subs]
+    basis_m, info_m = msgfem_ring_basis(tl, [r[0] for r in rm], [r[1] for r in rm], overlap, nev=nev, return_info=True)
+    assert info["converged"] and info_m["converged"]
+    for i, sd in enumerate(tl.rl.subs):
+        vecs, lam = co.geneo_ring_basis(sd.A_dir, rg[i][0], sd.pou, rg[i][1], {"nev": nev})
+        assert lam.max() < 1.0 - 1e-6      # no decoupled Dirichlet unit mode among the wanted ones (the library leaves them out)
+        assert np.allclose(info["eigenvalues"][sd.id], lam, rtol=1e-6, atol=1e-9), (sd.id, info["eigenvalues"][sd.id], lam)
+        _span_check(basis[sd.id], vecs, lam)
+        vecs, lam = co.msgfem_ring_basis(sd.A_dir, rm[i][0], overlap, sd.pou, 0, sd.dirichlet_ovlp, sd.boundary, rm[i][1], {"nev": nev})
+        assert np.allclose(info_m["eigenvalues"][sd.id], lam, rtol=1e-6, atol=1e-9), (sd.id, info_m["eigenvalues"][sd.id], lam)
+        _span_check(basis_m[sd.id], vecs, lam)
+    # both are usable coarse spaces: the two-level solve converges, and faster than one-level
+    one = TwoLevelSchwarz(dec, coarse="none")
+    r1, _, _ = one.solve(reduction=1e-8, maxit=500)
+    for b in (basis, basis_m):
+        tl.set_coarse_basis({s: np.where(np.asarray(dec.subs[s].dirichlet_ovlp)[None, :] > 0, 0.0, b[s]) for s in b})   # zero_at_dirichlet (poisson.cc:235-238)
+        tl.rebuild_combined("additive")
+        r2, _, _ = tl.solve(reduction=1e-8, maxit=500)
+        assert r2.converged and r2.iterations < r1.iterations
+    one.ctx.close()
+    tl.ctx.close()
+
+
+def test_harmonic_extension_and_pou_spaces(ddm):
+    from dune_ddm_amd import synth
+    from dune_ddm_amd.coarse_spaces import constraint_geneo_basis, harmonic_extension_basis, pou_basis
+    from dune_ddm_amd.geneo import geneo_basis
+    from dune_ddm_amd.problem import build_structured
+    from dune_ddm_amd.solver import TwoLevelSchwarz
+    from oracle import coarse_oracle as co
+    dec = build_structured(synth.StructuredPoisson((17, 15, 13), (2, 2, 1)), overlap=2, pou_type="distance", neumann=True)
+    tl = TwoLevelSchwarz(dec, coarse="none")
+    data = []
+    for sd in tl.rl.subs:
+        nb = int(sd.boundary.sum())
+        data.append(np.array([np.ones(nb), np.cos(np.arange(nb))]))
+    basis = harmonic_extension_basis(tl, data)
+    for i, sd in enumerate(tl.rl.subs):
+        ref = co.harmonic_extension_basis(sd.A_dir, sd.pou, list(data[i]), sd.boundary)
+        assert np.abs(basis[sd.id] - np.array(ref)).max() < 1e-10
+        p = pou_basis(tl)[sd.id]
+        assert p.shape == (1, sd.n) and abs(np.linalg.norm(p) - 1) < 1e-14
+    a = constraint_geneo_basis(tl, nev=3, seed=0)
+    b = geneo_basis(tl, nev=3, seed=0)
+    assert all(np.array_equal(a[s], b[s]) for s in a)
+    tl.ctx.close()

@@ -42,6 +42,18 @@ def test_multi_rhs_kernels(ddm):
         ctx.sync()
         assert torch.allclose(Y[:, j], yj, rtol=1e-13, atol=1e-13)
         assert (Z[:, j] == zj).all()
+    # ... and against the oracle (CSR product in row order; ILU(0) solve is bit-exact, a5)
+    from oracle import apply_oracle as ao
+    oA = ao.Csr(M)
+    oF = ao.Ilu0(oA)
+    Xh = X.cpu().numpy()
+    for j in range(m):
+        xj = np.ascontiguousarray(Xh[:, j])
+        zo, yo = np.empty(n), np.empty(n)
+        oF.apply(zo, xj)
+        oA.mv(xj, yo)
+        assert np.array_equal(Z[:, j].cpu().numpy(), zo)
+        assert np.allclose(Y[:, j].cpu().numpy(), yo, rtol=1e-13, atol=1e-13)
     ctx.close()
 
 
