@@ -21,9 +21,10 @@ def test_adaptors_compile_and_link(ddm):
     exe = _build()
     assert os.path.exists(exe)
     # every C-ABI symbol the adaptors use must be exported by the library
-    out = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True).stdout
-    used = sorted({ln.split()[-1] for ln in out.splitlines() if " ddm_" in ln})
-    assert used and all(u in ddm.SYMBOLS for u in used), [u for u in used if u not in ddm.SYMBOLS]
+    for e in (exe, os.path.join(CPP, "geneo_adaptor"), os.path.join(CPP, "coarse_adaptor")):
+        out = subprocess.run(["nm", "-D", "--undefined-only", e], capture_output=True, text=True).stdout
+        used = sorted({ln.split()[-1] for ln in out.splitlines() if " ddm_" in ln})
+        assert used and all(u in ddm.SYMBOLS for u in used), [u for u in used if u not in ddm.SYMBOLS]
 
 
 @pytest.mark.gpu
@@ -120,3 +121,70 @@ def test_geneo_coarse_space_adaptor_matches_oracle(ddm, tmp_path):
     Qd, _ = np.linalg.qr(Bd.T)
     Qo, _ = np.linalg.qr(np.array(vecs).T)
     assert np.linalg.norm(Qd - Qo @ (Qo.T @ Qd), 2) < 2e-3
+
+
+@pytest.mark.gpu
+def test_remaining_coarse_space_adaptors_match_oracle(ddm, tmp_path):
+    """MsGFEMCoarseSpace, ConstraintGenEOCoarseSpace, GenEORingCoarseSpace, MsGFEMRingCoarseSpace, HarmonicExtensionCoarseSpace
+    (+ EnergyMinimalExtension) constructed with the reference's signatures and run through a taskflow, one subdomain of a 2 x 2 x 2
+    decomposition, against oracle/coarse_oracle.py: eigenvalues 1e-6, spans 2e-3, harmonic extension 1e-10."""
+    import scipy.sparse as sp
+    from dune_ddm_amd import synth
+    from dune_ddm_amd.problem import build_structured
+    from oracle import coarse_oracle as co
+    from oracle import geneo_oracle as go
+    _build()
+    exe = os.path.join(CPP, "coarse_adaptor")
+    overlap, nev = 2, 4
+    grid = synth.StructuredPoisson((29, 27, 25), (2, 2, 2))
+    dec = build_structured(grid, overlap=overlap, pou_type="distance", neumann=True, second_region="all")
+    sd = dec.subs[3]
+
+    def ring_of(width):
+        ring = np.nonzero(sd.boundary_dist <= width)[0]
+        M = grid.neumann_matrix(sd.glob, sd.boundary_dist <= width, sd.dirichlet_ovlp)
+        return sp.csr_matrix(M)[ring][:, ring].tocsr(), ring
+
+    (R1, ring1), (R2, ring2) = ring_of(2 * overlap + 1), ring_of(2 * overlap)
+    _dump_csr(tmp_path, "N", sd.A_neu)
+    _dump_csr(tmp_path, "D", sd.A_dir)
+    _dump_csr(tmp_path, "R1", R1)
+    _dump_csr(tmp_path, "R2", R2)
+    sd.pou.astype(np.float64).tofile(tmp_path / "pou.bin")
+    np.asarray(sd.dirichlet_ovlp, dtype=np.float64).tofile(tmp_path / "dirichlet.bin")
+    sd.boundary.astype(np.float64).tofile(tmp_path / "boundary.bin")
+    ring1.astype(np.int64).tofile(tmp_path / "ring1.bin")
+    ring2.astype(np.int64).tofile(tmp_path / "ring2.bin")
+    nb = int(sd.boundary.sum())
+    bdata = np.array([np.ones(nb), np.sin(np.arange(nb))])
+    bdata.tofile(tmp_path / "bdata.bin")
+    p = subprocess.run([exe, str(tmp_path), str(nev), str(overlap)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert f"sizes {nev} {nev} {nev} {nev} 2" in p.stdout and "errors_caught 2" in p.stdout
+
+    def lam_of(name):
+        return np.array([float(ln.split()[2]) for ln in p.stdout.splitlines() if ln.startswith("lambda " + name + " ")])
+
+    def span_ok(name, vecs, lam, k=nev):
+        Bd = np.fromfile(tmp_path / (name + ".bin"), dtype=np.float64).reshape(k, sd.n)
+        assert np.abs(np.linalg.norm(Bd, axis=1) - 1.0).max() < 1e-12
+        Q, _ = np.linalg.qr(Bd.T)
+        below = [v / np.linalg.norm(v) for v, l in zip(vecs, lam) if l < lam[-1] * (1 - 1e-3)]
+        assert len(below) >= k - 2
+        for u in below:
+            assert np.linalg.norm(u - Q @ (Q.T @ u)) < 2e-3, name
+
+    vecs, lam = co.msgfem_basis(sd.A_neu, sd.A_dir, sd.pou, sd.dirichlet_ovlp, sd.boundary, {"nev": nev})
+    assert np.allclose(lam_of("msgfem"), lam, rtol=1e-6)
+    span_ok("msgfem", vecs, lam)
+    vecs, lam = go.geneo_basis(sd.A_neu, sd.A_neu, sd.pou, {"nev": nev})
+    span_ok("constraint_geneo", vecs, lam)
+    vecs, lam = co.geneo_ring_basis(sd.A_dir, R1, sd.pou, ring1, {"nev": nev})
+    assert np.allclose(lam_of("geneo_ring"), lam, rtol=1e-6)
+    span_ok("geneo_ring", vecs, lam)
+    vecs, lam = co.msgfem_ring_basis(sd.A_dir, R2, overlap, sd.pou, 0, sd.dirichlet_ovlp, sd.boundary, ring2, {"nev": nev})
+    assert np.allclose(lam_of("msgfem_ring"), lam, rtol=1e-6)
+    span_ok("msgfem_ring", vecs, lam)
+    ref = np.array(co.harmonic_extension_basis(sd.A_dir, sd.pou, list(bdata), sd.boundary))
+    got = np.fromfile(tmp_path / "harmonic.bin", dtype=np.float64).reshape(2, sd.n)
+    assert np.abs(got - ref).max() < 1e-10
