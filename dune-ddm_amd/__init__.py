@@ -121,6 +121,7 @@ SYMBOLS = {
     "ddm_geneo_params_default": (_I32, [ctypes.POINTER(GeneoParams)]),
     "ddm_geneo_basis": (_I32, [_P, _P, _P, _I64, _P, _P, _P, ctypes.POINTER(GeneoParams), _I64, _P, _P, _P, ctypes.POINTER(GeneoInfo)]),
     "ddm_msgfem_basis": (_I32, [_P, _P, _P, _I64, _P, _P, _P, _P, ctypes.POINTER(GeneoParams), _I64, _P, _P, _P, ctypes.POINTER(GeneoInfo)]),
+    "ddm_svd_basis": (_I32, [_P, _P, _I64, _P, _P, _P, _P, _I32, _I32, _D, _I32, _P, _P, ctypes.POINTER(GeneoInfo)]),
     "ddm_harmonic_create": (_I32, [_P, _P, _I64, _P, _I64, _P, _I64, _P, _PP]),
     "ddm_harmonic_destroy": (None, [_P]),
     "ddm_harmonic_extend": (_I32, [_P, _P, _I32, _P, _I64]),

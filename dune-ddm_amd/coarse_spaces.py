@@ -9,6 +9,7 @@ eigenvectors go) and the final ``v <- D v / ||D v||`` on the assembled vectors.
   geneo_ring_basis          GenEORingCoarseSpace           :502-648
   msgfem_ring_basis         MsGFEMRingCoarseSpace          :913-1163
   harmonic_extension_basis  HarmonicExtensionCoarseSpace   :1232-1266
+  svd_basis                 SVDCoarseSpace                 :1268-1407
   pou_basis                 POUCoarseSpace                 :1175-1231
 
 All return {local subdomain id: (k, n_s) ndarray}, the argument of ``TwoLevelSchwarz.set_coarse_basis``.
@@ -219,3 +220,27 @@ def harmonic_extension_basis(tl, boundary_data):
         ints.append(np.nonzero(~sd.boundary)[0])
         bnds.append(b)
     return _extend_and_finalize(tl, vecs, rings, ints, bnds)
+
+
+def svd_basis(tl, n_vectors=10, mult_pou=False, tol=1e-8, maxit=400, return_info=False, require_convergence=True):
+    """SVDCoarseSpace(A_ovlp, pou, subdomain_boundary_mask, dirichlet_boundary_mask, ptree) (coarse_spaces.hh:1268-1407; keys
+    `svd_coarse_space.n` and `.mult_pou`): the leading left singular vectors of T = D A_ii^-1 A_{i,Gamma} (ddm_svd_basis)."""
+    rl, ctx = tl.rl, tl.ctx
+    for sd in rl.subs:
+        _need(sd, "boundary", "pou")
+    bp = _np(rl.block_ptr, np.int64)
+    nsub = len(rl.subs)
+    basis = np.empty((n_vectors, rl.n), dtype=np.float64)
+    sv = np.zeros((nsub, n_vectors), dtype=np.float64)
+    info_c = GeneoInfo()
+    dA = CsrMatrix(ctx, rl.A_dir)
+    pou, dm = _np(rl.pou, np.float64), _np(rl.dirichlet_ovlp, np.uint8)
+    bm = _np(np.concatenate([sd.boundary for sd in rl.subs]), np.uint8)
+    ctx.check(ctx.lib.ddm_svd_basis(ctx.h, dA.h, nsub, _hp(bp), _hp(pou), _hp(dm), _hp(bm), int(n_vectors), int(bool(mult_pou)), float(tol), int(maxit),
+                                    _hp(basis), _hp(sv), ctypes.byref(info_c)))
+    info = {"iterations": int(info_c.iterations), "converged": bool(info_c.converged), "worst_residual": float(info_c.worst_residual),
+            "singular_values": {sd.id: sv[i].copy() for i, sd in enumerate(rl.subs)}}
+    if require_convergence and not info["converged"]:
+        raise RuntimeError(f"svd coarse space: eigensolver did not converge in {info['iterations']} block iterations (worst residual {info['worst_residual']:.3e})")
+    out = {sd.id: np.ascontiguousarray(basis[:, int(bp[i]):int(bp[i + 1])]) for i, sd in enumerate(rl.subs)}
+    return (out, info) if return_info else out

@@ -24,6 +24,8 @@
 // A~-norm, sqrt(r^T A~^-1 r) / mu  (r = C~ x - mu A~ x, x^T A~ x = 1) -- the quantity Spectra bounds by tol for its B-norm
 // Lanczos residual (HermEigsBase.h:158-175); with ILU(0) the Euclidean relative residual ||r|| / (mu ||A~ x||).
 #pragma once
+#include <functional>
+
 #include "dense_host.hpp"
 #include "geneo_kernels.hpp"
 
@@ -364,7 +366,8 @@ extern "C" int ddm_harmonic_extend(ddm_ctx *ctx, ddm_harmonic *H, int nrhs, doub
 
 static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, int64_t nsub, const int64_t *sub_ptr, const double *pou_host,
                      const uint8_t *dirichlet_host, const ddm_geneo_params &P, int nev, double *basis_dev /* nev x n */, double *eig_host /* nsub x nev */,
-                     ddm_geneo_info *info, ddm_harmonic *con = nullptr /* iterate in the a-harmonic subspace */, const double *pou_pencil_host = nullptr)
+                     ddm_geneo_info *info, ddm_harmonic *con = nullptr /* iterate in the a-harmonic subspace */, const double *pou_pencil_host = nullptr,
+                     const std::function<int(int, const double *, int64_t, double *, int64_t)> *op_C = nullptr /* replaces the product with C~ */)
 {
   const int64_t n = A_neu->nrows;
   const int m = nev + std::max(P.extra, 1);
@@ -392,6 +395,9 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
   DDMCHECK(ddm_csr_create(ctx, n, n, rpT.data(), ciT.data(), vaT.data(), &own.At));
   DDMCHECK(ddm_csr_create(ctx, n, n, rpT.data(), ciT.data(), vaC.data(), &own.C));
   { std::vector<double>().swap(vaT); std::vector<double>().swap(vaC); }
+  auto apply_C = [&](int mm, const double *X, int64_t ldx, double *Y, int64_t ldy) -> int {
+    return op_C ? (*op_C)(mm, X, ldx, Y, ldy) : csr_mm_ld(ctx, own.C, mm, X, ldx, Y, ldy);
+  };
   // ---- preconditioner ----
   int direct = 0;
   if (P.preconditioner != 1) {
@@ -458,7 +464,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
   hipLaunchKernelGGL(k_geneo_random, dim3(gnm), dim3(256), 0, ctx->stream, n, m, ld, 0x5DEECE66Dull + (unsigned long long)P.seed, maskd, S[0]);
   if (con) DDMCHECK(harmonic_apply(ctx, con, m, S[0], ld, true));
   DDMCHECK(csr_mm_ld(ctx, own.At, m, S[0], ld, AS[0], ld));
-  DDMCHECK(csr_mm_ld(ctx, own.C, m, S[0], ld, CS[0], ld));
+  DDMCHECK(apply_C(m, S[0], ld, CS[0], ld));
   int cur = 0, it = 0, converged = 0, rank_min = p;
   double worst = 0.0;
   const double tau = 1e-11;
@@ -494,7 +500,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
       hipLaunchKernelGGL(k_geneo_invsqrt_diag, dim3((unsigned)((nsub * m + 255) / 256)), dim3(256), 0, ctx->stream, (int)nsub, m, gmm[3], svec[1]);
       hipLaunchKernelGGL(k_geneo_colscale, dim3(gnm), dim3(256), 0, ctx->stream, n, m, W.sub_of_row, svec[1], Wb, ld);
       hipLaunchKernelGGL(k_geneo_colscale, dim3(gnm), dim3(256), 0, ctx->stream, n, m, W.sub_of_row, svec[1], AWb, ld);
-      DDMCHECK(csr_mm_ld(ctx, own.C, m, Wb, ld, CWb, ld));
+      DDMCHECK(apply_C(m, Wb, ld, CWb, ld));
       // A~-normalise the columns of P (zero columns stay zero)
       double *Pb = S[cur] + 2 * m, *APb = AS[cur] + 2 * m, *CPb = CS[cur] + 2 * m;
       DDMCHECK(W.gram(Pb, ld, m, APb, ld, m, gmm[3]));
@@ -575,7 +581,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
     if (it > 0 && it % 8 == 0) { // refresh A~X, C X from X: the recursions drift
       if (con) DDMCHECK(harmonic_apply(ctx, con, m, S[cur], ld, true));
       DDMCHECK(csr_mm_ld(ctx, own.At, m, S[cur], ld, AS[cur], ld));
-      DDMCHECK(csr_mm_ld(ctx, own.C, m, S[cur], ld, CS[cur], ld));
+      DDMCHECK(apply_C(m, S[cur], ld, CS[cur], ld));
     }
   }
   const double t_loop = since(t_iter);
@@ -605,7 +611,8 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
 
 static int geneo_basis_impl(ddm_ctx *ctx, const char *who, const ddm_csr *A_neu, const ddm_csr *B_neu, int64_t nsub, const int64_t *sub_ptr, const double *pou_host,
                             const uint8_t *dirichlet_host, const ddm_geneo_params *params, int64_t kmax, double *basis_host, int32_t *nconv,
-                            double *eigenvalues_host, ddm_geneo_info *info, ddm_harmonic *con, const double *pou_pencil_host)
+                            double *eigenvalues_host, ddm_geneo_info *info, ddm_harmonic *con, const double *pou_pencil_host,
+                            const std::function<int(int, const double *, int64_t, double *, int64_t)> *op_C = nullptr)
 {
   if (!ctx || !A_neu || !B_neu || !sub_ptr || !pou_host || !params || !basis_host || !nconv || !eigenvalues_host || nsub < 1)
     return fail(ctx, DDM_EINVAL, "%s: bad arguments", who);
@@ -623,7 +630,7 @@ static int geneo_basis_impl(ddm_ctx *ctx, const char *who, const ddm_csr *A_neu,
     double *basis_dev = nullptr;
     HIPCHECK(ctx, hipMalloc((void **)&basis_dev, sizeof(double) * (size_t)nev * (size_t)std::max<int64_t>(n, 1)));
     std::vector<double> eig((size_t)nsub * nev);
-    int rc = geneo_run(ctx, A_neu, B_neu, nsub, sub_ptr, pou_host, dirichlet_host, P, nev, basis_dev, eig.data(), info, con, pou_pencil_host);
+    int rc = geneo_run(ctx, A_neu, B_neu, nsub, sub_ptr, pou_host, dirichlet_host, P, nev, basis_dev, eig.data(), info, con, pou_pencil_host, op_C);
     if (!rc && hipMemcpy(basis_host, basis_dev, sizeof(double) * (size_t)nev * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, DDM_EHIP, "%s: basis download failed", who);
     (void)hipFree(basis_dev);
     if (rc) return rc;
@@ -688,6 +695,75 @@ extern "C" int ddm_msgfem_basis(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_cs
                           pou_int.data());
   ddm_harmonic_destroy(H);
   return rc;
+}
+
+// SVDCoarseSpace (coarse_spaces.hh:1268-1407): the leading left singular vectors of T = D A_ii^-1 A_{i,Gamma} (interior x subdomain
+// boundary; the reference forms T densely column by column and calls Eigen's bdcSvd).  Here: the leading eigenvectors of
+//     T T^T = D A_ii^-1 (A_{i,Gamma} A_{i,Gamma}^T) A_ii^-T D
+// by the block eigensolver of geneo_run with the identity as left-hand matrix and T T^T applied as an operator -- two multi-RHS
+// interior solves (the sparse direct factor of ddm_harmonic) around two sparse products per application; T is never formed.
+extern "C" int ddm_svd_basis(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t nsub, const int64_t *sub_ptr, const double *pou_host, const uint8_t *dirichlet_host,
+                             const uint8_t *boundary_host, int n_vectors, int mult_pou, double tolerance, int maxit, double *basis_host, double *singular_values_host,
+                             ddm_geneo_info *info)
+{
+  if (!ctx || !A_dir || !sub_ptr || !pou_host || !boundary_host || !basis_host || !singular_values_host || nsub < 1 || n_vectors < 1)
+    return fail(ctx, DDM_EINVAL, "ddm_svd_basis: bad arguments");
+  if (A_dir->nrows != A_dir->ncols || sub_ptr[0] != 0 || sub_ptr[nsub] != A_dir->nrows) return fail(ctx, DDM_EINVAL, "ddm_svd_basis: sub_ptr does not cover the matrix");
+  const int64_t n = A_dir->nrows;
+  std::vector<uint8_t> cls((size_t)n), notint((size_t)n);
+  std::vector<double> pou_int((size_t)n), ones((size_t)n, 1.0);
+  for (int64_t i = 0; i < n; ++i) { // :1293-1309
+    cls[(size_t)i] = (dirichlet_host && dirichlet_host[i]) ? 2 : boundary_host[i] ? 1 : 0;
+    notint[(size_t)i] = cls[(size_t)i] != 0;
+    pou_int[(size_t)i] = cls[(size_t)i] == 0 ? pou_host[i] : 0.0;
+  }
+  ddm_harmonic *H = nullptr;
+  DDMCHECK(harmonic_create_impl(ctx, A_dir, nsub, sub_ptr, cls.data(), true, &H));
+  struct Guard {
+    ddm_harmonic *H;
+    ddm_csr *I = nullptr;
+    double *d = nullptr;
+    ~Guard()
+    {
+      ddm_harmonic_destroy(H);
+      ddm_csr_destroy(I);
+      (void)hipFree(d);
+    }
+  } g{H};
+  if (!H->symmetric) return fail(ctx, DDM_ENOTIMPL, "ddm_svd_basis: the interior block of A_dir is not symmetric");
+  std::vector<int64_t> rp((size_t)n + 1);
+  std::vector<int32_t> ci((size_t)n);
+  for (int64_t i = 0; i <= n; ++i) rp[(size_t)i] = i;
+  for (int64_t i = 0; i < n; ++i) ci[(size_t)i] = (int32_t)i;
+  DDMCHECK(ddm_csr_create(ctx, n, n, rp.data(), ci.data(), ones.data(), &g.I));
+  DDMCHECK(upload(ctx, pou_int.data(), n, &g.d));
+  const std::function<int(int, const double *, int64_t, double *, int64_t)> op = [&](int m, const double *X, int64_t ldx, double *Y, int64_t ldy) -> int {
+    DDMCHECK(harmonic_reserve(ctx, H, m));
+    const unsigned gr = (unsigned)((n * (int64_t)m + 255) / 256);
+    hipLaunchKernelGGL(k_geneo_rowscale_to, dim3(gr), dim3(256), 0, ctx->stream, n, m, (const double *)g.d, X, ldx, H->t1, (int64_t)m); // D x
+    DDMCHECK(ilu0_solve_multi_ld(ctx, H->F, m, H->t1, m, H->t2, m));                                                                 // A_ii^-T
+    DDMCHECK(csr_mm_ld(ctx, H->Gbi, m, H->t2, m, H->t1, m));                                                                         // A_{i,Gamma}^T
+    DDMCHECK(csr_mm_ld(ctx, H->Gib, m, H->t1, m, H->t2, m));                                                                         // A_{i,Gamma}
+    DDMCHECK(ilu0_solve_multi_ld(ctx, H->F, m, H->t2, m, H->t1, m));                                                                 // A_ii^-1
+    hipLaunchKernelGGL(k_geneo_rowscale_to, dim3(gr), dim3(256), 0, ctx->stream, n, m, (const double *)g.d, (const double *)H->t1, (int64_t)m, Y, ldy); // D
+    HIPCHECK(ctx, hipGetLastError());
+    return DDM_OK;
+  };
+  ddm_geneo_params P;
+  ddm_geneo_params_default(&P);
+  P.nev = n_vectors;
+  P.extra = std::max(4, n_vectors / 2);
+  P.shift = 0.0;            // A~ = I
+  P.tolerance = tolerance > 0.0 ? tolerance : 1e-8;
+  P.maxit = maxit > 0 ? maxit : 400;
+  P.preconditioner = 1;     // ILU(0) of the identity: no preconditioner
+  P.raw = mult_pou ? 0 : 1; // :1403: finalize_eigenvectors only with mult_pou
+  std::vector<int32_t> nconv((size_t)nsub);
+  std::vector<double> eig((size_t)nsub * n_vectors);
+  DDMCHECK(geneo_basis_impl(ctx, "ddm_svd_basis", g.I, g.I, nsub, sub_ptr, pou_host, notint.data(), &P, n_vectors, basis_host, nconv.data(), eig.data(), info, nullptr,
+                            ones.data(), &op));
+  for (size_t k = 0; k < eig.size(); ++k) singular_values_host[k] = 1.0 / std::sqrt(std::max(eig[k], 1e-300)); // mu = sigma^2 = 1 / lambda
+  return DDM_OK;
 }
 
 // ---- the two dense block kernels on their own (parity tests against an FP64 host reference; also usable by callers that keep

@@ -548,3 +548,52 @@ public:
     ddm_hip::finalize_eigenvectors(this->basis_, pou);
   }
 };
+
+// SVDCoarseSpace (coarse_spaces.hh:1268-1407): the `n` leading left singular vectors of T = D A_ii^-1 A_{i,Gamma} (keys `<prefix>.n`,
+// `<prefix>.mult_pou`).  Device: ddm_svd_basis (T is never formed).  The reference also writes the singular values to
+// singular_values_<rank>.txt and logs them; here they are available from singular_values().
+template <class Vec = Dune::BlockVector<Dune::FieldVector<double, 1>>>
+class SVDCoarseSpace : public CoarseSpaceBuilder<Vec> {
+public:
+#if DUNE_DDM_HAVE_TASKFLOW
+  template <class Mat, class MaskVec, class MaskVec2>
+  SVDCoarseSpace(std::shared_ptr<Mat> A_ovlp, std::shared_ptr<PartitionOfUnity> pou, const MaskVec& subdomain_boundary_mask, const MaskVec2& dirichlet_boundary_mask, const Dune::ParameterTree& ptree,
+                 tf::Taskflow& taskflow, const std::string& ptree_prefix = "svd_coarse_space")
+  {
+    const int n = ptree.sub(ptree_prefix).get("n", 10);
+    const bool mult_pou = ptree.sub(ptree_prefix).get("mult_pou", false);
+    // masks by value, as the reference captures them (:1278)
+    this->setup_task = taskflow.emplace([subdomain_boundary_mask, dirichlet_boundary_mask, A_ovlp, pou, n, mult_pou, this]() { setup(*A_ovlp, *pou, subdomain_boundary_mask, dirichlet_boundary_mask, n, mult_pou); });
+  }
+#endif
+  SVDCoarseSpace() = default;
+  const std::vector<double>& singular_values() const { return singular_values_; }
+
+  template <class Mat, class MaskVec, class MaskVec2>
+  void setup(const Mat& A_ovlp, const PartitionOfUnity& pou, const MaskVec& subdomain_boundary_mask, const MaskVec2& dirichlet_boundary_mask, int n_vectors, bool mult_pou)
+  {
+    auto ctx = ddm_hip::Context::get();
+    const std::size_t n = A_ovlp.N();
+    std::vector<double> w(n);
+    std::vector<std::uint8_t> dir(n), bnd(n);
+    for (std::size_t i = 0; i < n; ++i) {
+      w[i] = pou[i];
+      dir[i] = dirichlet_boundary_mask[i] > 0 ? 1 : 0;
+      bnd[i] = subdomain_boundary_mask[i] ? 1 : 0;
+    }
+    ddm_hip::DeviceCsr dA(ctx, A_ovlp);
+    const int64_t sub_ptr[2] = {0, (int64_t)n};
+    std::vector<double> basis((std::size_t)n_vectors * n);
+    singular_values_.assign(n_vectors, 0.0);
+    ddm_geneo_info info{};
+    ddm_hip::check(ctx->handle(), ddm_svd_basis(ctx->handle(), dA.handle(), 1, sub_ptr, w.data(), dir.data(), bnd.data(), n_vectors, mult_pou ? 1 : 0, 0.0, 0, basis.data(), singular_values_.data(), &info),
+                   "ddm_svd_basis");
+    if (!info.converged) DUNE_THROW(Dune::Exception, "SVD coarse space: eigensolver did not converge in " << info.iterations << " block iterations");
+    this->basis_.assign(n_vectors, Vec(n));
+    for (int j = 0; j < n_vectors; ++j)
+      for (std::size_t i = 0; i < n; ++i) this->basis_[j][i] = basis[(std::size_t)j * n + i];
+  }
+
+private:
+  std::vector<double> singular_values_;
+};

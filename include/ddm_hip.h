@@ -261,6 +261,13 @@ int ddm_geneo_basis(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, in
 int ddm_msgfem_basis(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *A_dir, int64_t nsub, const int64_t *sub_ptr, const double *pou_host,
                      const uint8_t *dirichlet_host, const uint8_t *boundary_host, const ddm_geneo_params *params, int64_t kmax, double *basis_host,
                      int32_t *nconv, double *eigenvalues_host, ddm_geneo_info *info);
+/* SVDCoarseSpace(A_ovlp, pou, subdomain_boundary_mask, dirichlet_boundary_mask, ptree, taskflow, prefix = "svd_coarse_space")
+ * (coarse_spaces.hh:1268-1407): the n_vectors leading left singular vectors of T = D A_ii^-1 A_{i,Gamma}, zero outside the interior
+ * DoFs; with mult_pou != 0 followed by finalize_eigenvectors (:1403).  basis_host: n_vectors x n row-major;
+ * singular_values_host: nsub x n_vectors, descending.  T is never formed (csrc/geneo.hpp). */
+int ddm_svd_basis(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t nsub, const int64_t *sub_ptr, const double *pou_host, const uint8_t *dirichlet_host,
+                  const uint8_t *boundary_host, int n_vectors, int mult_pou, double tolerance, int maxit, double *basis_host, double *singular_values_host,
+                  ddm_geneo_info *info);
 /* EnergyMinimalExtension(A, interior_indices, boundary_indices) (coarsespaces/energy_minimal_extension.hh:36-229), the building
  * block of the ring and harmonic-extension coarse spaces (coarse_spaces.hh:598, 1097, 1250): u_i = -A_ii^-1 (A [0; u_b])_i.
  * A may be block diagonal (block_ptr[nblocks+1]: one sparse direct factor per block; Cholesky if the interior block is symmetric,

@@ -80,9 +80,13 @@ int main(int argc, char** argv)
     for (std::size_t k = 0; k < boundary_data->size(); ++k)
       for (std::size_t j = 0; j < nb; ++j) (*boundary_data)[k][j] = bd[k * nb + j];
     auto hext = std::make_unique<HarmonicExtensionCoarseSpace<Vec>>(std::const_pointer_cast<Mat>(A_dir), std::const_pointer_cast<PartitionOfUnity>(pou), boundary_data, boundary_mask, taskflow);
+    ptree.sub("svd_coarse_space")["n"] = "5";
+    auto svd = std::make_unique<SVDCoarseSpace<Vec>>(std::const_pointer_cast<Mat>(A_dir), std::const_pointer_cast<PartitionOfUnity>(pou), boundary_mask, dirichlet_mask, ptree, taskflow);
     tf::Executor executor(1);
     executor.run(taskflow).get();
-    std::printf("sizes %zu %zu %zu %zu %zu\n", msgfem->size(), cgeneo->size(), gring->size(), mring->size(), hext->size());
+    std::printf("sizes %zu %zu %zu %zu %zu %zu\n", msgfem->size(), cgeneo->size(), gring->size(), mring->size(), hext->size(), svd->size());
+    for (double l : svd->singular_values()) std::printf("lambda svd %.17g\n", l);
+    dump(dir + "/svd.bin", svd->get_basis());
     for (double l : msgfem->eigenvalues()) std::printf("lambda msgfem %.17g\n", l);
     for (double l : gring->eigenvalues()) std::printf("lambda geneo_ring %.17g\n", l);
     for (double l : mring->eigenvalues()) std::printf("lambda msgfem_ring %.17g\n", l);

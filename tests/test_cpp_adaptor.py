@@ -160,7 +160,7 @@ def test_remaining_coarse_space_adaptors_match_oracle(ddm, tmp_path):
     bdata.tofile(tmp_path / "bdata.bin")
     p = subprocess.run([exe, str(tmp_path), str(nev), str(overlap)], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    assert f"sizes {nev} {nev} {nev} {nev} 2" in p.stdout and "errors_caught 2" in p.stdout
+    assert f"sizes {nev} {nev} {nev} {nev} 2 5" in p.stdout and "errors_caught 2" in p.stdout
 
     def lam_of(name):
         return np.array([float(ln.split()[2]) for ln in p.stdout.splitlines() if ln.startswith("lambda " + name + " ")])
@@ -185,6 +185,13 @@ def test_remaining_coarse_space_adaptors_match_oracle(ddm, tmp_path):
     vecs, lam = co.msgfem_ring_basis(sd.A_dir, R2, overlap, sd.pou, 0, sd.dirichlet_ovlp, sd.boundary, ring2, {"nev": nev})
     assert np.allclose(lam_of("msgfem_ring"), lam, rtol=1e-6)
     span_ok("msgfem_ring", vecs, lam)
+    vecs, sv = co.svd_basis(sd.A_dir, sd.pou, sd.boundary, sd.dirichlet_ovlp, n_vectors=5)
+    assert np.allclose(lam_of("svd"), sv[:5], rtol=1e-6)
+    Bd = np.fromfile(tmp_path / "svd.bin", dtype=np.float64).reshape(5, sd.n)
+    Q, _ = np.linalg.qr(Bd.T)
+    for u, s_ in zip(vecs, sv[:5]):
+        if s_ > sv[4] * (1 + 1e-3):
+            assert np.linalg.norm(u - Q @ (Q.T @ u)) < 2e-3
     ref = np.array(co.harmonic_extension_basis(sd.A_dir, sd.pou, list(bdata), sd.boundary))
     got = np.fromfile(tmp_path / "harmonic.bin", dtype=np.float64).reshape(2, sd.n)
     assert np.abs(got - ref).max() < 1e-10

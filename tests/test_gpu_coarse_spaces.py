@@ -158,3 +158,32 @@ def test_harmonic_extension_and_pou_spaces(ddm):
     b = geneo_basis(tl, nev=3, seed=0)
     assert all(np.array_equal(a[s], b[s]) for s in a)
     tl.ctx.close()
+
+
+@pytest.mark.parametrize("mult_pou", [False, True])
+def test_svd_coarse_space_matches_oracle(ddm, mult_pou):
+    """ddm_svd_basis (operator form of T T^T, block eigensolver) against the oracle's dense SVD of T: singular values 1e-6 relative,
+    the leading left singular vectors inside the device span (sine < 2e-3; T's singular values of a box come in near-degenerate
+    groups, so only vectors strictly above the cut are compared)."""
+    from dune_ddm_amd import synth
+    from dune_ddm_amd.coarse_spaces import svd_basis
+    from dune_ddm_amd.problem import build_structured
+    from dune_ddm_amd.solver import TwoLevelSchwarz
+    from oracle import coarse_oracle as co
+    k = 6
+    dec = build_structured(synth.StructuredPoisson((17, 15, 13), (2, 2, 1)), overlap=2, pou_type="distance", neumann=True)
+    tl = TwoLevelSchwarz(dec, coarse="none")
+    basis, info = svd_basis(tl, n_vectors=k, mult_pou=mult_pou, return_info=True)
+    assert info["converged"]
+    for sd in tl.rl.subs:
+        vecs, s = co.svd_basis(sd.A_dir, sd.pou, sd.boundary, sd.dirichlet_ovlp, n_vectors=k, mult_pou=mult_pou)
+        assert np.allclose(info["singular_values"][sd.id], s[:k], rtol=1e-6), (info["singular_values"][sd.id], s[:k])
+        assert np.abs(np.linalg.norm(basis[sd.id], axis=1) - 1.0).max() < 1e-12
+        Q = _orth(basis[sd.id])
+        above = [np.asarray(v) / np.linalg.norm(v) for v, sv in zip(vecs, s[:k]) if sv > s[k - 1] * (1 + 1e-3)]
+        assert len(above) >= k - 3
+        for u in above:
+            assert np.linalg.norm(u - Q @ (Q.T @ u)) < 2e-3
+        outside = sd.boundary | (np.asarray(sd.dirichlet_ovlp) > 0)
+        assert np.all(basis[sd.id][:, outside] == 0)
+    tl.ctx.close()
