@@ -201,3 +201,46 @@ class RankLocal:
 
     def neumann_matrices(self):
         return _block_diag([sd.A_neu for sd in self.subs]), _block_diag([sd.B_neu for sd in self.subs])
+
+
+def build_distributed(ex, sub, nranks, overlap=2, pou_type="distance", shrink=0, nglobal=None) -> Decomposition:
+    """The same L3 setup run by ONE rank on its own non-overlapping data ``sub`` (synth.NovlpSubdomain) with neighbour exchanges only
+    (setup_dist.DistSetup over ``ex``: torch.distributed / threads) -- no global knowledge of the other subdomains.  Returns a
+    Decomposition whose ``subs`` list holds this rank's entry only (None elsewhere) and whose interface dictionaries hold the local
+    halves of the index lists, which is all ``RankLocal(dec, rank, nranks)`` reads when every rank owns one subdomain.
+    (The Neumann matrices of the GenEO-type coarse spaces come from the application's assembler, as in the reference:
+    examples/pdelab_helper.hh:113-436.)"""
+    from . import setup_dist as sdist
+    ds = sdist.DistSetup(ex, sub)
+    r = ex.rank
+    ifc0 = ds.interfaces()
+    novlp_all = {}
+    for q, l in ifc0["all_to_all"].items():
+        novlp_all[(r, q)] = (l, None)
+        novlp_all[(q, r)] = (None, l)
+    idx = ds.make_overlapping_communication(overlap)
+    A_dir, dm = ds.overlapping_matrix()
+    pou, bmask, dist = ds.partition_of_unity(A_dir, pou_type, shrink)
+    ifc = ds.interfaces()
+    ovlp_all, ovlp_owner = {}, {}
+    for q, l in ifc["all_to_all"].items():
+        ovlp_all[(r, q)] = (l, None)
+        ovlp_all[(q, r)] = (None, l)
+        if len(ifc["owner_send"][q]):
+            ovlp_owner[(r, q)] = (ifc["owner_send"][q], None)
+        if len(ifc["owner_recv"][q]):
+            ovlp_owner[(q, r)] = (None, ifc["owner_recv"][q])
+    sd = SubdomainData(r, idx.n_o, len(idx.glob), idx.glob, sub.A, sub.owner, sub.b, A_dir, idx.owner, dm, pou)
+    if bmask is not None:
+        sd.boundary = np.asarray(bmask, dtype=bool)
+    sd.boundary_dist = dist
+    subs = [None] * nranks
+    subs[r] = sd
+    # the Galerkin assembly exchanges basis vectors one neighbour slot at a time (galerkin_preconditioner.hh:298-309): the sender
+    # must know its position in the RECEIVER's sorted neighbour list
+    got = ex.sparse({q: np.asarray(ds.neighbours, dtype=np.int64) for q in ds.neighbours})
+    slots = {q: {r: int(np.nonzero(got[q] == r)[0][0])} for q in ds.neighbours}
+    slots[r] = {a: i for i, a in enumerate(ds.neighbours)}
+    return Decomposition(subs, novlp_all, ovlp_owner, ovlp_all, overlap, nglobal if nglobal is not None else -1,
+                         {"pou_type": pou_type, "shrink": shrink, "ext_boundary": {r: idx.ext_boundary}, "boundary": {r: bmask}, "distributed": True,
+                          "_nbr_slots": slots})

@@ -86,6 +86,38 @@ def main():
         return
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
+    if mode == "distsetup":
+        # every process holds ONE subdomain's non-overlapping data and runs the distributed setup over gloo; the
+        # result is compared (on every rank, for its own subdomain) with the global-knowledge product path
+        from dune_ddm_amd import setup_dist as sdist
+        from dune_ddm_amd import setup_host as sh
+        import scipy.sparse as sp
+        P = {2: (2, 1, 1), 4: (2, 2, 1)}[world]
+        grid = synth.StructuredPoisson((11, 10, 9), P)
+        nov = grid.subdomains()
+        overlap = 2
+        ds = sdist.DistSetup(sdist.TorchExchange(), nov[rank])
+        idx = ds.make_overlapping_communication(overlap)
+        A_dir, dm = ds.overlapping_matrix()
+        pou, bmask, _ = ds.partition_of_unity(A_dir, "distance", 0)
+        ifc = ds.interfaces()
+        ref = sh.make_overlapping_communication(nov, overlap, grid.nglobal)
+        pairs = sh.interface_pairs(ref, grid.nglobal, "all_to_all")
+        dmask = [grid.dirichlet_of(i.glob) for i in ref]
+        A_ref = [grid.dirichlet_matrix(i.glob, d) for i, d in zip(ref, dmask)]
+        pou_ref, bm_ref, _ = sh.partition_of_unity(ref, A_ref, pairs, grid.nglobal, "distance", 0, overlap)
+        ok = np.array_equal(idx.glob, ref[rank].glob) and np.array_equal(idx.owner, ref[rank].owner) and np.array_equal(idx.ext_boundary, ref[rank].ext_boundary)
+        ok = ok and np.array_equal(dm, dmask[rank]) and np.array_equal(bmask, bm_ref[rank]) and np.abs(pou - pou_ref[rank]).max() <= 1e-15
+        D = (A_dir - sp.csr_matrix(A_ref[rank])).tocsr()
+        ok = ok and (abs(D).max() if D.nnz else 0.0) <= 4e-16 * abs(A_ref[rank]).max()
+        for q in ds.neighbours:
+            ok = ok and np.array_equal(ifc["all_to_all"][q], pairs[(rank, q)][0])
+        flag = torch.tensor([1 if ok else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            print(("DISTSETUP_OK" if int(flag) else "DISTSETUP_FAIL") + f" {world}", flush=True)
+        dist.destroy_process_group()
+        return
     if mode == "plans":
         grid = synth.StructuredPoisson((11, 10, 9), (2, 2, 2))
         dec = build_structured(grid, overlap=2, pou_type="distance")
@@ -113,6 +145,28 @@ def main():
                     want = np.concatenate([ref[name][s] for s in local])
                     assert (r_[name] == want).all(), (name, local)
             print("PLANS_OK", world)
+    elif mode == "solve_dist":
+        # SURVEY 8f-1 end to end: each rank sets up ITS subdomain with neighbour exchanges only (problem.build_distributed over gloo),
+        # then the two-level CG solve through the C ABI; rank 0 checks the history against the oracle on the global-knowledge setup
+        from dune_ddm_amd import setup_dist as sdist
+        from dune_ddm_amd.problem import build_distributed
+        from dune_ddm_amd.solver import TorchComm, TwoLevelSchwarz
+        grid = synth.StructuredPoisson((15, 14, 13), {2: (2, 1, 1), 4: (2, 2, 1)}[world])
+        nov = grid.subdomains()
+        dec = build_distributed(sdist.TorchExchange(), nov[rank], world, overlap=2, pou_type="distance", nglobal=grid.nglobal)
+        comm = TorchComm()
+        tl = TwoLevelSchwarz(dec, rank, world, 0, comm, schwarz_type="standard", mode="additive", coarse="pou")
+        res, hist, x = tl.solve(reduction=1e-10, maxit=300)
+        if rank == 0:
+            from tests.oracle_bridge import oracle_solve
+            full = build_structured(grid, overlap=2, pou_type="distance")
+            it, conv, hist_o, xo = oracle_solve(full, reduction=1e-10, maxit=300, coarse="pou", schwarz_type="standard", mode="additive")
+            ho = np.array(hist_o)
+            assert res.iterations == it and res.converged and conv, (res.iterations, it)
+            assert (np.abs(hist - ho) <= 1e-8 * ho + 1e-14 * ho[0]).all()
+            assert np.max(np.abs(x.cpu().numpy() - xo[0])) <= 1e-8 * np.max(np.abs(xo[0]))
+            print("SOLVE_DIST_OK", world, it)
+        dist.barrier()
     elif mode == "solve":
         from dune_ddm_amd.solver import TorchComm, TwoLevelSchwarz
         grid = synth.StructuredPoisson((15, 14, 13), (2, 2, 2))

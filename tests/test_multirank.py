@@ -28,6 +28,14 @@ def test_two_rank_solve_shares_one_gpu():
 
 
 @pytest.mark.gpu
+def test_two_rank_solve_with_distributed_setup():
+    """SURVEY 8f-1 end to end: overlap extension, overlapping matrix, partition of unity and halo plans built rank by rank over gloo
+    (no global knowledge), then the device solve; history == oracle on the global-knowledge setup."""
+    p = _launch("solve_dist", 2, 29561)
+    assert p.returncode == 0 and "SOLVE_DIST_OK 2" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+@pytest.mark.gpu
 def test_rccl_exchange_self_test_on_one_gpu(ddm):
     """The in-library RCCL exchange (ddm_ctx_set_rccl: dlopen of librccl, ncclCommInitRank, grouped ncclSend / ncclRecv per halo,
     ncclAllReduce for dots and the coarse defect, all on the context's stream) exercised on ONE GPU: a communicator of size 1 in
