@@ -152,10 +152,11 @@ def load_library():
     """Loads libddm_hip.so (built by __graft_entry__.build()).  Fails loudly if it is missing."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("DDM_HIP_LIBRARY", LIB_PATH)   # (diagnostic: an experimental build of the same sources)
+        if not os.path.exists(path):
             raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(there is no CPU fallback for the HIP hot path)")
-        L = ctypes.CDLL(LIB_PATH)
+        L = ctypes.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)            # AttributeError if a declared symbol is not exported
             fn.restype = res

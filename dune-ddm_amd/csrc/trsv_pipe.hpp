@@ -30,10 +30,16 @@
 
 namespace ddm {
 
-constexpr int PIPE_NC = 1;          // compute waves per workgroup (steps of a task alternate between them)
+#ifndef DDM_PIPE_NC
+#define DDM_PIPE_NC 1
+#endif
+#ifndef DDM_PIPE_RING_KIB
+#define DDM_PIPE_RING_KIB 64
+#endif
+constexpr int PIPE_NC = DDM_PIPE_NC; // compute waves per workgroup (steps of a task alternate between them); experiments: -DDDM_PIPE_NC=2 -DDDM_PIPE_RING_KIB=112
 constexpr int PIPE_NL = 2;          // loader waves per workgroup
 constexpr int PIPE_DEPTH = 3;       // tiles a loader keeps in flight
-constexpr int PIPE_RING_KIB = 64;   // LDS byte ring of tiles per workgroup (two workgroups per CU).  2 NC tiles (the current and the
+constexpr int PIPE_RING_KIB = DDM_PIPE_RING_KIB; // LDS byte ring of tiles per workgroup (two workgroups per CU).  2 NC tiles (the current and the
                                     // prefetched step of every compute wave) + one in flight must fit, or loaders and compute waves
                                     // would wait for each other: 5 tiles of the widest row the builder accepts (pipe::MAX_W)
 constexpr int PIPE_STAMP_WORDS = 16 + 256; // stamped build: words per task (16 sums, then the time of every step's result store)
