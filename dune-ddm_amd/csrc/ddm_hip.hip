@@ -544,7 +544,7 @@ struct ddm_ilu0 {
   pipe::Group *p_groups = nullptr;
   pipe::Task *p_tasks = nullptr;
   unsigned char *p_stream = nullptr;
-  int32_t *p_koff = nullptr, *p_rowL = nullptr, *p_posU = nullptr;
+  int32_t *p_koff = nullptr, *p_rowL = nullptr, *p_posU = nullptr, *p_rowU = nullptr; // p_rowU: natural row of every U position (-1: padding)
   double *p_dperm = nullptr, *p_ypos = nullptr, *p_xpos = nullptr;
   unsigned long long *p_progress = nullptr;
   unsigned *p_queue = nullptr;
@@ -1281,6 +1281,7 @@ extern "C" void ddm_ilu0_destroy(ddm_ilu0 *F)
   (void)hipFree(F->p_koff);
   (void)hipFree(F->p_rowL);
   (void)hipFree(F->p_posU);
+  (void)hipFree(F->p_rowU);
   (void)hipFree(F->p_dperm);
   (void)hipFree(F->p_ypos);
   (void)hipFree(F->p_xpos);
@@ -1461,6 +1462,11 @@ static int build_pipe_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
   DDMCHECK(upload(ctx, S.koff.data(), (int64_t)S.koff.size(), &F->p_koff));
   DDMCHECK(upload(ctx, S.rowL.data(), (int64_t)S.rowL.size(), &F->p_rowL));
   DDMCHECK(upload(ctx, S.posU.data(), (int64_t)S.posU.size(), &F->p_posU));
+  {
+    std::vector<int32_t> rowU((size_t)std::max<int64_t>(S.nposU, 1), -1);
+    for (size_t i = 0; i < S.posU.size(); ++i) rowU[(size_t)S.posU[i]] = (int32_t)i;
+    DDMCHECK(upload(ctx, rowU.data(), (int64_t)rowU.size(), &F->p_rowU));
+  }
   HIPCHECK(ctx, hipMalloc((void **)&F->p_dperm, sizeof(double) * (size_t)std::max<int64_t>(S.nposL, 1)));
   HIPCHECK(ctx, hipMalloc((void **)&F->p_ypos, sizeof(double) * (size_t)std::max<int64_t>(S.nposL, 1)));
   HIPCHECK(ctx, hipMalloc((void **)&F->p_xpos, sizeof(double) * (size_t)std::max<int64_t>(S.nposU, 1)));
@@ -1497,6 +1503,7 @@ static int build_pipe_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
   return DDM_OK;
 }
 
+static unsigned perm_grid(ddm_ctx *ctx, int64_t npos) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>((npos + PERM_TILE - 1) / PERM_TILE, (int64_t)ctx->num_cu * 16)); }
 static void enqueue_pipe(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, unsigned long long *stamps, const double *scale = nullptr,
                          const double *add = nullptr)
 {
@@ -1516,10 +1523,10 @@ static void enqueue_pipe(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, 
   P.stamps = stamps;
   P.spread = F->p_spread;
   hipLaunchKernelGGL(k_pipe_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate, F->p_queue, F->ngroups * 4);
-  hipLaunchKernelGGL(k_pipe_permute_in, dim3(grid_for(F->p_nposL)), dim3(WG), 0, ctx->stream, F->p_nposL, F->p_rowL, d, F->p_dperm);
+  hipLaunchKernelGGL(k_pipe_permute_in, dim3(perm_grid(ctx, F->p_nposL)), dim3(PERM_WG), 0, ctx->stream, F->p_nposL, F->p_rowL, d, F->p_dperm);
   if (stamps) hipLaunchKernelGGL((k_trsv_pipe<true>), dim3(F->p_grid), dim3(64 * (PIPE_NC + PIPE_NL)), PIPE_LDS_BYTES, ctx->stream, P);
   else hipLaunchKernelGGL((k_trsv_pipe<false>), dim3(F->p_grid), dim3(64 * (PIPE_NC + PIPE_NL)), PIPE_LDS_BYTES, ctx->stream, P);
-  hipLaunchKernelGGL(k_pipe_permute_out, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, F->p_posU, F->p_xpos, x, scale, add);
+  hipLaunchKernelGGL(k_pipe_permute_out, dim3(perm_grid(ctx, F->p_nposU)), dim3(PERM_WG), 0, ctx->stream, F->p_nposU, F->p_rowU, (const double *)F->p_xpos, x, scale, add);
 }
 
 static int enqueue_tri(ddm_ctx *ctx, const TriSchedule &S, bool upper, const double *d, double *x)

@@ -201,24 +201,77 @@ __global__ void k_pipe_prologue(XcdState *st, unsigned *queue, int nwords)
     st->epoch += 1;
   }
 }
+// The two permutations between natural order and position order (position = task base + 64 * step + lane: lane = chain, on a
+// structured grid a grid line).  Read or written by position, the natural side touches 64 different cache lines per 64 positions
+// and uses 8 bytes of each (the next step's positions hit the same lines again: L2-request bound).  Both kernels therefore work
+// on tiles of 64 lanes x 16 steps and transpose through LDS: the position side is accessed in position order, the natural side
+// with the step index running fastest, i.e. 16 consecutive rows of a chain by 16 neighbouring threads (whole 128-byte segments
+// when a chain is a grid line; any other chain shape is merely not faster than before).
+constexpr int PERM_STEPS = 16, PERM_TILE = 64 * PERM_STEPS, PERM_WG = 256, PERM_PAD = 65;
 // dperm[pos] = d[row(pos)] (0 on padding positions)
-__global__ void k_pipe_permute_in(int64_t npos, const int32_t *__restrict__ rowL, const double *__restrict__ d, double *__restrict__ dperm)
+__global__ __launch_bounds__(PERM_WG) void k_pipe_permute_in(int64_t npos, const int32_t *__restrict__ rowL, const double *__restrict__ d, double *__restrict__ dperm)
 {
-  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < npos; p += (int64_t)gridDim.x * blockDim.x) {
-    const int32_t r = rowL[p];
-    dperm[p] = r >= 0 ? d[r] : 0.0;
+  __shared__ int32_t idx[PERM_STEPS * PERM_PAD];
+  __shared__ double val[PERM_STEPS * PERM_PAD];
+  const int64_t ntile = (npos + PERM_TILE - 1) / PERM_TILE;
+  for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int64_t p0 = tile * PERM_TILE;
+#pragma unroll
+    for (int q = 0; q < PERM_TILE / PERM_WG; ++q) {
+      const int e = q * PERM_WG + threadIdx.x; // position order: e = 64 * step + lane
+      const int64_t p = p0 + e;
+      idx[(e >> 6) * PERM_PAD + (e & 63)] = p < npos ? rowL[p] : -1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PERM_TILE / PERM_WG; ++q) {
+      const int e = q * PERM_WG + threadIdx.x; // chain order: e = 16 * lane + step
+      const int l = e / PERM_STEPS, st = e % PERM_STEPS;
+      const int32_t r = idx[st * PERM_PAD + l];
+      val[st * PERM_PAD + l] = r >= 0 ? d[r] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PERM_TILE / PERM_WG; ++q) {
+      const int e = q * PERM_WG + threadIdx.x;
+      const int64_t p = p0 + e;
+      if (p < npos) dperm[p] = val[(e >> 6) * PERM_PAD + (e & 63)];
+    }
+    __syncthreads();
   }
 }
-// x = P^T xpos, optionally followed by the Schwarz level's "x *= pou" and "x += coarse correction" (same operations in the same
-// order as the separate kernels, so the result is bit-identical; saves their passes over the overlapping vector)
-__global__ void k_pipe_permute_out(int64_t n, const int32_t *__restrict__ posU, const double *__restrict__ xpos, double *__restrict__ x,
-                                   const double *__restrict__ scale, const double *__restrict__ add)
+// x[row(pos)] = xpos[pos], optionally followed by the Schwarz level's "x *= pou" and "x += coarse correction" (same operations in
+// the same order as the separate kernels, so the result is bit-identical; saves their passes over the overlapping vector)
+__global__ __launch_bounds__(PERM_WG) void k_pipe_permute_out(int64_t npos, const int32_t *__restrict__ rowU, const double *__restrict__ xpos, double *__restrict__ x,
+                                                             const double *__restrict__ scale, const double *__restrict__ add)
 {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    double v = xpos[posU[i]];
-    if (scale) v *= scale[i];
-    if (add) v += add[i];
-    x[i] = v;
+  __shared__ int32_t idx[PERM_STEPS * PERM_PAD];
+  __shared__ double val[PERM_STEPS * PERM_PAD];
+  const int64_t ntile = (npos + PERM_TILE - 1) / PERM_TILE;
+  for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int64_t p0 = tile * PERM_TILE;
+#pragma unroll
+    for (int q = 0; q < PERM_TILE / PERM_WG; ++q) {
+      const int e = q * PERM_WG + threadIdx.x;
+      const int64_t p = p0 + e;
+      const int o = (e >> 6) * PERM_PAD + (e & 63);
+      idx[o] = p < npos ? rowU[p] : -1;
+      val[o] = p < npos ? xpos[p] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PERM_TILE / PERM_WG; ++q) {
+      const int e = q * PERM_WG + threadIdx.x;
+      const int l = e / PERM_STEPS, st = e % PERM_STEPS;
+      const int32_t r = idx[st * PERM_PAD + l];
+      if (r >= 0) {
+        double v = val[st * PERM_PAD + l];
+        if (scale) v *= scale[r];
+        if (add) v += add[r];
+        x[r] = v;
+      }
+    }
+    __syncthreads();
   }
 }
 
