@@ -2305,7 +2305,10 @@ static int combined_apply_fused(ddm_ctx *ctx, ddm_combined *C, double *x, const 
     hipStream_t main = ctx->stream;
     HIPCHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
     ctx->stream = ctx->side; // the coarse chain is enqueued on the side stream (kernels, RCCL all-reduce, timer)
-    const int rc = coarse_chain(std::min(G->nchunk, 2 * ctx->num_cu)); // two workgroups per CU: leaves wave slots for the pipe kernel
+    // a small grid: the chain only has to finish within the (latency-bound, ~3 ms) local solve, and a full-rate basis stream would
+    // queue in front of the pipe kernel's dependent L2 / HBM round trips (DDM_OVERLAP_GRID: workgroups, default 64)
+    static const int side_grid = std::getenv("DDM_OVERLAP_GRID") ? std::max(1, std::atoi(std::getenv("DDM_OVERLAP_GRID"))) : 64;
+    const int rc = coarse_chain(std::min(G->nchunk, side_grid));
     const hipError_t e = hipEventRecord(ctx->ev_join, ctx->side);
     ctx->stream = main;
     if (rc) return rc;
