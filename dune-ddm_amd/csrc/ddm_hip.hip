@@ -443,8 +443,30 @@ static int csr_mm_ld(ddm_ctx *ctx, const ddm_csr *A, int nrhs, const double *X, 
   if (!A || !X || !Y || X == Y || nrhs < 1 || ldx < nrhs || ldy < nrhs) return fail(ctx, DDM_EINVAL, "ddm_csr_mm: bad arguments");
   const int64_t threads = A->nrows * (int64_t)nrhs;
   if (threads == 0) return DDM_OK;
+  if (nrhs % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)X & 31) == 0 && ((uintptr_t)Y & 31) == 0) {
+    hipLaunchKernelGGL(k_spmm_rowmajor4<false>, dim3((unsigned)((threads / 4 + WG - 1) / WG)), dim3(WG), 0, ctx->stream, A->nrows, nrhs / 4, A->rp, A->ci, A->va,
+                       (const double *)nullptr, X, ldx, Y, (double *)nullptr, ldy);
+    HIPCHECK(ctx, hipGetLastError());
+    return DDM_OK;
+  }
   hipLaunchKernelGGL(k_spmm_rowmajor, dim3((unsigned)((threads + WG - 1) / WG)), dim3(WG), 0, ctx->stream, A->nrows, nrhs, A->rp, A->ci,
                      A->va, X, ldx, Y, ldy);
+  HIPCHECK(ctx, hipGetLastError());
+  return DDM_OK;
+}
+// Y1 = A1 X, Y2 = A2 X for two matrices on ONE pattern (same rp / ci arrays in value; checked by size only: internal use)
+static int csr_mm2_ld(ddm_ctx *ctx, const ddm_csr *A1, const ddm_csr *A2, int nrhs, const double *X, int64_t ldx, double *Y1, double *Y2, int64_t ldy)
+{
+  const bool fast = A1->nrows == A2->nrows && A1->nnz == A2->nnz && nrhs % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)X & 31) == 0 && ((uintptr_t)Y1 & 31) == 0 &&
+                    ((uintptr_t)Y2 & 31) == 0 && X != Y1 && X != Y2;
+  if (!fast) {
+    DDMCHECK(csr_mm_ld(ctx, A1, nrhs, X, ldx, Y1, ldy));
+    return csr_mm_ld(ctx, A2, nrhs, X, ldx, Y2, ldy);
+  }
+  const int64_t threads = A1->nrows * (int64_t)(nrhs / 4);
+  if (threads == 0) return DDM_OK;
+  hipLaunchKernelGGL(k_spmm_rowmajor4<true>, dim3((unsigned)((threads + WG - 1) / WG)), dim3(WG), 0, ctx->stream, A1->nrows, nrhs / 4, A1->rp, A1->ci, A1->va,
+                     (const double *)A2->va, X, ldx, Y1, Y2, ldy);
   HIPCHECK(ctx, hipGetLastError());
   return DDM_OK;
 }

@@ -395,8 +395,11 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
   DDMCHECK(ddm_csr_create(ctx, n, n, rpT.data(), ciT.data(), vaT.data(), &own.At));
   DDMCHECK(ddm_csr_create(ctx, n, n, rpT.data(), ciT.data(), vaC.data(), &own.C));
   { std::vector<double>().swap(vaT); std::vector<double>().swap(vaC); }
-  auto apply_C = [&](int mm, const double *X, int64_t ldx, double *Y, int64_t ldy) -> int {
-    return op_C ? (*op_C)(mm, X, ldx, Y, ldy) : csr_mm_ld(ctx, own.C, mm, X, ldx, Y, ldy);
+  // A~ X and C~ X of the same block in one pass (the two matrices share their pattern: build_pencil_host)
+  auto apply_AC = [&](int mm, const double *X, int64_t ldx, double *YA, double *YC, int64_t ldy) -> int {
+    if (!op_C) return csr_mm2_ld(ctx, own.At, own.C, mm, X, ldx, YA, YC, ldy);
+    DDMCHECK(csr_mm_ld(ctx, own.At, mm, X, ldx, YA, ldy));
+    return (*op_C)(mm, X, ldx, YC, ldy);
   };
   // ---- preconditioner ----
   int direct = 0;
@@ -463,8 +466,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
   // ---- initial block: random on the free DoFs, Rayleigh-Ritz on span X ----
   hipLaunchKernelGGL(k_geneo_random, dim3(gnm), dim3(256), 0, ctx->stream, n, m, ld, 0x5DEECE66Dull + (unsigned long long)P.seed, maskd, S[0]);
   if (con) DDMCHECK(harmonic_apply(ctx, con, m, S[0], ld, true));
-  DDMCHECK(csr_mm_ld(ctx, own.At, m, S[0], ld, AS[0], ld));
-  DDMCHECK(apply_C(m, S[0], ld, CS[0], ld));
+  DDMCHECK(apply_AC(m, S[0], ld, AS[0], CS[0], ld));
   int cur = 0, it = 0, converged = 0, rank_min = p;
   double worst = 0.0;
   const double tau = 1e-11;
@@ -495,12 +497,12 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
         const double *Bx[1] = {Wb};
         DDMCHECK(W.rotate(1, Ux, Ox, Bx, ld, m, gmm[3], m, ld, ld));
       }
-      DDMCHECK(csr_mm_ld(ctx, own.At, m, Wb, ld, AWb, ld));
+      DDMCHECK(apply_AC(m, Wb, ld, AWb, CWb, ld)); // both products of the unscaled W in one pass over it; scaled together below
       DDMCHECK(W.gram(Wb, ld, m, AWb, ld, m, gmm[3]));
       hipLaunchKernelGGL(k_geneo_invsqrt_diag, dim3((unsigned)((nsub * m + 255) / 256)), dim3(256), 0, ctx->stream, (int)nsub, m, gmm[3], svec[1]);
       hipLaunchKernelGGL(k_geneo_colscale, dim3(gnm), dim3(256), 0, ctx->stream, n, m, W.sub_of_row, svec[1], Wb, ld);
       hipLaunchKernelGGL(k_geneo_colscale, dim3(gnm), dim3(256), 0, ctx->stream, n, m, W.sub_of_row, svec[1], AWb, ld);
-      DDMCHECK(apply_C(m, Wb, ld, CWb, ld));
+      hipLaunchKernelGGL(k_geneo_colscale, dim3(gnm), dim3(256), 0, ctx->stream, n, m, W.sub_of_row, svec[1], CWb, ld);
       // A~-normalise the columns of P (zero columns stay zero)
       double *Pb = S[cur] + 2 * m, *APb = AS[cur] + 2 * m, *CPb = CS[cur] + 2 * m;
       DDMCHECK(W.gram(Pb, ld, m, APb, ld, m, gmm[3]));
@@ -580,8 +582,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
     }
     if (it > 0 && it % 8 == 0) { // refresh A~X, C X from X: the recursions drift
       if (con) DDMCHECK(harmonic_apply(ctx, con, m, S[cur], ld, true));
-      DDMCHECK(csr_mm_ld(ctx, own.At, m, S[cur], ld, AS[cur], ld));
-      DDMCHECK(apply_C(m, S[cur], ld, CS[cur], ld));
+      DDMCHECK(apply_AC(m, S[cur], ld, AS[cur], CS[cur], ld));
     }
   }
   const double t_loop = since(t_iter);

@@ -246,6 +246,44 @@ __global__ __launch_bounds__(WG) void k_spmm_rowmajor(int64_t n, int nrhs, const
   y[row * ldy + j] = s;
 }
 
+// The same for nrhs % 4 == 0 and 32-byte aligned rows: one thread per (row, group of 4 columns) -- a quarter of the index / value /
+// gather instructions per product; optionally TWO matrices on one pattern (va2, y2: the pencil matrices A~ and C~ of the block
+// eigensolver share their pattern), which reads the block X once for both products.  Row sums in entry order, as above.
+template <bool TWO>
+__global__ __launch_bounds__(WG) void k_spmm_rowmajor4(int64_t n, int nq /* nrhs / 4 */, const int64_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                        const double *__restrict__ va, const double *__restrict__ va2, const double *__restrict__ x, int64_t ldx,
+                                                        double *__restrict__ y, double *__restrict__ y2, int64_t ldy)
+{
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x;
+  const int64_t row = t / nq;
+  if (row >= n) return;
+  const int j = 4 * (int)(t - row * nq);
+  const int64_t k0 = rp[row], k1 = rp[row + 1];
+  d4 s = {0.0, 0.0, 0.0, 0.0}, s2 = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t kb = k0; kb < k1; kb += 4) {
+    int32_t c[4];
+    double v[4], w[4];
+    d4 xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool ok = kb + u < k1;
+      c[u] = ok ? ci[kb + u] : -1;
+      v[u] = ok ? va[kb + u] : 0.0;
+      if (TWO) w[u] = ok ? va2[kb + u] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xv[u] = c[u] >= 0 ? *reinterpret_cast<const d4 *>(x + (int64_t)c[u] * ldx + j) : d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s += v[u] * xv[u];
+      if (TWO) s2 += w[u] * xv[u];
+    }
+  }
+  *reinterpret_cast<d4 *>(y + row * ldy + j) = s;
+  if (TWO) *reinterpret_cast<d4 *>(y2 + row * ldy + j) = s2;
+}
+
 // Several consecutive small levels (each <= WG*TRSV_SMALL_ROWS rows) in ONE workgroup: the levels
 // are separated by workgroup barriers instead of kernel boundaries.  desc[l] = {m, w, row_off,
 // ent_off}.  All data of these levels is produced and consumed by this workgroup only.

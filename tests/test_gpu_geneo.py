@@ -17,15 +17,17 @@ def _sin_largest_angle(U, V):
     return float(np.linalg.norm(Qu - Qv @ (Qv.T @ Qu), 2))
 
 
-def test_multi_rhs_kernels(ddm):
-    """ddm_csr_mm and ddm_ilu0_solve_multi == column-by-column single-vector kernels (bit-exact: same order)."""
+@pytest.mark.parametrize("m", [7, 8, 24])
+def test_multi_rhs_kernels(ddm, m):
+    """ddm_csr_mm and ddm_ilu0_solve_multi == column-by-column single-vector kernels (bit-exact: same order); m = 8, 24 take the
+    four-columns-per-thread SpMM kernel."""
     import torch
     from dune_ddm_amd import synth
     ctx = ddm.torch_context(0)
     M = synth.StructuredPoisson((12, 11, 10), (1, 1, 1)).subdomain(0).A
     A = ddm.CsrMatrix(ctx, M)
     F = ddm.Ilu0(ctx, A)
-    n, m = M.shape[0], 7
+    n = M.shape[0]
     rng = np.random.default_rng(11)
     X = torch.as_tensor(rng.standard_normal((n, m))).cuda()
     Y = torch.empty_like(X)
