@@ -286,7 +286,16 @@ template <bool STAMP>
 __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipeParams P)
 {
   static_assert(PIPE_NC >= 1 && PIPE_NC <= pipe::MAX_NC, "late masks exist for up to MAX_NC compute waves");
+  // every compute wave holds its current tile and prefetches its next one while a loader fills a further one: 2 NC + 1 tiles give full
+  // overlap.  With -DDDM_PIPE_TIGHT_RING the ring only has to hold NC + 1 of the WIDEST tiles (all current tiles and one more): a wave whose
+  // next tile does not fit yet waits for the oldest step to release its tile -- less overlap on the wide steps, no deadlock (steps complete
+  // in order, and a completed step frees the space the youngest prefetch is waiting for).
+#ifdef DDM_PIPE_TIGHT_RING
+  static_assert((PIPE_NC + 1) * (pipe::Geometry(pipe::MAX_W).tile_bytes / 1024) <= PIPE_RING_KIB, "tile ring too small for the widest tiles");
+  static_assert((2 * PIPE_NC + 1) * (pipe::Geometry(pipe::MIN_W).tile_bytes / 1024) <= PIPE_RING_KIB, "tile ring too small for full overlap on the narrow tiles");
+#else
   static_assert((2 * PIPE_NC + 1) * (pipe::Geometry(pipe::MAX_W).tile_bytes / 1024) <= PIPE_RING_KIB, "tile ring too small for the widest tiles");
+#endif
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   // All LDS is dynamic and the result ring sits at LDS address 0, so that ring operands are ds_read addresses as they
   // stand.  Control words between the waves: relaxed workgroup-scope atomics (plain ds_read / ds_write; ordering is by
