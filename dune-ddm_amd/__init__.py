@@ -96,6 +96,7 @@ SYMBOLS = {
     "ddm_chol_host_get": (_I32, [_P, _P, _P, _P, _P]),
     "ddm_schwarz_create_ex": (_I32, [_P, _P, _I64, _P, _I64, _P, _P, _I32, ctypes.c_char_p, _P, _P, _PP]),
     "ddm_schwarz_engine": (_I32, [_P]),
+    "ddm_schwarz_factor_nnz": (_I64, [_P]),
     "ddm_schwarz_status": (_I32, [_P, _P]),
     "ddm_combined_status": (_I32, [_P, _P]),
     "ddm_ilu0_get_factors_host": (_I32, [_P, _P, _P]),
@@ -463,6 +464,10 @@ class SchwarzPreconditioner:
     def engine(self):
         """triangular-solve engine of the local solver: 'pipe', 'xcd2' (also when pipe declined the matrix) or 'levels'"""
         return self.ENGINES[int(self.ctx.lib.ddm_schwarz_engine(self.h))]
+
+    def factor_nnz(self):
+        """stored entries of the local solver's factor (roofline accounting)"""
+        return int(self.ctx.lib.ddm_schwarz_factor_nnz(self.h))
 
     def check_status(self):
         """raises DdmError if a single-launch local solve timed out since creation (synchronous)"""

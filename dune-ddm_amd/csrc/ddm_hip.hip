@@ -2039,6 +2039,7 @@ extern "C" void ddm_schwarz_destroy(ddm_schwarz *S)
   delete S;
 }
 extern "C" int64_t ddm_schwarz_num_levels(const ddm_schwarz *S, int upper) { return ddm_ilu0_num_levels(S->solver, upper); }
+extern "C" int64_t ddm_schwarz_factor_nnz(const ddm_schwarz *S) { return (S && S->solver) ? S->solver->nnz : 0; } // stored entries of L + U (+ diagonal)
 extern "C" int ddm_schwarz_engine(const ddm_schwarz *S) { return S ? ddm_ilu0_engine(S->solver) : -1; }
 // Synchronous.  DDM_OK, or DDM_ENUMERIC when a single-launch local solve gave up waiting (its results are invalid: the
 // GPU is shared with another process, or the grid was not co-resident) -- the reference's apply has no error return

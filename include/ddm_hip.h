@@ -192,6 +192,7 @@ int ddm_schwarz_create_ex(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t nblocks, c
 void ddm_schwarz_destroy(ddm_schwarz *S);
 int ddm_schwarz_apply(ddm_ctx *ctx, ddm_schwarz *S, double *x, const double *d); /* :115-149 */
 int64_t ddm_schwarz_num_levels(const ddm_schwarz *S, int upper); /* dependency levels of the local L / U solve */
+int64_t ddm_schwarz_factor_nnz(const ddm_schwarz *S); /* stored entries of the local solver's factor (ILU(0): nnz(A_dir); direct: nnz(L + U)) */
 int ddm_schwarz_engine(const ddm_schwarz *S);                    /* ddm_ilu0_engine of the local solver */
 /* Synchronous: DDM_OK, or DDM_ENUMERIC if a local solve since creation gave up waiting (results invalid).  apply has no
  * error return in the reference (schwarz.hh:131 discards the InverseOperatorResult); adaptors call this in post(). */
