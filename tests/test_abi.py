@@ -71,3 +71,16 @@ def test_pipe_kernel_has_no_spills():
         assert vals["ScratchSize [bytes/lane]"] == 0 and vals["AGPRs"] == 0 and vals["VGPRs Spill"] == 0, (name, vals)
         assert vals["VGPRs"] <= 256, (name, vals)              # two workgroups of three waves per CU
     assert seen == 1
+
+
+def test_bench_scripts_compile_and_keep_the_contract_keys():
+    """bench.py / bench_convdiff.py need a GPU to run; here: they compile, and the JSON line they print carries the keys of the driver's
+    contract plus the roofline / cpu_baseline objects."""
+    import py_compile
+    for name in ("bench.py", "bench_convdiff.py"):
+        path = os.path.join(ROOT, name)
+        py_compile.compile(path, doraise=True)
+        src = open(path).read()
+        for key in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"steps"', '"warmup"', '"ms_per_step"', '"higher_is_better"', '"scaling"', '"vs_baseline"',
+                    '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"', '"bound"', '"achieved"', '"peak"', '"frac"', '"traffic"', '"cores"', '"kind"', '"sample"'):
+            assert key in src, (name, key)
