@@ -30,6 +30,21 @@ def log(rank, *a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def launch_workers(n):
+    """Parent of `python bench.py --gpus N`: N worker processes via torch.distributed.run (children; no exec, no GPU call here)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] launching", " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -45,28 +60,46 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=8)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver may call it: this process becomes the launcher.  It starts the N workers (one
+        # process per GPU) through torch.distributed.run BEFORE anything here touches the GPU, passes their output through (rank 0
+        # prints the one JSON line) and exits with their return code.
+        sys.exit(launch_workers(args.gpus))
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
 
     import numpy as np
     import torch
     import __graft_entry__ as ge
     pkg = ge.import_package()
     pkg.load_library()                      # fails loudly if the HIP extension is missing
-    assert torch.cuda.is_available(), "bench.py needs a HIP device: the hot path has no CPU fallback"
+    ndev = torch.cuda.device_count()        # (does not initialise the GPU)
+    assert ndev > 0 and torch.cuda.is_available(), "bench.py needs a HIP device: the hot path has no CPU fallback"
     from dune_ddm_amd import CgIteration, synth
     from dune_ddm_amd.problem import build_structured
     from dune_ddm_amd.solver import TorchComm, TwoLevelSchwarz
 
-    torch.cuda.set_device(local_rank)
+    # one process per GPU over RCCL.  With fewer devices than ranks (rehearsal of the N > 1 path on a one-GPU box) the ranks share
+    # devices: RCCL refuses two ranks on one device, so the exchange is staged through gloo and the local solves use one launch
+    # per level (the single-launch engines need the whole GPU); the JSON line says so ("backend", "ranks_share_devices").
+    shared = ndev < world
+    backend = os.environ.get("DDM_BACKEND", "gloo" if shared else "nccl")
+    device = local_rank % ndev
+    torch.cuda.set_device(device)
     comm = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=os.environ.get("DDM_BACKEND", "nccl"), device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend=backend)
         comm = TorchComm()
+    local_rank = device
 
     def barrier():
         if world > 1:
@@ -137,7 +170,7 @@ def main():
                                                     "Schwarz/add solution", "GalerkinPrec/apply", "CombinedPreconditioner/apply")}
     cg.end()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert np.isfinite(deff), "defect became non-finite inside the timed region"
@@ -224,6 +257,8 @@ def main():
             "metric": "preconditioned CG iterations/sec (two-level additive Schwarz), 3D Poisson 10M DoF",
             "value": its_per_s, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "backend": "none (single rank)" if world == 1 else ("nccl (RCCL)" if backend == "nccl" else backend),
+            "exchange": tl.exchange, "rccl_comm_size": tl.ctx.rccl_size(), "ranks_share_devices": bool(shared), "visible_devices": ndev,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"3D Q1 Poisson {G}^3 = {ndof} DoF, {P ** 3} overlapping subdomains ({P}x{P}x{P}, overlap {args.overlap}), "
                                    f"ILU(0) subdomain solves, coarse space '{coarse}' (K = {0 if tl.galerkin is None else tl.K}), additive, CG",

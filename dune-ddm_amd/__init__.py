@@ -63,6 +63,7 @@ SYMBOLS = {
     "ddm_ctx_set_comm": (_I32, [_P, _I32, _I32, A2A_FN, ALLREDUCE_FN, _P]),
     "ddm_rccl_unique_id": (_I32, [_P]),
     "ddm_ctx_set_rccl": (_I32, [_P, _I32, _I32, _P, _I32]),
+    "ddm_ctx_rccl_size": (_I32, [_P, ctypes.POINTER(ctypes.c_int)]),
     "ddm_malloc": (_I32, [_P, _I64, _PP]),
     "ddm_free": (_I32, [_P, _P]),
     "ddm_memcpy_h2d": (_I32, [_P, _P, _P, _I64]),
@@ -80,6 +81,9 @@ SYMBOLS = {
     "ddm_ilu0_solve": (_I32, [_P, _P, _P, _P]),
     "ddm_ilu0_debug_stamps": (_I32, [_P, _P, _P, _P, _P]),
     "ddm_ilu0_status": (_I32, [_P, _P, ctypes.POINTER(ctypes.c_int)]),
+    "ddm_ilu0_peek_status": (_I32, [_P]),
+    "ddm_halo_exchange_to": (_I32, [_P, _P, _P, _P]),
+    "ddm_schwarz_local_solver": (_P, [_P]),
     "ddm_ilu0_pipe_trace": (_I32, [_P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(ctypes.c_int64)]),
     "ddm_ilu0_num_levels": (_I64, [_P, _I32]),
     "ddm_ilu0_engine": (_I32, [_P]),
@@ -215,6 +219,12 @@ class Context:
         assert len(unique_id) == 128
         self.check(self.lib.ddm_ctx_set_rccl(self.h, int(rank), int(nranks), ctypes.c_char_p(unique_id), int(bool(self_test))))
         self.rank, self.nranks = rank, nranks
+
+    def rccl_size(self):
+        """ranks of the in-library communicator as RCCL reports them (ncclCommCount); 0 = no in-library exchange"""
+        c = ctypes.c_int(0)
+        self.check(self.lib.ddm_ctx_rccl_size(self.h, ctypes.byref(c)))
+        return c.value
 
     def timing(self, on=True):
         self.check(self.lib.ddm_timing_enable(self.h, int(on)))
@@ -396,6 +406,10 @@ class Halo:
 
     def exchange(self, v):
         self.ctx.check(self.ctx.lib.ddm_halo_exchange(self.ctx.h, self.h, _ptr(v)))
+
+    def exchange_to(self, src, dst):
+        """pack from ``src``, unpack into ``dst`` (entries outside the destination list are left alone)"""
+        self.ctx.check(self.ctx.lib.ddm_halo_exchange_to(self.ctx.h, self.h, _ptr(src), _ptr(dst)))
 
     @property
     def sendbuf(self):

@@ -51,6 +51,7 @@ struct ddm_ctx {
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
   } nccl;
   ncclComm_t rccl_comm = nullptr;
   bool rccl = false, rccl_self = false; // rccl_self: route the self segment through RCCL too (single-GPU self test)
@@ -264,6 +265,7 @@ extern "C" int ddm_ctx_set_rccl(ddm_ctx *ctx, int rank, int nranks, const void *
   N.Recv = (decltype(N.Recv))dlsym(N.lib, "ncclRecv");
   N.AllReduce = (decltype(N.AllReduce))dlsym(N.lib, "ncclAllReduce");
   N.GetErrorString = (decltype(N.GetErrorString))dlsym(N.lib, "ncclGetErrorString");
+  N.CommCount = (decltype(N.CommCount))dlsym(N.lib, "ncclCommCount");
   if (!N.CommInitRank || !N.CommDestroy || !N.GroupStart || !N.GroupEnd || !N.Send || !N.Recv || !N.AllReduce)
     return fail(ctx, DDM_ECOMM, "librccl lacks a required entry point");
   HIPCHECK(ctx, hipSetDevice(ctx->device));
@@ -280,6 +282,16 @@ extern "C" int ddm_ctx_set_rccl(ddm_ctx *ctx, int rank, int nranks, const void *
   ctx->rccl_self = self_test != 0;
   ctx->a2a = nullptr;
   ctx->allreduce = nullptr;
+  return DDM_OK;
+}
+extern "C" int ddm_ctx_rccl_size(ddm_ctx *ctx, int *count)
+{
+  if (!ctx || !count) return DDM_EINVAL;
+  *count = 0; // no in-library communicator
+  if (!ctx->rccl_comm) return DDM_OK;
+  if (!ctx->nccl.CommCount) return fail(ctx, DDM_ECOMM, "librccl lacks ncclCommCount");
+  const ncclResult_t r = ctx->nccl.CommCount(ctx->rccl_comm, count);
+  if (r != ncclSuccess) return fail(ctx, DDM_ECOMM, "ncclCommCount failed: %s", ctx->nccl.GetErrorString ? ctx->nccl.GetErrorString(r) : "?");
   return DDM_OK;
 }
 #define NCCLCHECK(ctx, call)                                                                                                   \
@@ -1051,7 +1063,13 @@ static int ilu0_build_engines(ddm_ctx *ctx, ddm_ilu0 *F, const ddm_csr *A, const
   F->A = A;
   F->h_diag = diag;
   F->h_block_ptr.assign(block_ptr, block_ptr + nblocks + 1);
-  if (!rc && (hipMalloc((void **)&F->err, 128) != hipSuccess || hipMemset(F->err, 0, 128) != hipSuccess)) rc = fail(ctx, DDM_EHIP, "ILU(0): allocation failed");
+  // status word of the single-launch engines in pinned, device-mapped HOST memory: a wave that gives up waiting writes its code
+  // straight into it, so the host can look at it without synchronising the stream (ilu0_peek_status: every apply checks the
+  // applies before it -- fail fast instead of returning stale results until somebody calls ddm_ilu0_status)
+  if (!rc) {
+    if (hipHostMalloc((void **)&F->err, 128, hipHostMallocMapped) != hipSuccess) rc = fail(ctx, DDM_EHIP, "ILU(0): allocation failed");
+    else std::memset(F->err, 0, 128);
+  }
   if (!rc && F->mode == 8 && F->n > 0) rc = build_pipe_schedule(ctx, F); // part of the setup, not of the first solve (not applicable: pipe_state < 0, see ddm_ilu0_solve)
   return rc;
 }
@@ -1279,7 +1297,7 @@ extern "C" void ddm_ilu0_destroy(ddm_ilu0 *F)
   if (!F) return;
   if (F->graph) (void)hipGraphExecDestroy(F->graph);
   if (F->mgraph) (void)hipGraphExecDestroy(F->mgraph);
-  (void)hipFree(F->err);
+  if (F->err) (void)hipHostFree(F->err);
   (void)hipFree(F->perm);
   (void)hipFree(F->pd);
   (void)hipFree(F->px);
@@ -1320,11 +1338,14 @@ extern "C" void ddm_ilu0_destroy(ddm_ilu0 *F)
 // 0 = ok, 1 = a wave of the persistent kernel gave up waiting (results invalid); synchronous
 extern "C" int ddm_ilu0_status(ddm_ctx *ctx, const ddm_ilu0 *F, int *status)
 {
-  unsigned e = 0;
-  DDMCHECK(ddm_memcpy_d2h(ctx, &e, F->err, sizeof(unsigned)));
-  *status = (int)e;
+  if (!F || !status) return fail(ctx, DDM_EINVAL, "ddm_ilu0_status: bad arguments");
+  HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  *status = (int)*(volatile unsigned *)F->err;
   return DDM_OK;
 }
+// the same word WITHOUT synchronising: what the solves that have finished so far reported (0 = nothing wrong yet)
+static inline unsigned ilu0_peek_status(const ddm_ilu0 *F) { return (F && F->err) ? *(volatile unsigned *)F->err : 0u; }
+extern "C" int ddm_ilu0_peek_status(const ddm_ilu0 *F) { return (int)ilu0_peek_status(F); }
 extern "C" int64_t ddm_ilu0_num_levels(const ddm_ilu0 *F, int upper) { return upper ? F->U.nlev : F->L.nlev; }
 // engine the next ddm_ilu0_solve uses: 8 = pipe, 4 = xcd2 (also when pipe declined the matrix), 0 = one launch per level
 extern "C" int ddm_ilu0_engine(const ddm_ilu0 *F)
@@ -1849,11 +1870,18 @@ extern "C" void ddm_halo_destroy(ddm_halo *H)
 extern "C" double *ddm_halo_sendbuf(ddm_halo *H) { return H->sendbuf; }
 extern "C" double *ddm_halo_recvbuf(ddm_halo *H) { return H->recvbuf; }
 
-extern "C" int ddm_halo_exchange(ddm_ctx *ctx, ddm_halo *H, double *v)
+static int halo_exchange_impl(ddm_ctx *ctx, ddm_halo *H, const double *src, double *v);
+extern "C" int ddm_halo_exchange(ddm_ctx *ctx, ddm_halo *H, double *v) { return halo_exchange_impl(ctx, H, v, v); }
+extern "C" int ddm_halo_exchange_to(ddm_ctx *ctx, ddm_halo *H, const double *src, double *dst)
+{
+  if (!src || !dst) return fail(ctx, DDM_EINVAL, "ddm_halo_exchange_to: bad arguments");
+  return halo_exchange_impl(ctx, H, src, dst);
+}
+static int halo_exchange_impl(ddm_ctx *ctx, ddm_halo *H, const double *src, double *v)
 {
   if (!H) return DDM_OK;
   if (H->nsend == 0 && H->ndst == 0 && !H->remote) return DDM_OK;
-  if (H->nsend > 0) hipLaunchKernelGGL(k_pack, dim3(grid_for(H->nsend)), dim3(WG), 0, ctx->stream, H->nsend, H->send_idx, v, H->sendbuf);
+  if (H->nsend > 0) hipLaunchKernelGGL(k_pack, dim3(grid_for(H->nsend)), dim3(WG), 0, ctx->stream, H->nsend, H->send_idx, src, H->sendbuf);
   const double *rbuf = H->recvbuf;
   if (ctx->rccl && (ctx->nranks > 1 || ctx->rccl_self)) {
     // one grouped point-to-point exchange on the context's stream (xGMI links are point-to-point: every peer pair is its own
@@ -2044,6 +2072,7 @@ extern "C" int ddm_schwarz_engine(const ddm_schwarz *S) { return S ? ddm_ilu0_en
 // Synchronous.  DDM_OK, or DDM_ENUMERIC when a single-launch local solve gave up waiting (its results are invalid: the
 // GPU is shared with another process, or the grid was not co-resident) -- the reference's apply has no error return
 // (schwarz.hh:131 discards the InverseOperatorResult), so the adaptors poll this in post() and the Krylov drivers at the end.
+extern "C" ddm_ilu0 *ddm_schwarz_local_solver(ddm_schwarz *S) { return S ? S->solver : nullptr; } // borrowed (owned by S)
 extern "C" int ddm_schwarz_status(ddm_ctx *ctx, const ddm_schwarz *S)
 {
   if (!S) return fail(ctx, DDM_EINVAL, "ddm_schwarz_status: bad arguments");
@@ -2055,6 +2084,8 @@ extern "C" int ddm_schwarz_status(ddm_ctx *ctx, const ddm_schwarz *S)
 // x (= or +=) R~^T [D] A_dir^-1 R~ d
 static int schwarz_apply_impl(ddm_ctx *ctx, ddm_schwarz *S, double *x, const double *d, bool acc)
 {
+  if (const unsigned e = ilu0_peek_status(S->solver)) // fail fast: an earlier local solve gave up (no stream synchronisation here)
+    return fail(ctx, DDM_ENUMERIC, "an earlier local triangular solve timed out waiting for a dependency (code %u): results since then are invalid", e);
   {
     ScopedTimer t(ctx, "Schwarz/get defect");
     hipLaunchKernelGGL(k_extend, dim3(grid_for(S->n)), dim3(WG), 0, ctx->stream, S->n, S->ext_map, d, S->d_ovlp); // :121-122
@@ -2107,7 +2138,7 @@ extern "C" int ddm_galerkin_create(ddm_ctx *ctx, int64_t n, int64_t n_novlp, con
   if (!ctx || !out || !ext_map_host || !sub_ptr || !basis_host || !coarse_index || !a0inv_host)
     return fail(ctx, DDM_EINVAL, "ddm_galerkin_create: bad arguments");
   if (kmax < 1) return fail(ctx, DDM_EINVAL, "Must at least pass one template vector"); // galerkin_preconditioner.hh:129
-  if (kmax > 64) return fail(ctx, DDM_ENOTIMPL, "more than 64 basis vectors per subdomain are not supported");
+  if (kmax > COARSE_KMAX) return fail(ctx, DDM_ENOTIMPL, "more than %d basis vectors per subdomain are not supported", COARSE_KMAX);
   if (sub_ptr[0] != 0 || sub_ptr[nsub] != n) return fail(ctx, DDM_EINVAL, "Template vectors must match size of matrix"); // :131
   for (int64_t t = 0; t < nsub * kmax; ++t)
     if (coarse_index[t] >= K) return fail(ctx, DDM_EINVAL, "coarse_index out of range");
@@ -2207,7 +2238,7 @@ extern "C" int ddm_galerkin_products(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t
 {
   // out[j*nleft + i] = <left_i, A_dir right_j> over rows [row0,row1)   (column-major nleft x nright,
   // the slab layout of galerkin_preconditioner.hh:294 / helpers.hh:252)
-  if (!A_dir || !left || !right || !out_host || nleft < 1 || nleft > 64 || nright < 1 || row0 < 0 || row1 > A_dir->nrows || row0 > row1)
+  if (!A_dir || !left || !right || !out_host || nleft < 1 || nleft > COARSE_KMAX || nright < 1 || row0 < 0 || row1 > A_dir->nrows || row0 > row1)
     return fail(ctx, DDM_EINVAL, "ddm_galerkin_products: bad arguments");
   const int64_t n = A_dir->nrows;
   double *y = nullptr, *partial = nullptr, *outd = nullptr;
@@ -2361,6 +2392,8 @@ static int combined_apply_fused(ddm_ctx *ctx, ddm_combined *C, double *x, const 
 extern "C" int ddm_combined_apply(ddm_ctx *ctx, ddm_combined *C, double *x, const double *d)
 {
   ScopedTimer t(ctx, "CombinedPreconditioner/apply");
+  if (const unsigned e = C->schwarz ? ilu0_peek_status(C->schwarz->solver) : 0u) // fail fast, no synchronisation (see ddm_ilu0_status)
+    return fail(ctx, DDM_ENUMERIC, "an earlier local triangular solve timed out waiting for a dependency (code %u): results since then are invalid", e);
   if (C->mode == 0 && C->galerkin && C->fused) return combined_apply_fused(ctx, C, x, d, C->overlap);
   // x = 0; precs[0]->apply(x, d)  (:133-134)  -- the restrict kernel overwrites every entry of x
   DDMCHECK(schwarz_apply_impl(ctx, C->schwarz, x, d, false));

@@ -592,7 +592,7 @@ __global__ __launch_bounds__(64 * (1 + TRSV_L_LOADERS)) void k_trsv_xcd2(int ngr
     unsigned fail_ = 0;
     for (unsigned spins = 0; __hip_atomic_load(&st->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x; ++spins) {
       if (spins > (1u << 22)) {
-        __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         fail_ = 1;
         break;
       }
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(64 * (1 + TRSV_L_LOADERS)) void k_trsv_xcd2(int ngr
       if (more) issue(B, wk);
       for (unsigned spins = 0; seq >= *consumed + TRSV_L_SLOTS; ++spins) { // free ring slot?
         if (spins > (1u << 24)) {
-          if (lane == 0) __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0) __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           return;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(64 * (1 + TRSV_L_LOADERS)) void k_trsv_xcd2(int ngr
   for (unsigned seq = 0;; ++seq) {
     for (unsigned spins = 0; ready[seq % TRSV_L_SLOTS] != seq + 1; ++spins) {
       if (spins > (1u << 24)) {
-        if (lane == 0) __hip_atomic_store(err, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(err, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
       }
       __builtin_amdgcn_s_sleep(1);
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(64 * (1 + TRSV_L_LOADERS)) void k_trsv_xcd2(int ngr
         const unsigned v = lane < H.nact_prev ? __hip_atomic_load(fp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
         if (__all(v == epoch)) break;
         if (spins > (1u << 22)) {
-          if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           break;
         }
       }
@@ -991,6 +991,7 @@ __global__ void k_cg_direction(int64_t n, const double *__restrict__ scal, const
 // K6 coarse restriction d0[(s,j)] = <r_j^s, d_ovlp^s>  (galerkin_preconditioner.hh:165-167):
 // a tall-skinny GEMV.  Work item = (chunk of rows inside one subdomain); wave w of the
 // workgroup handles vectors w, w+4, ...; lanes stride the rows (coalesced).
+static constexpr int COARSE_KMAX = 256; // basis vectors per subdomain (GenEO threshold mode doubles nev up to nev_max, spectra.hh:157-163)
 struct RowChunk {
   int64_t r0, r1;
   int32_t sub, pad;
@@ -1058,7 +1059,8 @@ __global__ __launch_bounds__(WG) void k_coarse_prolong(int kmax, int64_t ld, con
                                                         const double *__restrict__ x0, const int64_t *__restrict__ coarse_index,
                                                         const RowChunk *__restrict__ chunks, double *__restrict__ xov, int nchunk)
 {
-  __shared__ double cj[64];
+  __shared__ double cj[COARSE_KMAX];
+  static_assert(COARSE_KMAX <= WG, "one thread per coefficient");
   for (int ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
   const RowChunk c = chunks[ch];
   __syncthreads(); // cj of the previous chunk is no longer read

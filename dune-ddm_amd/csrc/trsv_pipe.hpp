@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // (uniform: scalar control flow)
   XcdState *st = P.st;
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) { // static LDS in front of the ring: not this build
-    if (threadIdx.x == 0) __hip_atomic_store(P.err, 6u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(P.err, 6u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
   // the ring is zeroed once: its last row stays zero for good, every other row is written before it is read
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
     unsigned fail_ = 0;
     for (unsigned spins = 0; __hip_atomic_load(&st->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x; ++spins) {
       if (spins > (1u << 22)) {
-        __hip_atomic_store(P.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(P.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         fail_ = 1;
         break;
       }
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
               while (nfl > 0) publish_oldest(0);
               for (unsigned spins = 0; (int)(v + sz - lds_load(&sh_vconsumed)) > PIPE_RING_KIB; ++spins) {
                 if (spins > (1u << 24)) {
-                  if (lane == 0) __hip_atomic_store(P.err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  if (lane == 0) __hip_atomic_store(P.err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                   return;
                 }
                 __builtin_amdgcn_s_sleep(1);
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
           if (upper) { // the forward sweep of this subdomain must be complete (its results are this sweep's right-hand side)
             for (unsigned spins = 0; __hip_atomic_load(qbase + 2 * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ntaskL; ++spins) {
               if (spins > (1u << 22)) {
-                if (lane == 0) __hip_atomic_store(P.err, 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_store(P.err, 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 return;
               }
               __builtin_amdgcn_s_sleep(2);
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
               if (spins == 0) on_first_drain();
               if (__all(have0 >= need0 && have1 >= need1)) break;
               if (spins > (1u << 22)) {
-                if (lane == 0) __hip_atomic_store(P.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_store(P.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 failed = true;
                 return;
               }
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
               const unsigned rdy = (unsigned)__builtin_amdgcn_readfirstlane((int)rdy_v); // (uniform anyway: scalar branch)
               if (rdy == (unsigned)t + 1u) break;
               if (spins > (1u << 24)) {
-                if (lane == 0) __hip_atomic_store(P.err, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_store(P.err, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 failed = true;
                 return;
               }
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
             if (PIPE_NC > 1) { // the previous step's results must be in the ring now
               for (unsigned spins = 0; (unsigned)__builtin_amdgcn_readfirstlane((int)lds_load(&sh_stepdone)) < (unsigned)t; ++spins) {
                 if (spins > (1u << 24)) {
-                  if (lane == 0) __hip_atomic_store(P.err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  if (lane == 0) __hip_atomic_store(P.err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                   failed = true;
                   return;
                 }

@@ -229,13 +229,9 @@ class TwoLevelSchwarz:
             halo = Halo(ctx, 100 + t, Halo.COPY, plan)
             if self.comm is not None:
                 self.comm.register(halo)
-            mask = torch.zeros(rl.n, dtype=torch.float64, device=self.dev)
-            if len(plan["dst_idx"]):
-                mask[torch.as_tensor(plan["dst_idx"], device=self.dev)] = 1.0
-            V = R.clone()
+            V = torch.zeros_like(R)         # the neighbours' vectors restricted to the shared indices, zero elsewhere (:96-101)
             for j in range(kmax):
-                halo.exchange(V[j])
-            V *= mask[None, :]
+                halo.exchange_to(R[j], V[j])
             for s in rl.local:
                 if t >= len(nbrs[s]):
                     continue

