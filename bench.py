@@ -30,7 +30,7 @@ def log(rank, *a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def launch_workers(n):
+def launch_workers(n, script=None):
     """Parent of `python bench.py --gpus N`: N worker processes via torch.distributed.run (children; no exec, no GPU call here)."""
     import socket
     import subprocess
@@ -40,9 +40,42 @@ def launch_workers(n):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
                OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), os.path.abspath(script or __file__)] + sys.argv[1:]
     print("[bench] launching", " ".join(cmd), file=sys.stderr, flush=True)
     return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
+def init_distributed(gpus):
+    """Worker side of `--gpus N`: (rank, world, device index, TorchComm | None, backend, ranks_share_devices, visible devices, dist).
+    One process per GPU over RCCL.  With fewer devices than ranks (rehearsal of the N > 1 path on a one-GPU box) the ranks share
+    devices: RCCL refuses two ranks on one device, so the exchange is staged through gloo and the local solves use one launch per
+    level (the single-launch engines need the whole GPU); the JSON line says so ("backend", "ranks_share_devices")."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != gpus:
+        raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={world}")
+    import torch
+    import __graft_entry__ as ge
+    pkg = ge.import_package()
+    pkg.load_library()                      # fails loudly if the HIP extension is missing
+    ndev = torch.cuda.device_count()        # (does not initialise the GPU)
+    assert ndev > 0 and torch.cuda.is_available(), "the benchmark needs a HIP device: the hot path has no CPU fallback"
+    shared = ndev < world
+    backend = os.environ.get("DDM_BACKEND", "gloo" if shared else "nccl")
+    device = local_rank % ndev
+    torch.cuda.set_device(device)
+    comm, dist = None, None
+    if world > 1:
+        import torch.distributed as dist
+        from dune_ddm_amd.solver import TorchComm
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend=backend)
+        comm = TorchComm()
+    return rank, world, device, comm, backend, shared, ndev, dist
 
 
 def main():
@@ -58,6 +91,8 @@ def main():
     ap.add_argument("--no-solve", action="store_true", help="skip the full solve to 1e-10 (iteration count / residual check)")
     ap.add_argument("--cpu-iters", type=int, default=60, help="CG iterations of the CPU oracle timed for cpu_baseline (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=8)
+    ap.add_argument("--no-order-leg", action="store_true", help="skip the second oracle run (other summation order) of the cpu leg")
+    ap.add_argument("--no-geneo-check", action="store_true", help="skip the host (scipy) residual check of the device GenEO eigenpairs")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -66,40 +101,14 @@ def main():
         # prints the one JSON line) and exits with their return code.
         sys.exit(launch_workers(args.gpus))
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
-
     import numpy as np
     import torch
     import __graft_entry__ as ge
     pkg = ge.import_package()
-    pkg.load_library()                      # fails loudly if the HIP extension is missing
-    ndev = torch.cuda.device_count()        # (does not initialise the GPU)
-    assert ndev > 0 and torch.cuda.is_available(), "bench.py needs a HIP device: the hot path has no CPU fallback"
+    rank, world, local_rank, comm, backend, shared, ndev, dist = init_distributed(args.gpus)
     from dune_ddm_amd import CgIteration, synth
     from dune_ddm_amd.problem import build_structured
-    from dune_ddm_amd.solver import TorchComm, TwoLevelSchwarz
-
-    # one process per GPU over RCCL.  With fewer devices than ranks (rehearsal of the N > 1 path on a one-GPU box) the ranks share
-    # devices: RCCL refuses two ranks on one device, so the exchange is staged through gloo and the local solves use one launch
-    # per level (the single-launch engines need the whole GPU); the JSON line says so ("backend", "ranks_share_devices").
-    shared = ndev < world
-    backend = os.environ.get("DDM_BACKEND", "gloo" if shared else "nccl")
-    device = local_rank % ndev
-    torch.cuda.set_device(device)
-    comm = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
-        else:
-            dist.init_process_group(backend=backend)
-        comm = TorchComm()
-    local_rank = device
+    from dune_ddm_amd.solver import TwoLevelSchwarz
 
     def barrier():
         if world > 1:
@@ -118,6 +127,7 @@ def main():
         coarse = "none"     # a single subdomain has no overlap region: ILU(0)-preconditioned CG
     dec = build_structured(grid, overlap=args.overlap, pou_type="distance", shrink=0, neumann=(coarse == "geneo"))
     t_host = time.perf_counter() - t_setup0
+    geneo_check = None
     log(rank, f"host setup (assembly, overlap extension, POU): {t_host:.1f} s")
     t1 = time.perf_counter()
     if coarse == "geneo":
@@ -128,12 +138,26 @@ def main():
         log(rank, f"GenEO: {gi['iterations']} block iterations, converged={gi['converged']} (worst residual {gi['worst_residual']:.2e}), "
                   f"preconditioner {'sparse Cholesky' if gi['used_direct'] else 'ILU(0)'}, setup {gi['setup_s']:.1f} s + iterations {gi['iterate_s']:.1f} s, "
                   f"lambda range of subdomain {tl.rl.local[0]}: {gi['eigenvalues'][tl.rl.local[0]][[0, -1]]}")
+        if rank == 0 and world == 1 and not args.no_geneo_check:
+            # independent host check (scipy only) of ALL device-built eigenpairs at the benchmark's size: the basis the oracle leg
+            # below is handed is pinned here, not assumed (dune_ddm_amd.geneo.host_eigenpair_residuals)
+            from concurrent.futures import ThreadPoolExecutor
+            from dune_ddm_amd.geneo import host_eigenpair_residuals
+            t_chk = time.perf_counter()
+            with ThreadPoolExecutor(min(8, os.cpu_count() or 1)) as ex:
+                chk = list(ex.map(lambda sd: host_eigenpair_residuals(sd, basis[sd.id], gi["eigenvalues"][sd.id]), tl.rl.subs))
+            geneo_check = {"pairs": int(sum(len(c[0]) for c in chk)), "worst_residual": float(max(c[0].max() for c in chk)),
+                           "worst_rayleigh_quotient_mismatch": float(max(c[1].max() for c in chk)), "seconds": time.perf_counter() - t_chk,
+                           "what": "host (scipy) check of every device eigenpair: ||A_neu x - lambda D B_neu D x||_2 / ||lambda D B_neu D x||_2, x recovered from the finalised vector"}
+            log(rank, f"GenEO host check: {geneo_check['pairs']} pairs, worst residual {geneo_check['worst_residual']:.2e}, "
+                      f"worst Rayleigh-quotient mismatch {geneo_check['worst_rayleigh_quotient_mismatch']:.2e} ({geneo_check['seconds']:.1f} s)")
+            assert geneo_check["worst_residual"] < 1e-4, "device GenEO eigenpairs fail the host residual check"
         tl.set_coarse_basis(basis)
         tl.rebuild_combined("additive")
     else:
         tl = TwoLevelSchwarz(dec, rank, world, local_rank, comm, schwarz_type="standard", mode="additive", coarse=coarse)
     tl.ctx.sync()
-    t_dev = time.perf_counter() - t1
+    t_dev = time.perf_counter() - t1 - (geneo_check["seconds"] if geneo_check else 0.0)
     log(rank, f"device setup (upload, ILU(0), level schedule, coarse space '{coarse}', R A R^T): {t_dev:.1f} s; "
               f"ILU levels L/U = {tl.schwarz_levels()}")
 
@@ -221,6 +245,19 @@ def main():
         ao.set_threads(threads)
         basis_o = coarse if coarse in ("pou", "none") else tl.host_basis()
         t_cpu, it_cpu = oracle_time_iterations(dec, args.cpu_iters, coarse=basis_o, schwarz_type="standard", mode="additive")
+        ho_other = None
+        if not args.no_order_leg:
+            # the same oracle iterations once more with nothing changed but the ORDER of the additions inside the global dot products
+            # (pairwise instead of index by index; oracle/kernels.c orc_masked_dot_order): how far two correct FP64 CG runs drift
+            # apart -- the yardstick for the HIP-vs-oracle deviation of the late iterations (tests/test_oracle_order_sensitivity.py)
+            ho_ref = np.array(oracle_time_iterations.last_history)
+            ao.set_dot_order(2)
+            try:
+                oracle_time_iterations(dec, args.cpu_iters, coarse=basis_o, schwarz_type="standard", mode="additive")
+                ho_other = np.array(oracle_time_iterations.last_history)
+            finally:
+                ao.set_dot_order(0)
+            oracle_time_iterations.last_history = ho_ref
         ao.set_threads(1)
         cpu = {"value": it_cpu / t_cpu, "unit": "iterations/s", "cores": threads, "kind": "port",
                "sample": f"{it_cpu} CG iterations of the same {G}^3 / {P ** 3}-subdomain problem (setup excluded), one host thread per subdomain"}
@@ -238,6 +275,16 @@ def main():
                                                            "amplifies rounding-level differences (full-length comparison: tests/test_gpu_fullsize.py at 96^3; DESIGN.md section 6)",
                                               "ok": bool(np.all(dev[:kcheck + 1] <= 1e-8)),
                                               "rel_dev_at": {str(k): float(dev[k]) for k in (1, 10, 20, 30, 40, 50, 60) if k < len(ho)}}
+            if ho_other is not None:
+                mo = min(len(ho), len(ho_other))
+                dev_oo = np.abs(ho_other[:mo] - ho[:mo]) / ho[:mo]
+                env_oo = np.maximum.accumulate(dev_oo)
+                ratio = dev[:mo] / np.maximum(1e-8, env_oo)
+                cpu["parity_first_iterations"]["oracle_vs_oracle_other_summation_order"] = {
+                    "what": "relative deviation of ||r_k|| between two ORACLE runs that differ only in the order of the additions inside the global dots "
+                            "(running maximum): the drift any two correct FP64 CG implementations show; hip_over_envelope = max_k dev_hip[k] / max(1e-8, envelope[k])",
+                    "envelope_at": {str(k): float(env_oo[k]) for k in (1, 10, 20, 30, 40, 50, 60) if k < mo},
+                    "hip_over_envelope": float(ratio.max()), "hip_within_30x_envelope": bool((dev[:mo] <= np.maximum(1e-8, 30.0 * env_oo)).all())}
             # with --cpu-iters beyond the iteration count (e.g. 320) the oracle history reaches the reduction as well: full-length
             # comparison at BASELINE size in the form tests/test_gpu_fullsize.py asserts at 96^3
             red = float(solve_info["reduction_target"]) if solve_info and "reduction_target" in solve_info else 1e-10
@@ -266,7 +313,7 @@ def main():
             "dof_iters_per_sec": ndof * its_per_s,
             "solve": solve_info,
             "setup_s": {"host": t_host, "device": t_dev},
-            "geneo": None if getattr(tl, "geneo_info", None) is None else {k: tl.geneo_info[k] for k in ("iterations", "converged", "worst_residual", "used_direct", "setup_s", "iterate_s", "nev")},
+            "geneo": None if getattr(tl, "geneo_info", None) is None else dict({k: tl.geneo_info[k] for k in ("iterations", "converged", "worst_residual", "used_direct", "setup_s", "iterate_s", "nev")}, host_check=geneo_check),
             "roofline": roofline, "iteration_traffic": iteration, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -34,35 +34,30 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--problem", default="dg", choices=["dg", "elasticity"], help="dg = BASELINE configs[3] (default), elasticity = configs[4]")
     ap.add_argument("--cells", type=int, default=512)
+    ap.add_argument("--refine", type=int, default=1, help="elasticity: refinement levels of the 80 x 8 x 12 bar (1 -> 205 275 DoF)")
     ap.add_argument("--nev", type=int, default=16)
     ap.add_argument("--restart", type=int, default=100)
     ap.add_argument("--local-solver", default="umfpack", choices=["umfpack", "ilu0"])
     ap.add_argument("--cpu-iters", type=int, default=20, help="GMRES iterations of the CPU oracle timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-solve", action="store_true", help="skip the full solve (profiling runs)")
+    ap.add_argument("--profile-counts", action="store_true", help="count every local solve of the run (event timers on from the start): the divisor of the per-kernel PMC totals")
     args = ap.parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import bench as _b
+        sys.exit(_b.launch_workers(args.gpus, __file__))      # this process becomes the launcher (see bench.py)
 
     import numpy as np
     import torch
     import __graft_entry__ as ge
+    import bench as _b
     pkg = ge.import_package()
-    pkg.load_library()
-    assert torch.cuda.is_available(), "bench_convdiff.py needs a HIP device: the hot path has no CPU fallback"
+    rank, world, local_rank, comm, backend, shared, ndev, dist = _b.init_distributed(args.gpus)
     from dune_ddm_amd import gmres_solve, synth
     from dune_ddm_amd.geneo import geneo_basis
     from dune_ddm_amd.problem import build_structured
-    from dune_ddm_amd.solver import TorchComm, TwoLevelSchwarz
-
-    torch.cuda.set_device(local_rank)
-    comm = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=os.environ.get("DDM_BACKEND", "nccl"), device_id=torch.device("cuda", local_rank))
-        comm = TorchComm()
+    from dune_ddm_amd.solver import TwoLevelSchwarz
 
     def barrier():
         if world > 1:
@@ -70,33 +65,55 @@ def main():
 
     t0 = time.perf_counter()
     C = args.cells
-    grid = synth.StructuredDG2D((C, C), (4, 2))
     assert 8 % world == 0
-    dec = build_structured(grid, overlap=2, neumann=True)
+    if args.problem == "dg":
+        grid = synth.StructuredDG2D((C, C), (4, 2))
+        dec = build_structured(grid, overlap=2, neumann=True)
+        cfg = dict(schwarz_type="standard", mode="additive", reduction=1e-8, tol=1e-5, nev=args.nev, local=args.local_solver)
+        workload = (f"Q1-DG convection-diffusion {C}x{C} cells = {grid.nglobal} DoF, 8 overlapping subdomains (4x2, overlap 2), local solver "
+                    f"'{args.local_solver}', GenEO nev {args.nev} on the symmetric part")
+    else:
+        # BASELINE.json configs[4] (examples/linearelasticity.cc + .ini): P1 elasticity on the 80 x 8 x 12 bar, refine levels,
+        # 8 subdomains, overlap 1, restricted Schwarz, multiplicative coarse level, `cholmod` local solves, GenEO with B = A_neu
+        grid = synth.StructuredElasticity(refine=args.refine, parts=8)
+        dec = build_structured(grid, overlap=1, neumann=True, second_region="all")
+        local = "cholmod" if args.local_solver == "umfpack" else args.local_solver
+        cfg = dict(schwarz_type="restricted", mode="multiplicative", reduction=1e-6, tol=1e-6, nev=min(args.nev, 12), local=local)
+        workload = (f"P1 linear elasticity on the 80x8x12 bar, refine {args.refine} = {grid.nglobal} DoF, 8 overlapping subdomains (overlap 1), local solver "
+                    f"'{local}', GenEO nev {cfg['nev']} (B = A_neu), restricted Schwarz")
     t_host = time.perf_counter() - t0
     t1 = time.perf_counter()
-    tl = TwoLevelSchwarz(dec, rank, world, local_rank, comm, schwarz_type="standard", mode="additive", coarse="none", subdomain_solver=args.local_solver)
-    basis = geneo_basis(tl, nev=args.nev, tol=1e-5)
+    tl = TwoLevelSchwarz(dec, rank, world, local_rank, comm, schwarz_type=cfg["schwarz_type"], mode=cfg["mode"], coarse="none", subdomain_solver=cfg["local"])
+    basis = geneo_basis(tl, nev=cfg["nev"], tol=cfg["tol"])
     tl.set_coarse_basis(basis)
-    tl.rebuild_combined("additive")
+    tl.rebuild_combined(cfg["mode"])
     tl.ctx.sync()
     t_dev = time.perf_counter() - t1
     gi = tl.geneo_info
     log(rank, f"{grid.nglobal} DoF; host setup {t_host:.1f} s, device setup {t_dev:.1f} s (GenEO {gi['iterations']} block iterations, "
-              f"{gi['setup_s'] + gi['iterate_s']:.1f} s); local solver '{args.local_solver}', engine {tl.schwarz.engine()}, K = {tl.K}")
+              f"{gi['setup_s'] + gi['iterate_s']:.1f} s); local solver '{cfg['local']}', engine {tl.schwarz.engine()}, K = {tl.K}")
 
-    res, hist, x = tl.solve(reduction=1e-8, maxit=1000, solver="restartedgmressolver", restart=args.restart)
-    gpu_hist = np.asarray(hist, dtype=float)
-    solve_info = {"iterations": int(res.iterations), "converged": bool(res.converged), "reduction": float(res.reduction), "solve_s": float(res.elapsed_s),
-                  "reduction_target": 1e-8}
-    log(rank, f"full solve: {res.iterations} GMRES iterations to 1e-8, {res.elapsed_s:.3f} s")
-    del x
+    solve_info, gpu_hist = None, None
+    solves_before = 0
+    if args.profile_counts:
+        tl.ctx.timing(True)
+        tl.ctx.timing_reset()
+    if not args.no_solve:
+        res, hist, x = tl.solve(reduction=cfg["reduction"], maxit=1000, solver="restartedgmressolver", restart=args.restart)
+        gpu_hist = np.asarray(hist, dtype=float)
+        solve_info = {"iterations": int(res.iterations), "converged": bool(res.converged), "reduction": float(res.reduction), "solve_s": float(res.elapsed_s),
+                      "reduction_target": cfg["reduction"]}
+        log(rank, f"full solve: {res.iterations} GMRES iterations to {cfg['reduction']:g}, {res.elapsed_s:.3f} s")
+        del x
 
     # ---- timed region: exactly K GMRES iterations (reduction 0: the solver runs to maxit) ------------------------------------------
     b = tl.to_device(tl.rl.b)
     x = tl.zeros(tl.rl.n_o)
     gmres_solve(tl.ctx, tl.op, tl.prec, x, b, 1e-300, args.warmup, args.restart, False)
     x.zero_()
+    if args.profile_counts:
+        tl.ctx.sync()
+        solves_before = tl.ctx.timer("Schwarz/local solve")[1]
     tl.ctx.timing(True)
     tl.ctx.timing_reset()
     barrier()
@@ -112,7 +129,7 @@ def main():
     local_ms, local_cnt = tl.ctx.timer("Schwarz/local solve")
     timers = {name: tl.ctx.timer(name) for name in ("Operator/apply", "Schwarz/local solve", "GalerkinPrec/apply", "CombinedPreconditioner/apply")}
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     its_per_s = args.steps / elapsed
@@ -122,17 +139,25 @@ def main():
     alg_bytes = 12.0 * zf + 40.0 * n
     avg_ms = local_ms / max(local_cnt, 1)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "local solve: " + ("sparse L U factor, level-scheduled CSR kernels with supernodal blocks (k_trsv_csr_level)" if args.local_solver != "ilu0" else "ILU(0) triangular solve"),
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+    traffic, traffic_source = None, None
+    try:   # HBM bytes of ONE local solve (all its level launches) from the committed rocprofv3 --pmc passes of this command: NOT measured in this run
+        src = f"profiles/r03_pmc_traffic_{args.problem}.json"
+        pmc = json.load(open(os.path.join(ROOT, src)))
+        if pmc.get("cells") == (C if args.problem == "dg" else None) and pmc.get("refine") == (None if args.problem == "dg" else args.refine) and cfg["local"] == pmc.get("local_solver"):
+            traffic, traffic_source = pmc["local_solve_hbm_bytes_corrected"] / world, src
+    except Exception:
+        traffic = None
+    roofline = {"bound": "hbm", "kernel": "local solve: " + ("sparse direct factor, level-scheduled CSR kernels with supernodal blocks (k_trsv_csr_level)" if cfg["local"] != "ilu0" else "ILU(0) triangular solve"),
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches_timed": int(local_cnt)}
 
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_iters > 0:
+    if rank == 0 and world == 1 and args.cpu_iters > 0 and gpu_hist is not None:
         from oracle import apply_oracle as ao
         from tests.oracle_bridge import oracle_objects
         ao.set_threads(min(8, os.cpu_count() or 1))
-        op, sp_, prec, sch, gal = oracle_objects(dec, coarse=tl.host_basis(), schwarz_type="standard", mode="additive",
-                                                 local_solver="ilu0" if args.local_solver == "ilu0" else "direct")
+        op, sp_, prec, sch, gal = oracle_objects(dec, coarse=tl.host_basis(), schwarz_type=cfg["schwarz_type"], mode=cfg["mode"],
+                                                 local_solver="ilu0" if cfg["local"] == "ilu0" else "direct")
         xo = [np.zeros(sd.n_o) for sd in dec.subs]
         bo = [sd.b.copy() for sd in dec.subs]
         tc = time.perf_counter()
@@ -151,15 +176,17 @@ def main():
         log(rank, f"cpu_baseline: {it_cpu} iterations in {t_cpu:.1f} s; parity over {m - 1} iterations: max rel. dev {dev.max():.2e}")
 
     if rank == 0:
-        out = {"metric": "preconditioned GMRES iterations/sec (two-level additive Schwarz + GenEO), convection-diffusion DG 1M DoF",
+        out = {"metric": "preconditioned GMRES iterations/sec (two-level Schwarz + GenEO), " + ("convection-diffusion DG 1M DoF" if args.problem == "dg" else "3D linear elasticity"),
                "value": its_per_s, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": f"Q1-DG convection-diffusion {C}x{C} cells = {grid.nglobal} DoF, 8 overlapping subdomains (4x2, overlap 2), local solver "
-                                      f"'{args.local_solver}', GenEO nev {args.nev} on the symmetric part (K = {tl.K}), additive, GMRES({args.restart})",
-                          "subdomains_per_gpu": 8 // world, "parallelism": f"dd{world}"},
+               "backend": "none (single rank)" if world == 1 else ("nccl (RCCL)" if backend == "nccl" else backend), "exchange": tl.exchange,
+               "rccl_comm_size": tl.ctx.rccl_size(), "ranks_share_devices": bool(shared),
+               "config": {"workload": workload + f" (K = {tl.K}), {cfg['mode']}, GMRES({args.restart})",
+                          "problem": args.problem, "cells": C if args.problem == "dg" else None, "refine": args.refine if args.problem == "elasticity" else None,
+                          "local_solver": cfg["local"], "subdomains_per_gpu": 8 // world, "parallelism": f"dd{world}"},
                "dof_iters_per_sec": grid.nglobal * its_per_s, "solve": solve_info, "setup_s": {"host": t_host, "device": t_dev},
                "geneo": {k: gi[k] for k in ("iterations", "converged", "worst_residual", "used_direct", "setup_s", "iterate_s", "nev")},
-               "roofline": roofline, "phase_ms_per_iteration": {nm: (v[0] / max(v[1], 1)) for nm, v in timers.items()}, "cpu_baseline": cpu}
+               "roofline": roofline, "local_solves_in_run": (int(solves_before + local_cnt) if args.profile_counts else None), "phase_ms_per_iteration": {nm: (v[0] / max(v[1], 1)) for nm, v in timers.items()}, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     tl.ctx.close()
     if world > 1:

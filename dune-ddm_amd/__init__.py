@@ -59,6 +59,7 @@ SYMBOLS = {
     "ddm_ctx_destroy": (None, [_P]),
     "ddm_last_error": (ctypes.c_char_p, [_P]),
     "ddm_ctx_sync": (_I32, [_P]),
+    "ddm_ctx_fence": (_I32, [_P]),
     "ddm_ctx_stream": (_P, [_P]),
     "ddm_ctx_set_comm": (_I32, [_P, _I32, _I32, A2A_FN, ALLREDUCE_FN, _P]),
     "ddm_rccl_unique_id": (_I32, [_P]),
@@ -66,6 +67,7 @@ SYMBOLS = {
     "ddm_ctx_rccl_size": (_I32, [_P, ctypes.POINTER(ctypes.c_int)]),
     "ddm_malloc": (_I32, [_P, _I64, _PP]),
     "ddm_free": (_I32, [_P, _P]),
+    "ddm_memset_zero": (_I32, [_P, _P, _I64]),
     "ddm_memcpy_h2d": (_I32, [_P, _P, _P, _I64]),
     "ddm_memcpy_d2h": (_I32, [_P, _P, _P, _I64]),
     "ddm_csr_create": (_I32, [_P, _I64, _I64, _P, _P, _P, _PP]),

@@ -64,6 +64,7 @@ struct ddm_ctx {
   bool timing = false;
   std::map<std::string, TimerEntry> timers;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev_fence = nullptr; // ddm_ctx_fence
 };
 
 static int fail(ddm_ctx *ctx, int code, const char *fmt, ...)
@@ -208,6 +209,7 @@ extern "C" void ddm_ctx_destroy(ddm_ctx *ctx)
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->partial);
   (void)hipFree(ctx->scal);
+  if (ctx->ev_fence) (void)hipEventDestroy(ctx->ev_fence);
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -217,6 +219,17 @@ extern "C" const char *ddm_last_error(const ddm_ctx *ctx) { return ctx ? ctx->er
 extern "C" int ddm_ctx_sync(ddm_ctx *ctx)
 {
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return DDM_OK;
+}
+// host waits for the work enqueued on the context's stream SO FAR (an event, not a drain of the stream: work another thread or a
+// later call enqueues meanwhile is not waited for, the side stream is left alone) -- what an exchange callback needs before it
+// hands the packed buffer to a host-driven transport (MPI)
+extern "C" int ddm_ctx_fence(ddm_ctx *ctx)
+{
+  if (!ctx) return DDM_EINVAL;
+  if (!ctx->ev_fence) HIPCHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fence, hipEventDisableTiming));
+  HIPCHECK(ctx, hipEventRecord(ctx->ev_fence, ctx->stream));
+  HIPCHECK(ctx, hipEventSynchronize(ctx->ev_fence));
   return DDM_OK;
 }
 extern "C" void *ddm_ctx_stream(ddm_ctx *ctx) { return (void *)ctx->stream; }
@@ -319,6 +332,12 @@ extern "C" int ddm_malloc(ddm_ctx *ctx, int64_t bytes, void **dptr)
 extern "C" int ddm_free(ddm_ctx *ctx, void *dptr)
 {
   HIPCHECK(ctx, hipFree(dptr));
+  return DDM_OK;
+}
+extern "C" int ddm_memset_zero(ddm_ctx *ctx, void *dptr, int64_t bytes)
+{
+  if (!dptr || bytes < 0) return fail(ctx, DDM_EINVAL, "ddm_memset_zero: bad arguments");
+  HIPCHECK(ctx, hipMemsetAsync(dptr, 0, (size_t)bytes, ctx->stream));
   return DDM_OK;
 }
 extern "C" int ddm_memcpy_h2d(ddm_ctx *ctx, void *dst, const void *src, int64_t bytes)

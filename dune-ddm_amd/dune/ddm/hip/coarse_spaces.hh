@@ -231,7 +231,9 @@ public:
     this->setup_task = taskflow.emplace([pou, this] { build(std::vector<Vec>(), *pou); }).name("POU coarse space setup");
   }
 #endif
-  // :1211-1231: POU-scaled template vectors (TwoLevelSchwarzSolver uses 1, x, y, xy: twolevel_schwarz.hh:68-107)
+  // :1211-1224: the same without a task
+  explicit POUCoarseSpace(const PartitionOfUnity& pou) { build(std::vector<Vec>(), pou); }
+  // :1226-1230: POU-scaled template vectors (TwoLevelSchwarzSolver uses 1, x, y, xy: twolevel_schwarz.hh:68-107)
   POUCoarseSpace(const std::vector<Vec>& template_vecs, const PartitionOfUnity& pou) { build(template_vecs, pou); }
 
 private:

@@ -7,6 +7,7 @@
 //                over the ranks (gatherMatrixFromRowsFlat, helpers.hh:204-339, replicated).
 #pragma once
 
+#include <cmath>
 #include <memory>
 #include <numeric>
 #include <string>
@@ -20,37 +21,95 @@
 #include "backend.hh"
 
 namespace ddm_hip {
-// dense inverse by Gauss-Jordan with partial pivoting (K <= a few hundred; setup only)
-inline std::vector<double> invert(std::vector<double> a, int K)
+// The coarse solver behind `solver->apply` on rank 0 of the reference (galerkin_preconditioner.hh:49,178,338-346), chosen by the
+// `type` key of the coarse sub-tree through the dune-istl factory.  Here every rank holds the replicated dense K x K matrix and
+// applies its explicit inverse on the device (ddm_galerkin_apply: k_dense_mv), so the factory key selects the dense
+// factorisation the inverse is formed from:
+//   umfpack | superlu | spqr | hip_lu | lu          L U with partial pivoting (row interchanges), any non-singular A0
+//   cholmod | ldl | hip_cholesky | cholesky         L L^T, A0 must be symmetric positive definite (Dune::Exception otherwise,
+//                                                   as CHOLMOD reports "not positive definite")
+// Iterative factory entries (cgsolver, ...) have no meaning for the replicated explicit inverse: Dune::NotImplemented.
+inline std::vector<double> invert_lu(std::vector<double> a, int K)
 {
-  std::vector<double> inv((std::size_t)K * K, 0.0);
-  for (int i = 0; i < K; ++i) inv[(std::size_t)i * K + i] = 1.0;
+  std::vector<int> piv(K);
   for (int c = 0; c < K; ++c) {
     int p = c;
     for (int r = c + 1; r < K; ++r)
       if (std::abs(a[(std::size_t)r * K + c]) > std::abs(a[(std::size_t)p * K + c])) p = r;
     if (a[(std::size_t)p * K + c] == 0.0) DUNE_THROW(Dune::Exception, "coarse matrix R A R^T is singular");
+    piv[c] = p;
     if (p != c)
-      for (int j = 0; j < K; ++j) {
-        std::swap(a[(std::size_t)p * K + j], a[(std::size_t)c * K + j]);
-        std::swap(inv[(std::size_t)p * K + j], inv[(std::size_t)c * K + j]);
-      }
+      for (int j = 0; j < K; ++j) std::swap(a[(std::size_t)p * K + j], a[(std::size_t)c * K + j]);
     const double d = 1.0 / a[(std::size_t)c * K + c];
-    for (int j = 0; j < K; ++j) {
-      a[(std::size_t)c * K + j] *= d;
-      inv[(std::size_t)c * K + j] *= d;
-    }
-    for (int r = 0; r < K; ++r) {
-      if (r == c) continue;
-      const double f = a[(std::size_t)r * K + c];
+    for (int r = c + 1; r < K; ++r) {
+      const double f = a[(std::size_t)r * K + c] * d;
+      a[(std::size_t)r * K + c] = f;
       if (f == 0.0) continue;
-      for (int j = 0; j < K; ++j) {
-        a[(std::size_t)r * K + j] -= f * a[(std::size_t)c * K + j];
-        inv[(std::size_t)r * K + j] -= f * inv[(std::size_t)c * K + j];
-      }
+      for (int j = c + 1; j < K; ++j) a[(std::size_t)r * K + j] -= f * a[(std::size_t)c * K + j];
     }
   }
+  // the inverse row by row: solve L U X = P I (the right-hand sides are the rows of the permuted identity)
+  std::vector<double> inv((std::size_t)K * K, 0.0);
+  for (int i = 0; i < K; ++i) inv[(std::size_t)i * K + i] = 1.0;
+  for (int c = 0; c < K; ++c)
+    if (piv[c] != c)
+      for (int j = 0; j < K; ++j) std::swap(inv[(std::size_t)piv[c] * K + j], inv[(std::size_t)c * K + j]);
+  for (int r = 1; r < K; ++r)
+    for (int c = 0; c < r; ++c) {
+      const double f = a[(std::size_t)r * K + c];
+      if (f == 0.0) continue;
+      for (int j = 0; j < K; ++j) inv[(std::size_t)r * K + j] -= f * inv[(std::size_t)c * K + j];
+    }
+  for (int r = K - 1; r >= 0; --r) {
+    for (int c = r + 1; c < K; ++c) {
+      const double f = a[(std::size_t)r * K + c];
+      if (f == 0.0) continue;
+      for (int j = 0; j < K; ++j) inv[(std::size_t)r * K + j] -= f * inv[(std::size_t)c * K + j];
+    }
+    const double d = 1.0 / a[(std::size_t)r * K + r];
+    for (int j = 0; j < K; ++j) inv[(std::size_t)r * K + j] *= d;
+  }
   return inv;
+}
+inline std::vector<double> invert_cholesky(std::vector<double> a, int K)
+{
+  for (int c = 0; c < K; ++c) {   // a = L L^T, L in the lower triangle
+    double d = a[(std::size_t)c * K + c];
+    for (int k = 0; k < c; ++k) d -= a[(std::size_t)c * K + k] * a[(std::size_t)c * K + k];
+    if (!(d > 0.0)) DUNE_THROW(Dune::Exception, "coarse matrix R A R^T is not positive definite (this coarse solver type needs an SPD matrix; use umfpack)");
+    const double l = std::sqrt(d);
+    a[(std::size_t)c * K + c] = l;
+    for (int r = c + 1; r < K; ++r) {
+      double v = a[(std::size_t)r * K + c];
+      for (int k = 0; k < c; ++k) v -= a[(std::size_t)r * K + k] * a[(std::size_t)c * K + k];
+      a[(std::size_t)r * K + c] = v / l;
+    }
+  }
+  std::vector<double> inv((std::size_t)K * K, 0.0);
+  for (int i = 0; i < K; ++i) inv[(std::size_t)i * K + i] = 1.0;
+  for (int r = 0; r < K; ++r) {   // L Y = I
+    for (int c = 0; c < r; ++c) {
+      const double f = a[(std::size_t)r * K + c];
+      for (int j = 0; j <= c; ++j) inv[(std::size_t)r * K + j] -= f * inv[(std::size_t)c * K + j];
+    }
+    const double d = 1.0 / a[(std::size_t)r * K + r];
+    for (int j = 0; j <= r; ++j) inv[(std::size_t)r * K + j] *= d;
+  }
+  for (int r = K - 1; r >= 0; --r) {   // L^T X = Y
+    for (int c = r + 1; c < K; ++c) {
+      const double f = a[(std::size_t)c * K + r];
+      for (int j = 0; j < K; ++j) inv[(std::size_t)r * K + j] -= f * inv[(std::size_t)c * K + j];
+    }
+    const double d = 1.0 / a[(std::size_t)r * K + r];
+    for (int j = 0; j < K; ++j) inv[(std::size_t)r * K + j] *= d;
+  }
+  return inv;
+}
+inline std::vector<double> coarse_inverse(const std::vector<double>& a0, int K, const std::string& type)
+{
+  if (type == "umfpack" || type == "superlu" || type == "spqr" || type == "hip_lu" || type == "lu") return invert_lu(a0, K);
+  if (type == "cholmod" || type == "ldl" || type == "hip_cholesky" || type == "cholesky") return invert_cholesky(a0, K);
+  DUNE_THROW(Dune::NotImplemented, "coarse solver type '" + type + "': the replicated device coarse solve takes the direct solvers of the factory (umfpack, superlu, spqr, cholmod, ldl)");
 }
 }  // namespace ddm_hip
 
@@ -59,10 +118,15 @@ class GalerkinPreconditioner : public Dune::Preconditioner<Vec, Vec>, public ddm
 public:
   // reference ctor: galerkin_preconditioner.hh:118-144
   template <class Mat>
-  GalerkinPreconditioner(const Mat& A, const std::vector<Vec>& ts, std::shared_ptr<Communication> comm, const Dune::ParameterTree& /*ptree*/,
-                         const std::string& /*subtree_name*/ = "galerkin")
+  GalerkinPreconditioner(const Mat& A, const std::vector<Vec>& ts, std::shared_ptr<Communication> comm, const Dune::ParameterTree& ptree,
+                         const std::string& subtree_name = "galerkin")
       : comm(std::move(comm)), n(A.N()), num_t((int)ts.size()), ctx(ddm_hip::Context::get())
   {
+    // the coarse solver's factory key (:338-346), checked before any work like every other configuration error
+    const auto& subtree = subtree_name.size() == 0 ? ptree : ptree.sub(subtree_name);
+    if (not subtree.hasKey("type")) DUNE_THROW(Dune::Exception, "You must specify the solver in the subtree " << subtree_name << " using the key 'type'");   // :344-345
+    coarse_solver_type = subtree.get("type", std::string(""));
+    (void)ddm_hip::coarse_inverse(std::vector<double>{1.0}, 1, coarse_solver_type);   // unknown type: throws here
     ctx->require(this->comm->communicator());
     if (ts.size() == 0) DUNE_THROW(Dune::Exception, "Must at least pass one template vector");              // :129
     if (ts[0].N() != A.N()) DUNE_THROW(Dune::Exception, "Template vectors must match size of matrix");      // :131
@@ -74,7 +138,7 @@ public:
     offset_per_rank.assign(size, 0);
     std::exclusive_scan(num_t_per_rank.begin(), num_t_per_rank.end(), offset_per_rank.begin(), 0);           // :256
     const int kmax = *std::max_element(num_t_per_rank.begin(), num_t_per_rank.end());
-    if (kmax > 64) DUNE_THROW(Dune::NotImplemented, "more than 64 coarse vectors per subdomain");
+    if (kmax > 256) DUNE_THROW(Dune::NotImplemented, "more than 256 coarse vectors per subdomain");   // COARSE_KMAX of the library
 
     // basis as kmax x n row-major (zero rows beyond num_t), copied like restr_vecs (:138-139)
     basis.assign((std::size_t)kmax * n, 0.0);
@@ -137,21 +201,18 @@ private:
       } one;
       one.m.emplace(nbr, std::make_pair(info.first, info.second));
       ddm_hip::Halo h(ctx, tag++, 0, one);
-      std::vector<double> host((std::size_t)kmax * n, 0.0), mask(n, 0.0);
-      for (std::size_t i = 0; i < info.second.size(); ++i) mask[info.second[i]] = 1.0;
-      ddm_hip::check(ctx->handle(), ddm_memcpy_h2d(ctx->handle(), V.data(), basis.data(), (int64_t)(basis.size() * sizeof(double))), "h2d");
-      for (int j = 0; j < kmax; ++j) ddm_hip::check(ctx->handle(), ddm_halo_exchange(ctx->handle(), h.handle(), V.data() + (std::size_t)j * n), "basis exchange");
-      ddm_hip::check(ctx->handle(), ddm_memcpy_d2h(ctx->handle(), host.data(), V.data(), (int64_t)(host.size() * sizeof(double))), "d2h");
+      // V_j = the neighbour's vector j on the shared indices, zero elsewhere (CopyGatherScatterWithRank, :66-103): pack from R,
+      // unpack into the zeroed V -- all on the device (round 2 moved the whole basis over PCIe three times per neighbour for this)
+      ddm_hip::check(ctx->handle(), ddm_memset_zero(ctx->handle(), V.data(), (int64_t)(basis.size() * sizeof(double))), "zero");
       for (int j = 0; j < kmax; ++j)
-        for (std::size_t i = 0; i < n; ++i) host[(std::size_t)j * n + i] *= mask[i];   // zero outside the shared indices (:96-101)
-      ddm_hip::check(ctx->handle(), ddm_memcpy_h2d(ctx->handle(), V.data(), host.data(), (int64_t)(host.size() * sizeof(double))), "h2d");
+        ddm_hip::check(ctx->handle(), ddm_halo_exchange_to(ctx->handle(), h.handle(), R.data() + (std::size_t)j * n, V.data() + (std::size_t)j * n), "basis exchange");
       ddm_hip::check(ctx->handle(), ddm_galerkin_products(ctx->handle(), dA->handle(), kmax, R.data(), kmax, V.data(), 0, (int64_t)n, blk.data()), "galerkin products");
       for (int i = 0; i < num_t; ++i)
         for (int j = 0; j < num_t_per_rank[nbr]; ++j) A0[(std::size_t)(offset_per_rank[rank] + i) * K + offset_per_rank[nbr] + j] = blk[(std::size_t)j * kmax + i];
     }
     comm->communicator().sum(A0.data(), (int)A0.size());   // every rank gets the full K x K matrix (replaces the gather to rank 0, :331)
     (void)size;
-    A0inv = ddm_hip::invert(A0, K);
+    A0inv = ddm_hip::coarse_inverse(A0, K, coarse_solver_type);
   }
 
   void create(std::size_t n_novlp)
@@ -178,6 +239,7 @@ private:
   std::vector<int> num_t_per_rank, offset_per_rank;
   std::shared_ptr<ddm_hip::Context> ctx;
   std::vector<double> basis, A0, A0inv;
+  std::string coarse_solver_type;
   std::unique_ptr<ddm_hip::DeviceCsr> dA;
   std::unique_ptr<ddm_hip::Halo> h_copy, h_add;
   std::unique_ptr<ddm_hip::DeviceVector> dd, dx;

@@ -4,6 +4,9 @@
 // Counterparts in the reference: the MPI calls behind comm->copyOwnerToAll / addOwnerCopyToOwnerCopy / addOwnerCopyToAll
 // (schwarz.hh:125,138,142; nonoverlapping_operator.hh:38,48; galerkin_preconditioner.hh:162,190), comm->dot (MPI_Allreduce) and
 // MPI_Gatherv / MPI_Scatterv of the coarse defect (galerkin_preconditioner.hh:171,183).
+// MPI is driven from the host, so each callback has to wait until the data it sends exists: one event wait (ddm_ctx_fence) per
+// exchange -- 3 halos + 4 reductions per CG iteration.  That cost is inherent to a host-driven transport; the exchange without
+// any host involvement is ddm_ctx_set_rccl (everything enqueued on the stream).
 // Call once, before constructing any operator:   ddm_hip::install_mpi_exchange(MPI_COMM_WORLD, device);
 // (Alternative without MPI in the data path: ddm_ctx_set_rccl, include/ddm_hip.h -- RCCL over xGMI inside the library.)
 #pragma once
@@ -29,7 +32,7 @@ inline int mpi_alltoall_cb(void* user, int tag, const double* sendbuf, double* r
   const auto it = x.ctx->halo_counts.find(tag);
   if (it == x.ctx->halo_counts.end()) return 1;
   const auto& c = it->second;
-  if (ddm_ctx_sync(x.ctx->handle()) != DDM_OK) return 1;   // the pack kernel has finished
+  if (ddm_ctx_fence(x.ctx->handle()) != DDM_OK) return 1;   // event wait: the pack kernel enqueued before this callback has finished
   const int P = (int)c.send_counts.size();
   int64_t ns = 0, nr = 0;
   for (int r = 0; r < P; ++r) { ns += c.send_counts[r]; nr += c.recv_counts[r]; }
@@ -62,7 +65,7 @@ inline int mpi_alltoall_cb(void* user, int tag, const double* sendbuf, double* r
 inline int mpi_allreduce_cb(void* user, double* buf, int64_t n)
 {
   auto& x = *static_cast<MpiExchange*>(user);
-  if (ddm_ctx_sync(x.ctx->handle()) != DDM_OK) return 1;
+  if (ddm_ctx_fence(x.ctx->handle()) != DDM_OK) return 1;   // the partial sums are in `buf`
 #ifdef DDM_HIP_STAGE_THROUGH_HOST
   x.hsend.resize(n);
   if (ddm_memcpy_d2h(x.ctx->handle(), x.hsend.data(), buf, n * 8) != DDM_OK) return 1;

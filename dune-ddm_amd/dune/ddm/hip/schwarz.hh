@@ -9,9 +9,14 @@
 #include <dune/common/parallel/interface.hh>
 #include <dune/common/parametertree.hh>
 #include <dune/istl/preconditioner.hh>
+#include <dune/istl/solver.hh>
 #include <dune/istl/solvercategory.hh>
 
 #include <dune/ddm/pou.hh>
+
+#if DUNE_DDM_HAVE_TASKFLOW
+#include <taskflow/taskflow.hpp>
+#endif
 
 #include "backend.hh"
 
@@ -21,6 +26,41 @@ enum class SchwarzType : std::uint8_t { Standard, Restricted };
 // unchanged); only size() and operator[] are needed here.
 template <class Mat, class Vec, class Communication>
 class SchwarzPreconditioner : public Dune::Preconditioner<Vec, Vec>, public ddm_hip::DeviceLevel {
+  using Solver = Dune::InverseOperator<Vec, Vec>;   // schwarz.hh:57
+
+  // What getSolver() hands out (schwarz.hh:155): the local solver `A_dir^-1` on the OVERLAPPING index set as a
+  // Dune::InverseOperator.  It is a view of the factor inside the ddm_schwarz object (ddm_schwarz_local_solver), not a second
+  // factorisation; apply() = one upload, ddm_ilu0_solve, one download.
+  class LocalSolverView : public Solver {
+  public:
+    explicit LocalSolverView(SchwarzPreconditioner& owner) : P(owner) {}
+    Dune::SolverCategory::Category category() const override { return Dune::SolverCategory::sequential; }
+    void apply(Vec& x, Vec& b, Dune::InverseOperatorResult& res) override
+    {
+      const std::size_t n = P.Aovlp->N();
+      if (b.N() != n || x.N() != n) DUNE_THROW(Dune::InvalidStateException, "local solver: vectors must live on the overlapping index set (size " << n << ")");
+      if (!P.S) P.create(P.novlp_comm ? P.novlp_comm->indexSet().size() : n);
+      if (!bd) {
+        bd = std::make_unique<ddm_hip::DeviceVector>(P.ctx, n);
+        xd = std::make_unique<ddm_hip::DeviceVector>(P.ctx, n);
+      }
+      bd->upload(b);
+      ddm_ilu0* F = ddm_schwarz_local_solver(P.S);
+      ddm_hip::check(P.ctx->handle(), ddm_ilu0_solve(P.ctx->handle(), F, bd->data(), xd->data()), "ddm_ilu0_solve");
+      xd->download(x);
+      int st = 0;
+      ddm_hip::check(P.ctx->handle(), ddm_ilu0_status(P.ctx->handle(), F, &st), "ddm_ilu0_status");
+      res.clear();
+      res.iterations = 1;
+      res.converged = st == 0;
+    }
+    void apply(Vec& x, Vec& b, [[maybe_unused]] double reduction, Dune::InverseOperatorResult& res) override { apply(x, b, res); }
+
+  private:
+    SchwarzPreconditioner& P;
+    std::unique_ptr<ddm_hip::DeviceVector> bd, xd;
+  };
+
 public:
   // reference ctor: schwarz.hh:73-94
   SchwarzPreconditioner(std::shared_ptr<Mat> Aovlp, std::shared_ptr<Communication> comm, std::shared_ptr<PartitionOfUnity> pou,
@@ -61,7 +101,8 @@ public:
   Dune::SolverCategory::Category category() const override { return Dune::SolverCategory::nonoverlapping; }
   void pre(Vec&, Vec&) override {}
   // apply() has no error return (the reference discards the local solver's InverseOperatorResult, schwarz.hh:131): a local solve
-  // that gave up (single-launch engine, GPU shared with another process) is reported here, at the end of the Krylov solve
+  // that gave up (single-launch engine, GPU shared with another process) makes the NEXT apply throw (ddm_schwarz_apply looks at
+  // the status word in pinned host memory on entry, no synchronisation) and is reported here at the latest
   void post(Vec&) override
   {
     if (S) ddm_hip::check(ctx->handle(), ddm_schwarz_status(ctx->handle(), S), "SchwarzPreconditioner::post");
@@ -82,6 +123,20 @@ public:
   }
   ddm_hip::Halo& copyHalo() { return *h_copy; }
   ddm_hip::Halo& addHalo() { return *h_add; }
+
+  // reference schwarz.hh:155: reference to the local subdomain solver
+  Solver& getSolver()
+  {
+    if (!solver_view) solver_view = std::make_unique<LocalSolverView>(*this);
+    return *solver_view;
+  }
+#if DUNE_DDM_HAVE_TASKFLOW
+  // reference schwarz.hh:162 (a default-constructed tf::Task there, too: the constructor does the whole setup)
+  tf::Task& get_setup_task() { return setup_task; }
+#endif
+  // reference schwarz.hh:165: public data member, set by TwoLevelSchwarzSolver (twolevel_schwarz.hh:109); here it also tells the
+  // device object the non-overlapping size before the first defect vector arrives
+  std::shared_ptr<Communication> novlp_comm;
 
 private:
   // The non-overlapping size is only known from the first defect vector ("extend" is a prefix copy,
@@ -114,5 +169,9 @@ private:
   std::unique_ptr<ddm_hip::DeviceCsr> dA;
   std::unique_ptr<ddm_hip::Halo> h_copy, h_add;
   std::unique_ptr<ddm_hip::DeviceVector> dd, dx;
+  std::unique_ptr<LocalSolverView> solver_view;
+#if DUNE_DDM_HAVE_TASKFLOW
+  tf::Task setup_task;
+#endif
   ddm_schwarz* S = nullptr;
 };

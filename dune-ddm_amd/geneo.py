@@ -95,3 +95,34 @@ def geneo_basis(tl, nev=20, tol=1e-5, shift=1e-3, maxit=400, extra=4, seed=0, ve
         a, b = int(rl.block_ptr[i]), int(rl.block_ptr[i + 1])
         out[sd.id] = np.ascontiguousarray(basis[:int(nconv[i]), a:b])
     return (out, info) if return_info else out
+
+
+def host_eigenpair_residuals(sd, vectors, eigenvalues):
+    """Independent host check (scipy only, nothing of the device path) of the GenEO pairs of ONE subdomain as ``geneo_basis`` returns
+    them: vectors v_j = D x_j / ||D x_j||_2 (D = diag(pou), Dirichlet entries zero) and eigenvalues lambda_j of
+    A_neu x = lambda D B_neu D x (coarse_spaces.hh:319-331).  The eigenvector itself is recovered from v: x = v / pou where pou > 0;
+    on the rows G with pou = 0 (the subdomain boundary) the pencil's right-hand side vanishes, so those rows of the eigen-equation read
+    A_GG x_G = -A_GI x_I and determine x_G (sparse LU of the small boundary block).  Returns for every pair
+        || A_neu x - lambda D B_neu D x ||_2 / || lambda D B_neu D x ||_2      (rows with pou > 0; the G rows hold by construction)
+    and the relative mismatch of the Rayleigh quotient (x^T A x) / (x^T D B D x) with lambda."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    A = sp.csr_matrix(sd.A_neu)
+    B = sp.csr_matrix(sd.B_neu)
+    pou = np.asarray(sd.pou, dtype=np.float64)
+    V = np.asarray(vectors, dtype=np.float64)
+    lam = np.asarray(eigenvalues, dtype=np.float64)[:V.shape[0]]
+    I = np.nonzero(pou > 0)[0]
+    G = np.nonzero(pou <= 0)[0]
+    X = np.zeros((A.shape[0], V.shape[0]))
+    X[I] = (V[:, I] / pou[I][None, :]).T
+    if len(G):
+        AGG = A[G][:, G].tocsc()
+        rhs = -(A[G][:, I] @ X[I])
+        X[G] = spl.splu(AGG).solve(np.ascontiguousarray(rhs))
+    AX = A @ X
+    CX = pou[:, None] * (B @ (pou[:, None] * X))
+    R = AX - CX * lam[None, :]
+    res = np.linalg.norm(R[I], axis=0) / np.linalg.norm(CX * lam[None, :], axis=0)
+    rq = np.einsum("ij,ij->j", X, AX) / np.einsum("ij,ij->j", X, CX)
+    return res, np.abs(rq - lam) / np.abs(lam)

@@ -47,6 +47,9 @@ int ddm_ctx_create(int device, void *hip_stream, ddm_ctx **out);
 void ddm_ctx_destroy(ddm_ctx *ctx);
 const char *ddm_last_error(const ddm_ctx *ctx);
 int ddm_ctx_sync(ddm_ctx *ctx); /* hipStreamSynchronize */
+/* the host waits for the work enqueued on the context's stream so far (event record + wait; later work is not waited for):
+ * what an exchange callback of a host-driven transport (MPI) calls before it touches the packed send buffer */
+int ddm_ctx_fence(ddm_ctx *ctx);
 void *ddm_ctx_stream(ddm_ctx *ctx);
 
 /* Inter-rank exchange is delegated to the host program (MPI in a DUNE build, torch.distributed
@@ -74,6 +77,7 @@ int ddm_ctx_rccl_size(ddm_ctx *ctx, int *count);
 /* raw device memory helpers for callers that do not bring their own allocator */
 int ddm_malloc(ddm_ctx *ctx, int64_t bytes, void **dptr);
 int ddm_free(ddm_ctx *ctx, void *dptr);
+int ddm_memset_zero(ddm_ctx *ctx, void *dptr, int64_t bytes);                 /* enqueued on the context's stream */
 int ddm_memcpy_h2d(ddm_ctx *ctx, void *dst, const void *src, int64_t bytes); /* synchronous */
 int ddm_memcpy_d2h(ddm_ctx *ctx, void *dst, const void *src, int64_t bytes); /* synchronous */
 

@@ -45,6 +45,8 @@ def lib():
         L.orc_ilu0_solve.argtypes = [I, P, P, P, P, P, P]
         L.orc_masked_dot.argtypes = [I, P, P, P]
         L.orc_masked_dot.restype = D
+        L.orc_masked_dot_order.argtypes = [I, P, P, P, ctypes.c_int]
+        L.orc_masked_dot_order.restype = D
         L.orc_dot.argtypes = [I, P, P]
         L.orc_dot.restype = D
         L.orc_axpy.argtypes = [I, D, P, P]
@@ -85,6 +87,17 @@ def pfor(fn, n):
     else:
         for r in range(n):
             fn(r)
+
+
+# Summation order of the global dot products: 0 = the reference's (ascending index, ascending rank).  1 / 2 are used by the
+# order-sensitivity tests only (see orc_masked_dot_order in kernels.c).
+DOT_ORDER = 0
+
+
+def set_dot_order(order):
+    global DOT_ORDER
+    assert order in (0, 1, 2)
+    DOT_ORDER = int(order)
 
 
 class Csr:
@@ -165,7 +178,14 @@ class Comm:
 
     def dot(self, xs, ys):
         """OwnerOverlapCopyCommunication::dot: owner-masked local sums + MPI_Allreduce(SUM)
-        (ranks added in rank order here)."""
+        (ranks added in rank order here).  DOT_ORDER != 0 (set_dot_order; NOT reference semantics, order-sensitivity tests only):
+        the same sums with the additions in another order -- 1: descending index and rank, 2: pairwise."""
+        if DOT_ORDER:
+            parts = [lib().orc_masked_dot_order(len(xs[r]), _p(self.owner[r]), _p(xs[r]), _p(ys[r]), DOT_ORDER) for r in range(self.nranks)]
+            tot = 0.0
+            for v in (reversed(parts) if DOT_ORDER == 1 else parts):
+                tot += v
+            return tot
         tot = 0.0
         for r in range(self.nranks):
             tot += lib().orc_masked_dot(len(xs[r]), _p(self.owner[r]), _p(xs[r]), _p(ys[r]))

@@ -97,6 +97,33 @@ double orc_masked_dot(i64 n, const uint8_t *owner, const double *x, const double
   return s;
 }
 
+/* The same owner-masked sum in two OTHER summation orders -- not reference semantics: they exist so that the tests can show how far
+ * two correct FP64 implementations of the same CG drift apart when only the order of the additions inside the global dot products
+ * differs (tests/test_oracle_order_sensitivity.py; the HIP path sums wavefront-wise, the reference index by index).
+ *   order 1: descending index;  order 2: pairwise (recursive halving, blocks of 64 summed ascending) */
+static double masked_pairwise(const uint8_t *owner, const double *x, const double *y, i64 lo, i64 hi)
+{
+  if (hi - lo <= 64) {
+    double s = 0.0;
+    for (i64 i = lo; i < hi; ++i)
+      if (owner[i]) s += x[i] * y[i];
+    return s;
+  }
+  const i64 mid = lo + (hi - lo) / 2;
+  return masked_pairwise(owner, x, y, lo, mid) + masked_pairwise(owner, x, y, mid, hi);
+}
+double orc_masked_dot_order(i64 n, const uint8_t *owner, const double *x, const double *y, int order)
+{
+  if (order == 1) {
+    double s = 0.0;
+    for (i64 i = n - 1; i >= 0; --i)
+      if (owner[i]) s += x[i] * y[i];
+    return s;
+  }
+  if (order == 2) return masked_pairwise(owner, x, y, 0, n);
+  return orc_masked_dot(n, owner, x, y);
+}
+
 /* plain dot: restr_vecs[k] * y (dune/ddm/galerkin_preconditioner.hh:165-167, 294) */
 double orc_dot(i64 n, const double *x, const double *y)
 {

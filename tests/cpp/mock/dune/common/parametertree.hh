@@ -7,6 +7,7 @@ namespace Dune {
 class ParameterTree {
 public:
   bool hasKey(const std::string& k) const { return values.count(k) > 0; }
+  bool hasSub(const std::string& k) const { return subs.count(k) > 0; }
   std::string& operator[](const std::string& k) { return values[k]; }
   ParameterTree& sub(const std::string& k) { return subs[k]; }
   const ParameterTree& sub(const std::string& k) const

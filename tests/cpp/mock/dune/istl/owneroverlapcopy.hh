@@ -1,6 +1,7 @@
 #pragma once
 // Single-process stand-in of OwnerOverlapCopyCommunication: index set with attributes, per-neighbour
 // remote index lists (filled by hand in tests), a trivial communicator.
+#include <cmath>
 #include <cstddef>
 #include <map>
 #include <vector>
@@ -59,6 +60,17 @@ public:
   mock::RemoteIndices& remoteIndices() { return ri; }
   const mock::RemoteIndices& remoteIndices() const { return ri; }
   const mock::Communicator& communicator() const { return cc; }
+  // single process: every index has one holder, the exchanges move nothing
+  template <class T1, class T2> void copyOwnerToAll(const T1&, T2&) const {}
+  template <class T1, class T2> void addOwnerCopyToAll(const T1&, T2&) const {}
+  template <class T1, class T2> void addOwnerCopyToOwnerCopy(const T1&, T2&) const {}
+  template <class T> double norm(const T& x) const
+  {
+    double s = 0;
+    for (const auto& idx : is)
+      if (idx.local().attribute() == OwnerOverlapCopyAttributeSet::owner) s += x[idx.local().local()][0] * x[idx.local().local()][0];
+    return std::sqrt(s);
+  }
 private:
   mock::IndexSet is;
   mock::RemoteIndices ri;

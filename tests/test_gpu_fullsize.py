@@ -72,8 +72,12 @@ def test_full_length_cg_parity_geneo_96(ddm):
       * while ||r_k|| >= 2e-3 ||r_0|| (the first ~40 iterations): | ||r_k||_hip - ||r_k||_oracle | <= 1e-8 ||r_k||
         (measured 1e-14 at k = 20, 2e-10 at k = 40);
       * afterwards CG amplifies the rounding-level differences (10^6-term reductions in another order, explicit replicated inverse
-        of the coarse matrix vs LU): the two residual curves are two equally valid finite-precision CG trajectories, measured up to
-        12 % apart at single iterations (k = 80) and closer again later -- asserted: within a factor 2 at every iteration;
+        of the coarse matrix vs LU).  That this is a property of CG in floating point and not of the HIP path is DEMONSTRATED
+        here, not assumed: the oracle is run a second and third time with nothing changed but the order of the additions inside
+        its global dot products (descending, pairwise: tests/test_oracle_order_sensitivity.py has the CPU-only version); the
+        running maximum of the relative deviation between those ORACLE runs is the envelope two correct implementations drift
+        apart by.  Asserted: at every iteration the HIP-vs-oracle deviation is at most ENVELOPE_FACTOR x that envelope
+        (floored at 1e-8), and the HIP curve is not an outlier of the family {oracle, oracle-descending, oracle-pairwise};
       * iteration counts equal, or different by ONE because the iterate that sits on the threshold 1e-10 ||r_0|| is just below it
         on one side and just above on the other (measured: 141 HIP / 142 oracle, ||r_141|| = 0.97e-10 vs 1.0e-10 ||r_0||)."""
     from dune_ddm_amd import synth
@@ -86,6 +90,15 @@ def test_full_length_cg_parity_geneo_96(ddm):
     tl = TwoLevelSchwarz(dec, coarse="none")
     basis, info = geneo_basis(tl, nev=20, return_info=True)
     assert info["converged"]
+    # the device-built GenEO pairs checked on the host, independently of the device path AND of the oracle (scipy only): all 160
+    # pairs satisfy A_neu x = lambda D B_neu D x to the eigensolver tolerance (the oracle below is handed this basis)
+    from dune_ddm_amd.geneo import host_eigenpair_residuals
+    worst_res = worst_rq = 0.0
+    for sd in dec.subs:
+        r_, q_ = host_eigenpair_residuals(sd, basis[sd.id], info["eigenvalues"][sd.id])
+        worst_res, worst_rq = max(worst_res, float(r_.max())), max(worst_rq, float(q_.max()))
+    print(f"[96^3 GenEO] host check of the 160 device eigenpairs: worst ||A x - lambda C x|| / ||lambda C x|| = {worst_res:.2e}, worst Rayleigh-quotient mismatch {worst_rq:.2e}")
+    assert worst_res < 1e-4 and worst_rq < 1e-8
     tl.set_coarse_basis(basis)
     tl.rebuild_combined("additive")
     res, hist, x = tl.solve(reduction=1e-10, maxit=1000)
@@ -93,16 +106,33 @@ def test_full_length_cg_parity_geneo_96(ddm):
     ao.set_threads(8)
     try:
         it, conv, hist_o, xo = oracle_solve(dec, reduction=1e-10, maxit=1000, coarse={s: list(basis[s]) for s in basis}, schwarz_type="standard", mode="additive")
+        variants = {}
+        for order in (1, 2):           # the same oracle, only the summation order of the global dots changed
+            ao.set_dot_order(order)
+            it_v, conv_v, hist_v, _ = oracle_solve(dec, reduction=1e-10, maxit=1000, coarse={s: list(basis[s]) for s in basis}, schwarz_type="standard", mode="additive")
+            variants[order] = (it_v, conv_v, np.asarray(hist_v))
     finally:
+        ao.set_dot_order(0)
         ao.set_threads(1)
     ho, hh = np.asarray(hist_o), np.asarray(hist)
     assert res.converged and conv and abs(res.iterations - it) <= 1, (res.iterations, it)
-    m = min(len(ho), len(hh))
+    m = min([len(ho), len(hh)] + [len(v[2]) for v in variants.values()])
     dev = np.abs(hh[:m] - ho[:m])
-    print("[96^3 GenEO] k, r_k/r_0, |dr|/r_k:", [(k, f"{ho[k] / ho[0]:.1e}", f"{dev[k] / ho[k]:.1e}") for k in range(0, m, 10)])
+    rel = dev / ho[:m]
+    env = np.zeros(m)
+    for order, (it_v, conv_v, hv) in variants.items():
+        assert conv_v and abs(it_v - it) <= 1
+        env = np.maximum(env, np.maximum.accumulate(np.abs(hv[:m] - ho[:m]) / ho[:m]))
+    print("[96^3 GenEO] k, r_k/r_0, |dr|/r_k hip-vs-oracle, envelope oracle-vs-oracle(other summation order):",
+          [(k, f"{ho[k] / ho[0]:.1e}", f"{rel[k]:.1e}", f"{env[k]:.1e}") for k in range(0, m, 10)])
     early = ho[:m] >= 2e-3 * ho[0]
     assert early.sum() >= 30 and (dev[early] <= 1e-8 * ho[:m][early]).all(), float(np.max(dev[early] / ho[:m][early]))
-    assert (np.abs(np.log(hh[:m] / ho[:m])) < np.log(2.0)).all(), float(np.max(dev / ho[:m]))
+    ENVELOPE_FACTOR = 5.0             # measured: 0.70 (the HIP run deviates LESS from the oracle than the oracle from its re-ordered self)
+    bound = np.maximum(1e-8, ENVELOPE_FACTOR * env)
+    worst = int(np.argmax(rel / bound))
+    print(f"[96^3 GenEO] max over k of (hip-vs-oracle deviation) / max(1e-8, envelope): {np.max(rel / np.maximum(1e-8, env)):.2f} at k = {int(np.argmax(rel / np.maximum(1e-8, env)))}")
+    assert (rel <= bound).all(), (worst, float(rel[worst]), float(env[worst]))
+    assert env.max() >= 1e-4           # the oracle runs themselves drift apart by orders of magnitude: the effect is CG's
     if res.iterations != it:   # the last common iterate sits on the threshold
         k = m - 1
         assert min(hh[k], ho[k]) <= 1e-10 * ho[0] < max(hh[k], ho[k])

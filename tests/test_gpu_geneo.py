@@ -154,3 +154,42 @@ def test_geneo_nev20_symmetric_grid_multiple_eigenvalues(ddm):
     assert (np.abs(np.log(hist / h2)) < np.log(2.0)).all()
     print(f"[geneo nev=20] device {res.iterations} iterations, oracle basis {it}; block iterations {info['iterations']}, direct {info['used_direct']}")
     tl.ctx.close()
+
+
+def test_geneo_threshold_mode_matches_oracle(ddm):
+    """Threshold mode of spectra_gevp_op (dune/ddm/eigensolvers/spectra.hh:157-163, 186-189) through ddm_geneo_basis: start with
+    nev = 4, double until the largest computed eigenvalue exceeds the threshold (or nev >= nev_max = 2 nev), keep the eigenvalues below it.
+    On the 25^3 islands problem with threshold 0.5 the subdomains keep 3 or 4 vectors, six of the eight only after a doubling
+    (eigenvalues: 0.2713 0.2716 0.4026 | 0.8905 ... resp. 0.1767 0.2715 0.4027 0.4425 | 0.7014 ...).  Against the oracle's literal
+    restatement (oracle/geneo_oracle.py), subdomain by subdomain: the same NUMBER of vectors, eigenvalues 1e-6, spans 2e-3 -- and
+    the independent host check of every returned pair (geneo.host_eigenpair_residuals)."""
+    from dune_ddm_amd import synth
+    from dune_ddm_amd.geneo import geneo_basis_from_params, host_eigenpair_residuals
+    from dune_ddm_amd.problem import build_structured
+    from dune_ddm_amd.solver import TwoLevelSchwarz
+    from oracle import geneo_oracle as go
+    N = (25, 25, 25)
+    kappa = synth.islands_kappa(tuple(n - 1 for n in N), contrast=1e4, period=6, width=2)
+    dec = build_structured(synth.StructuredPoisson(N, (2, 2, 2), kappa), overlap=2, pou_type="distance", neumann=True)
+    tl = TwoLevelSchwarz(dec, coarse="none")
+    eig = {"nev": 4, "threshold": 0.5}
+    # (no nev_max key: eigensolver_params.hh:23 lets that key overwrite ncv and leaves nev_max UNINITIALISED in the reference; without
+    #  it nev_max = 2 nev = 8, so the subdomains whose 4th eigenvalue is below the threshold double once)
+    basis, info = geneo_basis_from_params(tl, eig)
+    assert info["converged"]
+    counts = []
+    for sd in dec.subs:
+        vecs, lam = go.geneo_basis(sd.A_neu, sd.B_neu, sd.pou, dict(eig))
+        k = len(vecs)
+        counts.append(k)
+        assert info["nconv"][sd.id] == k == basis[sd.id].shape[0], (sd.id, info["nconv"][sd.id], k)
+        assert np.allclose(info["eigenvalues"][sd.id][:k], lam[:k], rtol=1e-6)
+        assert (lam[:max(k - 1, 1)] < 0.5).all()
+        ov = np.array(vecs)
+        ov[:, sd.dirichlet_ovlp > 0] = 0.0
+        assert _sin_largest_angle(basis[sd.id], ov) < 2e-3
+        res, rq = host_eigenpair_residuals(sd, basis[sd.id], info["eigenvalues"][sd.id][:k])
+        assert res.max() < 1e-3 and rq.max() < 1e-6, (sd.id, res.max(), rq.max())
+    assert min(counts) >= 1 and len(set(counts)) > 1          # the subdomains really keep different numbers of vectors
+    assert info["nev"] == 8                                    # and nev was doubled
+    tl.ctx.close()
