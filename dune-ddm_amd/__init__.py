@@ -91,6 +91,10 @@ SYMBOLS = {
     "ddm_ilu0_engine": (_I32, [_P]),
     "ddm_chol_create": (_I32, [_P, _P, _I64, _P, _D, _PP]),
     "ddm_ilu0_is_direct": (_I32, [_P]),
+    "ddm_sn_host_create": (_I32, [_I64, _P, _P, _I64, _P, _PP]),
+    "ddm_sn_host_destroy": (None, [_P]),
+    "ddm_sn_host_sizes": (_I32, [_P, _I64, _P, ctypes.POINTER(ctypes.c_double)]),
+    "ddm_sn_host_get": (_I32, [_P, _I64, _P, _P, _P, _P, _P, _P]),
     "ddm_ilu0_nnz": (_I64, [_P]),
     "ddm_chol_host_create": (_I32, [_I64, _P, _P, _P, _I64, _P, _PP]),
     "ddm_direct_host_create": (_I32, [_I64, _P, _P, _P, _I64, _P, _I32, _PP]),
@@ -324,6 +328,38 @@ def chol_host(M, block_ptr=None, numeric=True, general=False):
         lib.ddm_chol_host_get(h, _hp(out["perm"]), _hp(out["rowptr"]), _hp(out["col"]), _hp(out["lu"]))
     finally:
         lib.ddm_chol_host_destroy(h)
+    return out
+
+
+def sn_symbolic_host(M, block_ptr=None):
+    """Host half of the device supernodal Cholesky (ordering + symbolic analysis, no device needed): list of per-block dicts
+    perm, first, rptr, rows, parent, level, flops, entries."""
+    import scipy.sparse as sp
+    lib = load_library()
+    M = sp.csr_matrix(M)
+    if not M.has_sorted_indices:
+        M = M.sorted_indices()
+    n = M.shape[0]
+    bp = _np([0, n] if block_ptr is None else block_ptr, np.int64)
+    rp, ci = _np(M.indptr, np.int64), _np(M.indices, np.int32)
+    h = ctypes.c_void_p()
+    rc = lib.ddm_sn_host_create(n, _hp(rp), _hp(ci), len(bp) - 1, _hp(bp), ctypes.byref(h))
+    if rc != DDM_OK:
+        raise DdmError(rc, "ddm_sn_host_create failed")
+    out = []
+    try:
+        for b in range(len(bp) - 1):
+            sz = np.zeros(4, dtype=np.int64)
+            fl = ctypes.c_double()
+            lib.ddm_sn_host_sizes(h, b, _hp(sz), ctypes.byref(fl))
+            nsn, nrows = int(sz[0]), int(sz[1])
+            d = {"perm": np.empty(int(bp[b + 1] - bp[b]), dtype=np.int32), "first": np.empty(nsn + 1, dtype=np.int32), "rptr": np.empty(nsn + 1, dtype=np.int64),
+                 "rows": np.empty(nrows, dtype=np.int32), "parent": np.empty(nsn, dtype=np.int32), "level": np.empty(nsn, dtype=np.int32),
+                 "flops": fl.value, "entries": int(sz[2]), "levels": int(sz[3])}
+            lib.ddm_sn_host_get(h, b, _hp(d["perm"]), _hp(d["first"]), _hp(d["rptr"]), _hp(d["rows"]), _hp(d["parent"]), _hp(d["level"]))
+            out.append(d)
+    finally:
+        lib.ddm_sn_host_destroy(h)
     return out
 
 

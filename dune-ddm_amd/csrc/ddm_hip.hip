@@ -4,6 +4,7 @@
 #include "kernels.hpp"
 #include "trsv_pipe.hpp"
 #include "sparse_chol_host.hpp"
+#include "sn_chol.hpp"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h> // types and enums only: the library is opened with dlopen when ddm_ctx_set_rccl is called
@@ -615,6 +616,7 @@ struct ddm_ilu0 {
   int pm_nrhs = 0;
   int direct = 0;
   double direct_flops = 0.0;
+  sn::Factor *sn = nullptr;       // supernodal factor computed ON THE DEVICE (sn_chol.hpp); solves run on its panels, in place in pd / pD
   int64_t nvirt = 0; // virtual unknowns of the supernodal transformation: the permuted work vectors hold n + nvirt entries
   std::vector<double> h_lu; // factor values in the pattern of A
   TriSchedule L, U;
@@ -1272,6 +1274,130 @@ extern "C" int ddm_chol_host_get(const ddm_chol_host *H, int32_t *perm, int64_t 
   return DDM_OK;
 }
 
+// Supernodal Cholesky on the device.  Returns DDM_OK / an error code, or 1 when the factorisation is too small to be worth it and
+// force == false (the caller then takes the host path).
+static int sn_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, double max_flops, bool force, ddm_ilu0 **out)
+{
+  const int64_t n = A->nrows;
+  if (block_ptr[0] != 0 || block_ptr[nblocks] != n) return fail(ctx, DDM_EINVAL, "block_ptr does not cover the matrix");
+  const int64_t *rp = A->h_rp.data();
+  const int32_t *ci = A->h_ci.data();
+  std::vector<sn::BlockSym> BS((size_t)nblocks);
+  std::vector<int> bad((size_t)nblocks, 0);
+  {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int nthreads = (int)std::min<int64_t>(nblocks, hw);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t)
+      th.emplace_back([&, t]() {
+        for (int64_t b = t; b < nblocks; b += nthreads) {
+          const int64_t r0 = block_ptr[b], r1 = block_ptr[b + 1];
+          for (int64_t i = r0; i < r1 && !bad[(size_t)b]; ++i)
+            for (int64_t k = rp[i]; k < rp[i + 1]; ++k)
+              if (ci[k] < r0 || ci[k] >= r1) bad[(size_t)b] = 1;
+          if (bad[(size_t)b]) continue;
+          BS[(size_t)b] = sn::analyse(chol::block_graph(rp, ci, r0, r1));
+        }
+      });
+    for (auto &t : th) t.join();
+  }
+  for (int64_t b = 0; b < nblocks; ++b)
+    if (bad[(size_t)b]) return fail(ctx, DDM_EINVAL, "sparse direct solver: block %lld has entries outside its diagonal block", (long long)b);
+  double flops = 0.0;
+  int64_t entries = 0;
+  for (auto &S : BS) {
+    flops += S.flops;
+    entries += S.entries;
+  }
+  double min_flops = 2e9;
+  if (const char *e = std::getenv("DDM_DIRECT_DEVICE_MIN_FLOPS")) min_flops = std::atof(e);
+  if (!force && flops < min_flops) return 1;
+  if (max_flops > 0.0 && flops > max_flops)
+    return fail(ctx, DDM_ENOTIMPL, "sparse direct solver: the factorisation needs %.3g flops (limit %.3g)", flops, max_flops);
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)entries * 8.0 > 0.85 * (double)free_b)
+    return fail(ctx, DDM_ENOTIMPL, "sparse direct solver: the factor needs %.1f GB, %.1f GB of device memory are free", entries * 8e-9, free_b * 1e-9);
+  const auto t0 = std::chrono::steady_clock::now();
+  sn::Factor *S = new sn::Factor;
+  if (!sn::build(*S, n, nblocks, block_ptr, BS)) {
+    delete S;
+    return fail(ctx, DDM_EHIP, "sparse direct solver (device): allocation of %.1f GB failed", entries * 8e-9);
+  }
+  unsigned badsn = 0;
+  const hipError_t he = sn::factorize(*S, ctx->stream, A->rp, A->ci, A->va, &badsn);
+  if (he != hipSuccess) {
+    delete S;
+    return fail(ctx, DDM_EHIP, "sparse direct solver (device): %s", hipGetErrorString(he));
+  }
+  if (badsn) {
+    delete S;
+    return fail(ctx, DDM_ENUMERIC, "sparse direct solver: matrix is not positive definite (supernode %u)", badsn - 1);
+  }
+  if (std::getenv("DDM_PIPE_VERBOSE"))
+    std::fprintf(stderr, "[ddm] device supernodal Cholesky: %lld rows, %d supernodes, %d levels, %.2f GB of panels, %.3g flops, numeric factorisation %.3f s (%.2f TFLOP/s)\n",
+                 (long long)n, S->nsn, S->nlev, S->entries * 8e-9, S->flops, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(),
+                 2e-12 * S->flops / std::max(1e-9, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()));
+  ddm_ilu0 *F = new ddm_ilu0;
+  F->n = n;
+  F->nnz = S->entries;
+  F->direct = 1;
+  F->direct_flops = S->flops;
+  F->sn = S;
+  F->mode = 0;
+  F->L.nlev = F->U.nlev = S->nlev;
+  int rc = DDM_OK;
+  if (hipHostMalloc((void **)&F->err, 128, hipHostMallocMapped) != hipSuccess) rc = fail(ctx, DDM_EHIP, "sparse direct solver: allocation failed");
+  else std::memset(F->err, 0, 128);
+  if (!rc && hipMalloc((void **)&F->pd, sizeof(double) * (size_t)std::max<int64_t>(n, 1)) != hipSuccess) rc = fail(ctx, DDM_EHIP, "sparse direct solver: allocation failed");
+  if (rc) {
+    ddm_ilu0_destroy(F);
+    return rc;
+  }
+  *out = F;
+  return DDM_OK;
+}
+// host part of the device engine alone (ordering + supernodal symbolic analysis; no device needed): used by the CPU tests
+struct ddm_sn_host {
+  std::vector<sn::BlockSym> BS;
+  std::vector<int64_t> block_ptr;
+};
+extern "C" int ddm_sn_host_create(int64_t n, const int64_t *rp, const int32_t *ci, int64_t nblocks, const int64_t *block_ptr, ddm_sn_host **out)
+{
+  if (!out || !rp || !ci || nblocks < 1 || !block_ptr || block_ptr[0] != 0 || block_ptr[nblocks] != n) return DDM_EINVAL;
+  ddm_sn_host *H = new ddm_sn_host;
+  H->block_ptr.assign(block_ptr, block_ptr + nblocks + 1);
+  for (int64_t b = 0; b < nblocks; ++b) H->BS.push_back(sn::analyse(chol::block_graph(rp, ci, block_ptr[b], block_ptr[b + 1])));
+  *out = H;
+  return DDM_OK;
+}
+extern "C" void ddm_sn_host_destroy(ddm_sn_host *H) { delete H; }
+// sizes[4] = {supernodes, entries of `rows`, panel entries, levels}; flops = multiply-adds of the factorisation
+extern "C" int ddm_sn_host_sizes(const ddm_sn_host *H, int64_t block, int64_t *sizes, double *flops)
+{
+  if (!H || block < 0 || block >= (int64_t)H->BS.size() || !sizes) return DDM_EINVAL;
+  const sn::BlockSym &S = H->BS[(size_t)block];
+  int32_t nlev = 0;
+  for (int32_t l : S.level) nlev = std::max(nlev, l + 1);
+  sizes[0] = (int64_t)S.first.size() - 1;
+  sizes[1] = (int64_t)S.rows.size();
+  sizes[2] = S.entries;
+  sizes[3] = nlev;
+  if (flops) *flops = S.flops;
+  return DDM_OK;
+}
+// perm[n_b] (perm[new] = old, block-local), first[nsn + 1], rptr[nsn + 1], rows[...], parent[nsn], level[nsn] of one block
+extern "C" int ddm_sn_host_get(const ddm_sn_host *H, int64_t block, int32_t *perm, int32_t *first, int64_t *rptr, int32_t *rows, int32_t *parent, int32_t *level)
+{
+  if (!H || block < 0 || block >= (int64_t)H->BS.size()) return DDM_EINVAL;
+  const sn::BlockSym &S = H->BS[(size_t)block];
+  if (perm) std::copy(S.perm.begin(), S.perm.end(), perm);
+  if (first) std::copy(S.first.begin(), S.first.end(), first);
+  if (rptr) std::copy(S.rptr.begin(), S.rptr.end(), rptr);
+  if (rows) std::copy(S.rows.begin(), S.rows.end(), rows);
+  if (parent) std::copy(S.parent.begin(), S.parent.end(), parent);
+  if (level) std::copy(S.level.begin(), S.level.end(), level);
+  return DDM_OK;
+}
 extern "C" int ddm_chol_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, double max_flops, ddm_ilu0 **out)
 {
   return ddm_direct_create(ctx, A, nblocks, block_ptr, 0, max_flops, out);
@@ -1280,6 +1406,16 @@ extern "C" int ddm_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks
 {
   if (!ctx || !A || !out || nblocks < 1 || !block_ptr) return fail(ctx, DDM_EINVAL, "ddm_direct_create: bad arguments");
   if (A->nrows != A->ncols) return fail(ctx, DDM_EINVAL, "the sparse direct solver needs a square matrix");
+  // Engine: "device" = supernodal factorisation and solves on the GPU (sn_chol.hpp; symmetric positive definite input), "host" = the
+  // up-looking host factorisation with CSR level solves on the device.  Default: the device engine when the matrix is symmetric
+  // and the factorisation is worth a launch sequence (DDM_DIRECT_DEVICE_MIN_FLOPS, default 2e9); DDM_DIRECT_ENGINE overrides.
+  if (!general) {
+    const char *eng = std::getenv("DDM_DIRECT_ENGINE");
+    if (!eng || std::strcmp(eng, "host") != 0) {
+      const int rcs = sn_direct_create(ctx, A, nblocks, block_ptr, max_flops, eng && !std::strcmp(eng, "device"), out);
+      if (rcs != 1) return rcs; // 1 = not taken (too small for the device engine): fall through to the host path
+    }
+  }
   CholResult R;
   const int rc0 = chol_build(A->nrows, A->h_rp.data(), A->h_ci.data(), A->h_va.data(), nblocks, block_ptr, max_flops, true, R, general != 0);
   if (rc0) return fail(ctx, rc0, "sparse direct solver: %s", R.error.c_str());
@@ -1317,6 +1453,7 @@ extern "C" void ddm_ilu0_destroy(ddm_ilu0 *F)
   if (F->graph) (void)hipGraphExecDestroy(F->graph);
   if (F->mgraph) (void)hipGraphExecDestroy(F->mgraph);
   if (F->err) (void)hipHostFree(F->err);
+  delete F->sn;
   (void)hipFree(F->perm);
   (void)hipFree(F->pd);
   (void)hipFree(F->px);
@@ -1375,6 +1512,7 @@ extern "C" int ddm_ilu0_engine(const ddm_ilu0 *F)
 extern "C" int ddm_ilu0_get_factors_host(ddm_ctx *ctx, const ddm_ilu0 *F, double *lu_host)
 {
   if (!F || !lu_host) return fail(ctx, DDM_EINVAL, "bad arguments");
+  if (F->sn) return fail(ctx, DDM_ENOTIMPL, "ddm_ilu0_get_factors_host: the device supernodal factor has no CSR form");
   std::memcpy(lu_host, F->h_lu.data(), sizeof(double) * (size_t)F->nnz);
   return DDM_OK;
 }
@@ -1679,6 +1817,7 @@ static int ilu0_solve_epilogue(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, doubl
     (void)hipGraphExecDestroy(F->graph);
     F->graph = nullptr;
   }
+  if (F->sn && !sn::reserve(*F->sn, 1)) return fail(ctx, DDM_EHIP, "sparse direct solver: allocation failed");
   if (F->mode == 8 && F->pipe_state == 0) DDMCHECK(build_pipe_schedule(ctx, F));
   if (F->mode == 8 && F->pipe_state < 0) F->mode = 4; // not applicable: the loader engine takes any matrix
   if (F->mode == 4 && !F->xcd_built) DDMCHECK(build_xcd_schedule(ctx, F));
@@ -1687,12 +1826,17 @@ static int ilu0_solve_epilogue(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, doubl
   int rc = DDM_OK;
   const double *d_user = d;
   double *x_user = x;
+  bool epilogue_done = false;
+  if (F->sn) { // supernodal device factor: gather into the permuted work vector, solve in place on the panels, scatter
+    hipLaunchKernelGGL(k_perm_gather, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, 1, F->sn->d_perm, d_user, (int64_t)1, F->pd);
+    sn::solve(*F->sn, ctx->stream, 1, F->pd, 1);
+    hipLaunchKernelGGL(k_perm_scatter, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, 1, F->sn->d_perm, (const double *)F->pd, x_user, (int64_t)1);
+  } else {
   if (F->perm) { // sparse direct factor: solve in the fill-reducing order
     hipLaunchKernelGGL(k_perm_gather, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, 1, F->perm, d_user, (int64_t)1, F->pd);
     d = F->pd;
     x = F->px;
   }
-  bool epilogue_done = false;
   if (F->mode == 8) {
     epilogue_done = !F->perm;
     enqueue_pipe(ctx, F, d, x, nullptr, epilogue_done ? scale : nullptr, epilogue_done ? add : nullptr);
@@ -1709,6 +1853,7 @@ static int ilu0_solve_epilogue(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, doubl
     if (!rc) rc = enqueue_tri(ctx, F->U, true, d, x);
   }
   if (F->perm) hipLaunchKernelGGL(k_perm_scatter, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, 1, F->perm, (const double *)F->px, x_user, (int64_t)1);
+  }
   d = d_user;
   x = x_user;
   if (!epilogue_done) {
@@ -1777,6 +1922,17 @@ static int ilu0_solve_multi_ld(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double
     (void)hipGraphExecDestroy(F->mgraph);
     F->mgraph = nullptr;
   }
+  if (F->sn) {
+    if (nrhs > 48) return fail(ctx, DDM_EINVAL, "ddm_ilu0_solve_multi: at most 48 right-hand sides per call with the device direct solver");
+    if (!sn::reserve(*F->sn, nrhs)) return fail(ctx, DDM_EHIP, "sparse direct solver: allocation failed");
+    if (F->pm_nrhs < nrhs) {
+      (void)hipFree(F->pD);
+      F->pD = nullptr;
+      F->pm_nrhs = 0;
+      HIPCHECK(ctx, hipMalloc((void **)&F->pD, sizeof(double) * (size_t)F->n * (size_t)nrhs));
+      F->pm_nrhs = nrhs;
+    }
+  }
   if (F->perm && F->pm_nrhs < nrhs) {
     (void)hipFree(F->pD);
     (void)hipFree(F->pX);
@@ -1788,7 +1944,11 @@ static int ilu0_solve_multi_ld(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double
   }
   hipGraph_t g = nullptr;
   HIPCHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-  if (F->perm) { // sparse direct factor: solve in the fill-reducing order on packed work blocks
+  if (F->sn) {
+    hipLaunchKernelGGL(k_perm_gather, dim3(grid_for(F->n * nrhs)), dim3(WG), 0, ctx->stream, F->n, nrhs, F->sn->d_perm, D, ldd, F->pD);
+    sn::solve(*F->sn, ctx->stream, nrhs, F->pD, nrhs);
+    hipLaunchKernelGGL(k_perm_scatter, dim3(grid_for(F->n * nrhs)), dim3(WG), 0, ctx->stream, F->n, nrhs, F->sn->d_perm, (const double *)F->pD, X, ldx);
+  } else if (F->perm) { // sparse direct factor: solve in the fill-reducing order on packed work blocks
     hipLaunchKernelGGL(k_perm_gather, dim3(grid_for(F->n * nrhs)), dim3(WG), 0, ctx->stream, F->n, nrhs, F->perm, D, ldd, F->pD);
     enqueue_multi_levels_csr(ctx, F->Lc, false, nrhs, F->pD, nrhs, F->pX, nrhs);
     enqueue_multi_levels_csr(ctx, F->Uc, true, nrhs, F->pD, nrhs, F->pX, nrhs);

@@ -1,0 +1,608 @@
+// Supernodal sparse Cholesky ON THE DEVICE: numeric factorisation and the (multi-right-hand-side) triangular solves of the sparse
+// direct local solver -- what the reference obtains from CHOLMOD / UMFPACK through the dune-istl solver factory
+// (dune/ddm/schwarz.hh:85-92, examples/poisson.ini:23,26), from `SymShiftInvert` inside the GenEO eigensolver
+// (dune/ddm/eigensolvers/spectra.hh:28-89) and from the multi-RHS solver dune/ddm/eigensolvers/umfpack.hh:16-333.
+// Host: ordering + symbolic analysis only (sn_chol_host.hpp).  Everything with arithmetic is below.
+//
+// Data: all diagonal blocks (subdomains) of the rank share one supernode list in GLOBAL permuted numbering; supernode s owns the
+// columns [first[s], first[s+1]) (at most SN_MAX_COLS) and a dense column-major panel [D_s; R_s] of (ncol + nrow) x ncol doubles,
+// D_s = diagonal block (lower triangle used), R_s = the rows `rows[rptr[s] .. rptr[s+1])` below it.
+// After the factorisation D_s holds W_s = L_ss^-1 (explicit inverse of the Cholesky factor of the diagonal block: every solve with
+// it is a product) and R_s holds L_{rows, s}.
+//
+// Factorisation = right-looking, level by level of the supernodal elimination tree (supernodes of one level are independent):
+//   k_sn_diag    one workgroup per supernode: Cholesky + in-place triangular inverse of the diagonal block in LDS;
+//   k_sn_panel   R_s <- R_s W_s^T                                   (FP64 MFMA, one workgroup per 64 rows);
+//   k_sn_update  U = R_s R_s^T (lower triangle, 64 x 64 tiles, FP64 MFMA) subtracted from the panels of the ancestors that own
+//                the columns `rows[...]`: the row positions inside a target panel are found by binary search once per (tile,
+//                target) in LDS, the subtraction is a hardware FP64 atomic add (two supernodes of one level may update the same
+//                ancestor entry; the ORDER of these additions is not fixed, so the factor is reproducible to rounding only).
+// Solves (row-major n x m work block in the permuted numbering, in place), level by level:
+//   forward   k_sn_fwd_diag: Y_s = W_s B_s;   k_sn_fwd_update: B_rows -= R_s Y_s (atomic adds, as above);
+//   backward  k_sn_bwd_partial (supernodes with many rows): per 64-row tile R_tile^T X_rows;   k_sn_bwd_diag: X_s = W_s^T (Y_s - R_s^T X_rows),
+//             tile partials summed in tile order.
+// Bounding roofline: the factorisation is FP64-MFMA work (flop count from the symbolic analysis), the solves stream the panels once
+// per sweep: 8 * entries bytes (+ the work block).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "sn_chol_host.hpp"
+
+namespace sn {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int TILE = 64;      // rows per panel / update tile
+constexpr int BWD_SMALL = 8;  // supernodes with at most this many row tiles do their backward reduction inside k_sn_bwd_diag
+
+struct Meta { // device pointers
+  int32_t nsn;
+  const int32_t *first;     // [nsn + 1]
+  const int32_t *nrow;      // [nsn]
+  const int64_t *rptr;      // [nsn + 1]
+  const int32_t *rows;
+  const int64_t *pptr;      // [nsn + 1] (doubles)
+  const int32_t *sn_of_col; // [n]
+  double *panels;
+};
+
+__device__ __forceinline__ int32_t lower_bound_i32(const int32_t *__restrict__ a, int32_t n, int32_t v)
+{
+  int32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int32_t mid = (lo + hi) >> 1;
+    if (a[mid] < v) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+// position of global row r in the index list [cols(t); rows(t)] of supernode t (r must be in it)
+__device__ __forceinline__ int32_t row_pos(const Meta &M, int32_t t, int32_t r)
+{
+  const int32_t f = M.first[t], nc = M.first[t + 1] - f;
+  if (r < f + nc) return r - f;
+  return nc + lower_bound_i32(M.rows + M.rptr[t], M.nrow[t], r);
+}
+// work item -> (supernode of the level, local tile): pre[0 .. cnt] is the exclusive prefix of the per-supernode tile counts
+__device__ __forceinline__ int find_item(const int32_t *__restrict__ pre, int cnt, int32_t item)
+{
+  int lo = 0, hi = cnt; // largest i with pre[i] <= item
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (pre[mid] <= item) lo = mid;
+    else hi = mid;
+  }
+  return lo;
+}
+
+// ---- assembly: the lower triangle of the permuted matrix into the panels (one thread per row of A) ----------------------------
+__global__ __launch_bounds__(256) void k_sn_assemble(Meta M, int64_t n, const int64_t *__restrict__ rp, const int32_t *__restrict__ ci, const double *__restrict__ va,
+                                                    const int32_t *__restrict__ iperm)
+{
+  const int64_t io = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (io >= n) return;
+  const int32_t i = iperm[io];
+  for (int64_t k = rp[io]; k < rp[io + 1]; ++k) {
+    const int32_t j = iperm[ci[k]];
+    if (j > i) continue;
+    const int32_t t = M.sn_of_col[j];
+    const int32_t f = M.first[t], nc = M.first[t + 1] - f;
+    M.panels[M.pptr[t] + row_pos(M, t, i) + (int64_t)(j - f) * (nc + M.nrow[t])] = va[k];
+  }
+}
+
+// ---- diagonal block: Cholesky + triangular inverse in LDS --------------------------------------------------------------------
+// err: first supernode (+1) whose diagonal block is not positive definite
+__global__ __launch_bounds__(256) void k_sn_diag(Meta M, const int32_t *__restrict__ lev_sn, unsigned *__restrict__ err)
+{
+  extern __shared__ __attribute__((aligned(16))) double a[];
+  __shared__ double rowbuf[SN_MAX_COLS];
+  const int32_t s = lev_sn[blockIdx.x];
+  const int32_t nc = M.first[s + 1] - M.first[s];
+  const int64_t ld = nc + M.nrow[s];
+  double *P = M.panels + M.pptr[s];
+  const int ldl = nc | 1;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < nc * nc; idx += 256) {
+    const int i = idx % nc, j = idx / nc;
+    a[i + j * ldl] = i >= j ? P[i + j * ld] : 0.0;
+  }
+  __syncthreads();
+  for (int k = 0; k < nc; ++k) {
+    if (tid == 0) {
+      double d = a[k + k * ldl];
+      if (!(d > 0.0) || !(d < 1.7e308)) {
+        atomicCAS(err, 0u, (unsigned)s + 1u);
+        d = 1.0;
+      }
+      a[k + k * ldl] = sqrt(d);
+    }
+    __syncthreads();
+    const double piv = a[k + k * ldl];
+    for (int i = k + 1 + tid; i < nc; i += 256) a[i + k * ldl] /= piv;
+    __syncthreads();
+    const int m = nc - k - 1;
+    for (int idx = tid; idx < m * m; idx += 256) {
+      const int i = k + 1 + idx % m, j = k + 1 + idx / m;
+      if (i >= j) a[i + j * ldl] -= a[i + k * ldl] * a[j + k * ldl];
+    }
+    __syncthreads();
+  }
+  // W = L^-1 in place, row by row: row i of W from row i of L (staged) and the rows of W above
+  for (int i = 0; i < nc; ++i) {
+    if (tid <= i) rowbuf[tid] = a[i + tid * ldl];
+    __syncthreads();
+    if (tid <= i) {
+      const int j = tid;
+      double acc = (i == j) ? 1.0 : 0.0;
+      for (int k = j; k < i; ++k) acc -= rowbuf[k] * a[k + j * ldl];
+      a[i + j * ldl] = acc / rowbuf[i];
+    }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < nc * nc; idx += 256) {
+    const int i = idx % nc, j = idx / nc;
+    if (i >= j) P[i + j * ld] = a[i + j * ldl];
+  }
+}
+
+// ---- panel: R_s <- R_s W_s^T  (64 rows per workgroup, 16 per wavefront, all ncol <= 128 columns in registers) ---------------
+__global__ __launch_bounds__(256) void k_sn_panel(Meta M, const int32_t *__restrict__ lev_sn, const int32_t *__restrict__ pre, int cnt)
+{
+  const int it = find_item(pre, cnt, (int32_t)blockIdx.x);
+  const int32_t s = lev_sn[it];
+  const int tile = (int)blockIdx.x - pre[it];
+  const int32_t nc = M.first[s + 1] - M.first[s], nr = M.nrow[s];
+  const int64_t ld = nc + nr;
+  double *P = M.panels + M.pptr[s];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lc = lane & 15, lr = lane >> 4;
+  const int row = tile * TILE + wave * 16 + lc; // A operand row of this lane
+  const bool rok = row < nr;
+  const int tb = (nc + 15) >> 4;
+  v4d acc[SN_MAX_COLS / 16];
+#pragma unroll
+  for (int t = 0; t < SN_MAX_COLS / 16; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < nc; k0 += 4) {
+    const int k = k0 + lr;
+    const double av = (rok && k < nc) ? P[nc + row + (int64_t)k * ld] : 0.0;
+#pragma unroll
+    for (int t = 0; t < SN_MAX_COLS / 16; ++t) {
+      if (t < tb) {
+        const int c = (t << 4) + lc;                        // B[k][j = c] = W[c][k] (lower: k <= c)
+        const double bv = (c < nc && k <= c) ? P[c + (int64_t)k * ld] : 0.0;
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < SN_MAX_COLS / 16; ++t) {
+    if (t >= tb) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = tile * TILE + wave * 16 + lr + 4 * q, c = (t << 4) + lc;
+      if (r < nr && c < nc) P[nc + r + (int64_t)c * ld] = acc[t][q];
+    }
+  }
+}
+
+// ---- update: lower-triangular 64 x 64 tiles of R_s R_s^T subtracted from the ancestors' panels ---------------------------------
+__global__ __launch_bounds__(256) void k_sn_update(Meta M, const int32_t *__restrict__ lev_sn, const int32_t *__restrict__ pre, int cnt)
+{
+  __shared__ int32_t rowid[TILE], colid[TILE], slot_of_col[TILE], slot_t[TILE], slot_first[TILE];
+  __shared__ int64_t slot_base[TILE], slot_ld[TILE];
+  __shared__ int32_t rpos[TILE * TILE]; // [slot][row]
+  __shared__ int nslots_s;
+  const int it = find_item(pre, cnt, (int32_t)blockIdx.x);
+  const int32_t s = lev_sn[it];
+  int u = (int)blockIdx.x - pre[it]; // index into the lower triangle of the T x T tile grid, row-major: u = ti (ti + 1) / 2 + tj
+  int ti = (int)((sqrt(8.0 * (double)u + 1.0) - 1.0) * 0.5);
+  while ((ti + 1) * (ti + 2) / 2 <= u) ++ti;
+  while (ti * (ti + 1) / 2 > u) --ti;
+  const int tj = u - ti * (ti + 1) / 2;
+  const int32_t nc = M.first[s + 1] - M.first[s], nr = M.nrow[s];
+  const int64_t ld = nc + nr;
+  const double *P = M.panels + M.pptr[s];
+  const int32_t *R = M.rows + M.rptr[s];
+  const int tid = threadIdx.x;
+  if (tid < TILE) {
+    const int r = ti * TILE + tid, c = tj * TILE + tid;
+    rowid[tid] = r < nr ? R[r] : -1;
+    colid[tid] = c < nr ? R[c] : -1;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int ns = 0;
+    for (int c = 0; c < TILE; ++c) {
+      if (colid[c] < 0) {
+        slot_of_col[c] = -1;
+        continue;
+      }
+      const int32_t t = M.sn_of_col[colid[c]];
+      if (ns == 0 || slot_t[ns - 1] != t) {
+        slot_t[ns] = t;
+        const int32_t f = M.first[t];
+        slot_first[ns] = f;
+        slot_ld[ns] = (int64_t)(M.first[t + 1] - f) + M.nrow[t];
+        slot_base[ns] = M.pptr[t];
+        ++ns;
+      }
+      slot_of_col[c] = ns - 1;
+    }
+    nslots_s = ns;
+  }
+  __syncthreads();
+  const int ns = nslots_s;
+  for (int idx = tid; idx < ns * TILE; idx += 256) {
+    const int sl = idx / TILE, r = idx % TILE;
+    const int32_t g = rowid[r];
+    rpos[idx] = (g >= 0 && g >= slot_first[sl]) ? row_pos(M, slot_t[sl], g) : -1;
+  }
+  const int lane = tid & 63, wave = tid >> 6, lc = lane & 15, lr = lane >> 4;
+  v4d acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+  const int arow = ti * TILE + wave * 16 + lc;
+  const bool aok = arow < nr;
+  for (int k0 = 0; k0 < nc; k0 += 4) {
+    const int k = k0 + lr;
+    const bool kok = k < nc;
+    const double av = (aok && kok) ? P[nc + arow + (int64_t)k * ld] : 0.0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int brow = tj * TILE + (t << 4) + lc;
+      const double bv = (brow < nr && kok) ? P[nc + brow + (int64_t)k * ld] : 0.0;
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int c = (t << 4) + lc;
+    const int sl = slot_of_col[c];
+    if (sl < 0) continue;
+    const int32_t gc = colid[c];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = wave * 16 + lr + 4 * q;
+      const int32_t gr = rowid[r];
+      if (gr < gc) continue; // (also gr == -1) lower triangle only
+      const int32_t rp = rpos[sl * TILE + r];
+      unsafeAtomicAdd(M.panels + slot_base[sl] + rp + (int64_t)(gc - slot_first[sl]) * slot_ld[sl], -acc[t][q]);
+    }
+  }
+}
+
+// ---- solves ----------------------------------------------------------------------------------------------------------------------
+// Y_s = W_s B_s, in place in the work block (row-major, leading dimension ldb, m <= 48 columns)
+__global__ __launch_bounds__(256) void k_sn_fwd_diag(Meta M, const int32_t *__restrict__ lev_sn, int m, double *__restrict__ B, int64_t ldb)
+{
+  extern __shared__ __attribute__((aligned(16))) double bs[]; // nc x m
+  const int32_t s = lev_sn[blockIdx.x];
+  const int32_t f = M.first[s], nc = M.first[s + 1] - f;
+  const int64_t ld = nc + M.nrow[s];
+  const double *W = M.panels + M.pptr[s];
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < nc * m; idx += 256) bs[idx] = B[(int64_t)(f + idx / m) * ldb + idx % m];
+  __syncthreads();
+  for (int idx = tid; idx < nc * m; idx += 256) {
+    const int i = idx / m, c = idx % m;
+    double acc = 0.0;
+    for (int k = 0; k <= i; ++k) acc += W[i + (int64_t)k * ld] * bs[k * m + c];
+    B[(int64_t)(f + i) * ldb + c] = acc;
+  }
+}
+// B[rows] -= R_s Y_s, one workgroup per 64 rows of R_s
+__global__ __launch_bounds__(256) void k_sn_fwd_update(Meta M, const int32_t *__restrict__ lev_sn, const int32_t *__restrict__ pre, int cnt, int m,
+                                                      double *__restrict__ B, int64_t ldb)
+{
+  extern __shared__ __attribute__((aligned(16))) double ys[]; // nc x m
+  const int it = find_item(pre, cnt, (int32_t)blockIdx.x);
+  const int32_t s = lev_sn[it];
+  const int tile = (int)blockIdx.x - pre[it];
+  const int32_t f = M.first[s], nc = M.first[s + 1] - f, nr = M.nrow[s];
+  const int64_t ld = nc + nr;
+  const double *P = M.panels + M.pptr[s];
+  const int32_t *R = M.rows + M.rptr[s];
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < nc * m; idx += 256) ys[idx] = B[(int64_t)(f + idx / m) * ldb + idx % m];
+  __syncthreads();
+  for (int idx = tid; idx < TILE * m; idx += 256) {
+    const int r = tile * TILE + idx % TILE, c = idx / TILE;
+    if (r >= nr) continue;
+    double acc = 0.0;
+    for (int k = 0; k < nc; ++k) acc += P[nc + r + (int64_t)k * ld] * ys[k * m + c];
+    unsafeAtomicAdd(B + (int64_t)R[r] * ldb + c, -acc);
+  }
+}
+// partial[item][k * m + c] = sum over the rows r of the tile of R_s[r][k] X[rows[r]][c]   (supernodes with more than BWD_SMALL tiles)
+__global__ __launch_bounds__(256) void k_sn_bwd_partial(Meta M, const int32_t *__restrict__ big_sn, const int32_t *__restrict__ pre, int cnt, int m,
+                                                       const double *__restrict__ X, int64_t ldb, double *__restrict__ partial)
+{
+  extern __shared__ __attribute__((aligned(16))) double xr[]; // 64 x m
+  const int it = find_item(pre, cnt, (int32_t)blockIdx.x);
+  const int32_t s = big_sn[it];
+  const int tile = (int)blockIdx.x - pre[it];
+  const int32_t nc = M.first[s + 1] - M.first[s], nr = M.nrow[s];
+  const int64_t ld = nc + nr;
+  const double *P = M.panels + M.pptr[s];
+  const int32_t *R = M.rows + M.rptr[s];
+  const int tid = threadIdx.x;
+  const int r0 = tile * TILE, rn = min(TILE, nr - r0);
+  for (int idx = tid; idx < rn * m; idx += 256) xr[idx] = X[(int64_t)R[r0 + idx / m] * ldb + idx % m];
+  __syncthreads();
+  double *out = partial + (int64_t)blockIdx.x * SN_MAX_COLS * m;
+  for (int idx = tid; idx < nc * m; idx += 256) {
+    const int k = idx / m, c = idx % m;
+    const double *col = P + nc + r0 + (int64_t)k * ld;
+    double acc = 0.0;
+    for (int r = 0; r < rn; ++r) acc += col[r] * xr[r * m + c];
+    out[idx] = acc;
+  }
+}
+// X_s = W_s^T (Y_s - R_s^T X_rows); big_index[s] >= 0: position of s in the level's list of big supernodes (partials), else -1
+__global__ __launch_bounds__(256) void k_sn_bwd_diag(Meta M, const int32_t *__restrict__ lev_sn, const int32_t *__restrict__ big_index, const int32_t *__restrict__ pre_big,
+                                                    const double *__restrict__ partial, int m, double *__restrict__ B, int64_t ldb)
+{
+  extern __shared__ __attribute__((aligned(16))) double sh[]; // t: nc x m, then xr: 64 x m
+  const int32_t s = lev_sn[blockIdx.x];
+  const int32_t f = M.first[s], nc = M.first[s + 1] - f, nr = M.nrow[s];
+  const int64_t ld = nc + nr;
+  const double *P = M.panels + M.pptr[s];
+  const int32_t *R = M.rows + M.rptr[s];
+  double *t = sh, *xr = sh + (int64_t)nc * m;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < nc * m; idx += 256) t[idx] = B[(int64_t)(f + idx / m) * ldb + idx % m];
+  const int ntile = (nr + TILE - 1) / TILE;
+  const int bi = big_index[blockIdx.x];
+  if (bi >= 0) {
+    __syncthreads();
+    for (int idx = tid; idx < nc * m; idx += 256) {
+      double acc = t[idx];
+      const double *pp = partial + (int64_t)pre_big[bi] * SN_MAX_COLS * m + idx;
+      for (int tl = 0; tl < ntile; ++tl) acc -= pp[(int64_t)tl * SN_MAX_COLS * m];
+      t[idx] = acc;
+    }
+  } else {
+    for (int tl = 0; tl < ntile; ++tl) {
+      const int r0 = tl * TILE, rn = min(TILE, nr - r0);
+      __syncthreads();
+      for (int idx = tid; idx < rn * m; idx += 256) xr[idx] = B[(int64_t)R[r0 + idx / m] * ldb + idx % m];
+      __syncthreads();
+      for (int idx = tid; idx < nc * m; idx += 256) {
+        const int k = idx / m, c = idx % m;
+        const double *col = P + nc + r0 + (int64_t)k * ld;
+        double acc = 0.0;
+        for (int r = 0; r < rn; ++r) acc += col[r] * xr[r * m + c];
+        t[idx] -= acc;
+      }
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < nc * m; idx += 256) {
+    const int i = idx / m, c = idx % m;
+    const double *wc = P + (int64_t)i * ld; // column i of W: W[k][i], k >= i
+    double acc = 0.0;
+    for (int k = i; k < nc; ++k) acc += wc[k] * t[k * m + c];
+    B[(int64_t)(f + i) * ldb + c] = acc;
+  }
+}
+
+// ---- host driver -------------------------------------------------------------------------------------------------------------------
+struct Factor {
+  int64_t n = 0, entries = 0;
+  int32_t nsn = 0, nlev = 0;
+  double flops = 0.0;
+  Meta M{};
+  std::vector<int32_t> h_perm;           // perm[new] = old (global)
+  std::vector<int32_t> lev_ptr;          // [nlev + 1] into lev_sn
+  std::vector<int32_t> lev_big_ptr;      // [nlev + 1] into big_sn
+  std::vector<int32_t> lev_maxnc;        // widest supernode of the level
+  // device
+  int32_t *d_first = nullptr, *d_nrow = nullptr, *d_rows = nullptr, *d_sn_of_col = nullptr, *d_iperm = nullptr, *d_perm = nullptr;
+  int64_t *d_rptr = nullptr, *d_pptr = nullptr;
+  double *d_panels = nullptr;
+  int32_t *d_lev_sn = nullptr;   // supernodes sorted by level
+  int32_t *d_preT = nullptr;     // per level: exclusive prefix of the row-tile counts (lev_ptr[l] + l .. : cnt + 1 entries)
+  int32_t *d_preU = nullptr;     // the same for the update tiles T (T + 1) / 2
+  int32_t *d_big_sn = nullptr, *d_big_index = nullptr, *d_preB = nullptr; // supernodes with more than BWD_SMALL row tiles, per level
+  std::vector<int32_t> h_tilesT, h_tilesU, h_tilesB; // totals per level
+  unsigned *d_err = nullptr;
+  double *d_partial = nullptr;
+  int64_t partial_cap = 0; // doubles
+  int64_t max_big_tiles = 0;
+  void release()
+  {
+    for (void *p : {(void *)d_first, (void *)d_nrow, (void *)d_rows, (void *)d_sn_of_col, (void *)d_iperm, (void *)d_perm, (void *)d_rptr, (void *)d_pptr, (void *)d_panels,
+                    (void *)d_lev_sn, (void *)d_preT, (void *)d_preU, (void *)d_big_sn, (void *)d_big_index, (void *)d_preB, (void *)d_err, (void *)d_partial})
+      if (p) (void)hipFree(p);
+    d_first = d_nrow = d_rows = d_sn_of_col = d_iperm = d_perm = d_lev_sn = d_preT = d_preU = d_big_sn = d_big_index = d_preB = nullptr;
+    d_rptr = d_pptr = nullptr;
+    d_panels = d_partial = nullptr;
+    d_err = nullptr;
+  }
+  ~Factor() { release(); }
+};
+
+template <class T>
+static inline bool up(const std::vector<T> &h, T **d)
+{
+  if (hipMalloc((void **)d, sizeof(T) * std::max<size_t>(h.size(), 1)) != hipSuccess) return false;
+  return h.empty() || hipMemcpy(*d, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice) == hipSuccess;
+}
+
+// symbolic results of all blocks -> one global structure on the device.  Returns false on an allocation failure.
+static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *block_ptr, std::vector<BlockSym> &BS)
+{
+  F.n = n;
+  std::vector<int32_t> first, nrow, rows, sn_of_col((size_t)n), iperm((size_t)n), level;
+  std::vector<int64_t> rptr(1, 0), pptr(1, 0);
+  F.h_perm.resize((size_t)n);
+  for (int64_t b = 0; b < nblocks; ++b) {
+    BlockSym &S = BS[(size_t)b];
+    const int32_t off = (int32_t)block_ptr[b];
+    const int32_t nsn = (int32_t)S.first.size() - 1;
+    for (int32_t s = 0; s < nsn; ++s) {
+      const int32_t gs = (int32_t)first.size();
+      first.push_back(off + S.first[(size_t)s]);
+      const int64_t r0 = S.rptr[(size_t)s], r1 = S.rptr[(size_t)s + 1];
+      nrow.push_back((int32_t)(r1 - r0));
+      for (int64_t k = r0; k < r1; ++k) rows.push_back(off + S.rows[(size_t)k]);
+      rptr.push_back((int64_t)rows.size());
+      const int64_t nc = S.first[(size_t)s + 1] - S.first[(size_t)s];
+      pptr.push_back(pptr.back() + nc * (nc + (r1 - r0)));
+      level.push_back(S.level[(size_t)s]);
+      for (int32_t c = S.first[(size_t)s]; c < S.first[(size_t)s + 1]; ++c) sn_of_col[(size_t)(off + c)] = gs;
+    }
+    for (int32_t k = 0; k < S.n; ++k) {
+      F.h_perm[(size_t)(off + k)] = off + S.perm[(size_t)k];
+      iperm[(size_t)(off + S.perm[(size_t)k])] = off + k;
+    }
+    F.flops += S.flops;
+    S = BlockSym();
+  }
+  first.push_back((int32_t)n);
+  F.nsn = (int32_t)nrow.size();
+  F.entries = pptr.back();
+  int32_t nlev = 0;
+  for (int32_t l : level) nlev = std::max(nlev, l + 1);
+  F.nlev = nlev;
+  // supernodes by level (stable) and the per-level tile prefixes
+  F.lev_ptr.assign((size_t)nlev + 1, 0);
+  for (int32_t l : level) F.lev_ptr[(size_t)l + 1]++;
+  for (int32_t l = 0; l < nlev; ++l) F.lev_ptr[(size_t)l + 1] += F.lev_ptr[(size_t)l];
+  std::vector<int32_t> lev_sn((size_t)F.nsn), pos(F.lev_ptr.begin(), F.lev_ptr.end() - 1);
+  for (int32_t s = 0; s < F.nsn; ++s) lev_sn[(size_t)pos[(size_t)level[(size_t)s]]++] = s;
+  std::vector<int32_t> preT((size_t)F.nsn + nlev), preU((size_t)F.nsn + nlev), big_sn, big_index((size_t)F.nsn, -1), preB;
+  F.h_tilesT.assign((size_t)nlev, 0);
+  F.h_tilesU.assign((size_t)nlev, 0);
+  F.h_tilesB.assign((size_t)nlev, 0);
+  F.lev_maxnc.assign((size_t)nlev, 0);
+  F.lev_big_ptr.assign((size_t)nlev + 1, 0);
+  for (int32_t l = 0; l < nlev; ++l) {
+    int64_t aT = 0, aU = 0, aB = 0;
+    const int32_t base = F.lev_ptr[(size_t)l] + l;
+    const int32_t bbase = (int32_t)preB.size();
+    preB.push_back(0);
+    for (int32_t k = F.lev_ptr[(size_t)l]; k < F.lev_ptr[(size_t)l + 1]; ++k) {
+      const int32_t s = lev_sn[(size_t)k];
+      const int64_t T = (nrow[(size_t)s] + TILE - 1) / TILE;
+      preT[(size_t)(base + k - F.lev_ptr[(size_t)l])] = (int32_t)aT;
+      preU[(size_t)(base + k - F.lev_ptr[(size_t)l])] = (int32_t)aU;
+      aT += T;
+      aU += T * (T + 1) / 2;
+      if (T > BWD_SMALL) {
+        big_index[(size_t)k] = (int32_t)(big_sn.size() - (size_t)F.lev_big_ptr[(size_t)l]);
+        big_sn.push_back(s);
+        aB += T;
+        preB.push_back((int32_t)aB);
+      }
+      F.lev_maxnc[(size_t)l] = std::max(F.lev_maxnc[(size_t)l], first[(size_t)s + 1] - first[(size_t)s]);
+    }
+    if (aU > 2000000000ll) return false;
+    preT[(size_t)(base + F.lev_ptr[(size_t)l + 1] - F.lev_ptr[(size_t)l])] = (int32_t)aT;
+    preU[(size_t)(base + F.lev_ptr[(size_t)l + 1] - F.lev_ptr[(size_t)l])] = (int32_t)aU;
+    F.h_tilesT[(size_t)l] = (int32_t)aT;
+    F.h_tilesU[(size_t)l] = (int32_t)aU;
+    F.h_tilesB[(size_t)l] = (int32_t)aB;
+    F.lev_big_ptr[(size_t)l + 1] = (int32_t)big_sn.size();
+    F.max_big_tiles = std::max(F.max_big_tiles, aB);
+    (void)bbase;
+  }
+  bool ok = up(first, &F.d_first) && up(nrow, &F.d_nrow) && up(rows, &F.d_rows) && up(sn_of_col, &F.d_sn_of_col) && up(iperm, &F.d_iperm) && up(F.h_perm, &F.d_perm) &&
+            up(rptr, &F.d_rptr) && up(pptr, &F.d_pptr) && up(lev_sn, &F.d_lev_sn) && up(preT, &F.d_preT) && up(preU, &F.d_preU) && up(big_sn, &F.d_big_sn) &&
+            up(big_index, &F.d_big_index) && up(preB, &F.d_preB);
+  if (!ok) return false;
+  if (hipMalloc((void **)&F.d_err, 128) != hipSuccess || hipMemset(F.d_err, 0, 128) != hipSuccess) return false;
+  if (hipMalloc((void **)&F.d_panels, sizeof(double) * (size_t)std::max<int64_t>(F.entries, 1)) != hipSuccess) return false;
+  F.M.nsn = F.nsn;
+  F.M.first = F.d_first;
+  F.M.nrow = F.d_nrow;
+  F.M.rptr = F.d_rptr;
+  F.M.rows = F.d_rows;
+  F.M.pptr = F.d_pptr;
+  F.M.sn_of_col = F.d_sn_of_col;
+  F.M.panels = F.d_panels;
+  return true;
+}
+
+// numeric factorisation of the matrix (device CSR, original numbering); *bad = supernode + 1 whose diagonal block was not positive definite
+static inline hipError_t factorize(Factor &F, hipStream_t st, const int64_t *d_rp, const int32_t *d_ci, const double *d_va, unsigned *bad)
+{
+  hipError_t e = hipMemsetAsync(F.d_panels, 0, sizeof(double) * (size_t)std::max<int64_t>(F.entries, 1), st);
+  if (e != hipSuccess) return e;
+  (void)hipMemsetAsync(F.d_err, 0, 4, st);
+  if (F.n > 0) hipLaunchKernelGGL(k_sn_assemble, dim3((unsigned)((F.n + 255) / 256)), dim3(256), 0, st, F.M, F.n, d_rp, d_ci, d_va, F.d_iperm);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)k_sn_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (SN_MAX_COLS + 1) * SN_MAX_COLS * 8);
+    attr_set = true;
+  }
+  for (int32_t l = 0; l < F.nlev; ++l) {
+    const int32_t cnt = F.lev_ptr[(size_t)l + 1] - F.lev_ptr[(size_t)l];
+    if (cnt == 0) continue;
+    const int32_t *lsn = F.d_lev_sn + F.lev_ptr[(size_t)l];
+    const int nc = F.lev_maxnc[(size_t)l];
+    hipLaunchKernelGGL(k_sn_diag, dim3((unsigned)cnt), dim3(256), (size_t)(nc | 1) * nc * 8, st, F.M, lsn, F.d_err);
+    if (F.h_tilesT[(size_t)l] > 0)
+      hipLaunchKernelGGL(k_sn_panel, dim3((unsigned)F.h_tilesT[(size_t)l]), dim3(256), 0, st, F.M, lsn, (const int32_t *)(F.d_preT + F.lev_ptr[(size_t)l] + l), cnt);
+    if (F.h_tilesU[(size_t)l] > 0)
+      hipLaunchKernelGGL(k_sn_update, dim3((unsigned)F.h_tilesU[(size_t)l]), dim3(256), 0, st, F.M, lsn, (const int32_t *)(F.d_preU + F.lev_ptr[(size_t)l] + l), cnt);
+  }
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return e;
+  return hipMemcpy(bad, F.d_err, 4, hipMemcpyDeviceToHost);
+}
+
+// scratch of the backward sweep for m right-hand sides (call OUTSIDE a stream capture)
+static inline bool reserve(Factor &F, int m)
+{
+  const int64_t need = F.max_big_tiles * SN_MAX_COLS * (int64_t)m;
+  if (need <= F.partial_cap) return true;
+  if (F.d_partial) (void)hipFree(F.d_partial);
+  F.d_partial = nullptr;
+  F.partial_cap = 0;
+  if (hipMalloc((void **)&F.d_partial, sizeof(double) * (size_t)std::max<int64_t>(need, 1)) != hipSuccess) return false;
+  F.partial_cap = need;
+  return true;
+}
+
+// in-place solve L L^T X = B on the permuted row-major work block (n x m, leading dimension ldb); enqueues only (graph capturable)
+static inline void solve(const Factor &F, hipStream_t st, int m, double *B, int64_t ldb)
+{
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)k_sn_fwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, SN_MAX_COLS * 48 * 8);
+    (void)hipFuncSetAttribute((const void *)k_sn_fwd_update, hipFuncAttributeMaxDynamicSharedMemorySize, SN_MAX_COLS * 48 * 8);
+    (void)hipFuncSetAttribute((const void *)k_sn_bwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (SN_MAX_COLS + TILE) * 48 * 8);
+    attr_set = true;
+  }
+  for (int32_t l = 0; l < F.nlev; ++l) {
+    const int32_t cnt = F.lev_ptr[(size_t)l + 1] - F.lev_ptr[(size_t)l];
+    if (cnt == 0) continue;
+    const int32_t *lsn = F.d_lev_sn + F.lev_ptr[(size_t)l];
+    const size_t lds = (size_t)F.lev_maxnc[(size_t)l] * m * 8;
+    hipLaunchKernelGGL(k_sn_fwd_diag, dim3((unsigned)cnt), dim3(256), lds, st, F.M, lsn, m, B, ldb);
+    if (F.h_tilesT[(size_t)l] > 0)
+      hipLaunchKernelGGL(k_sn_fwd_update, dim3((unsigned)F.h_tilesT[(size_t)l]), dim3(256), lds, st, F.M, lsn, (const int32_t *)(F.d_preT + F.lev_ptr[(size_t)l] + l), cnt, m, B, ldb);
+  }
+  for (int32_t l = F.nlev - 1; l >= 0; --l) {
+    const int32_t cnt = F.lev_ptr[(size_t)l + 1] - F.lev_ptr[(size_t)l];
+    if (cnt == 0) continue;
+    const int32_t *lsn = F.d_lev_sn + F.lev_ptr[(size_t)l];
+    const int32_t nbig = F.lev_big_ptr[(size_t)l + 1] - F.lev_big_ptr[(size_t)l];
+    const int32_t *preB = F.d_preB + F.lev_big_ptr[(size_t)l] + l;
+    if (nbig > 0)
+      hipLaunchKernelGGL(k_sn_bwd_partial, dim3((unsigned)F.h_tilesB[(size_t)l]), dim3(256), (size_t)TILE * m * 8, st, F.M, (const int32_t *)(F.d_big_sn + F.lev_big_ptr[(size_t)l]),
+                         preB, nbig, m, (const double *)B, ldb, F.d_partial);
+    hipLaunchKernelGGL(k_sn_bwd_diag, dim3((unsigned)cnt), dim3(256), (size_t)(F.lev_maxnc[(size_t)l] + TILE) * m * 8, st, F.M, lsn,
+                       (const int32_t *)(F.d_big_index + F.lev_ptr[(size_t)l]), preB, (const double *)F.d_partial, m, B, ldb);
+  }
+}
+
+} // namespace sn

@@ -69,7 +69,9 @@ inline Graph block_graph(const int64_t *rp, const int32_t *ci, int64_t r0, int64
 }
 
 // Nested-dissection elimination order: perm[new] = old (local indices).
-inline std::vector<int32_t> nested_dissection(const Graph &G, int leaf = 48)
+// group_ends (optional): perm.size() after every emitted group (a leaf region or a separator) -- the candidate supernodes of the
+// supernodal device factorisation (sn_chol_host.hpp): the vertices of one group are eliminated consecutively.
+inline std::vector<int32_t> nested_dissection(const Graph &G, int leaf = 48, std::vector<int32_t> *group_ends = nullptr)
 {
   const int32_t n = G.n;
   std::vector<int32_t> perm;
@@ -117,6 +119,7 @@ inline std::vector<int32_t> nested_dissection(const Graph &G, int leaf = 48)
         perm.push_back(v);
         region[v] = -1;
       }
+      if (group_ends) group_ends->push_back((int32_t)perm.size());
       continue;
     }
     const int32_t rid = next_region++;
@@ -150,6 +153,7 @@ inline std::vector<int32_t> nested_dissection(const Graph &G, int leaf = 48)
         perm.push_back(v);
         region[v] = -1;
       }
+      if (group_ends) group_ends->push_back((int32_t)perm.size());
       continue;
     }
     // level sizes; separator = the narrowest level whose lower side holds 30-70 % of the vertices (else the median level)

@@ -147,6 +147,22 @@ int ddm_chol_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64
 /* general != 0: L U without pivoting on the pattern of A + A^T, for non-symmetric matrices whose symmetric part is positive
  * definite (the DG convection-diffusion operator; `type = umfpack`); DDM_ENUMERIC on a vanishing pivot.  general == 0 = ddm_chol_create. */
 int ddm_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, int general, double max_flops, ddm_ilu0 **out);
+/* Engines of ddm_chol_create / ddm_direct_create(general = 0), environment DDM_DIRECT_ENGINE = device | host (default: device when
+ * the factorisation needs at least DDM_DIRECT_DEVICE_MIN_FLOPS = 2e9 multiply-adds):
+ *   device  SUPERNODAL Cholesky with numeric factorisation AND solves on the GPU (csrc/sn_chol.hpp): nested-dissection supernodes of
+ *           at most 128 columns, dense panels, FP64-MFMA updates, level by level of the supernodal elimination tree; the host only
+ *           orders and analyses.  Updates of one tree level are added with hardware FP64 atomics: results are reproducible to
+ *           rounding, not bit for bit.  DDM_ENOTIMPL if the panels do not fit into the free device memory.
+ *   host    up-looking factorisation on host threads, CSR level solves on the device (bitwise reproducible; the only engine for
+ *           general = 1).
+ * The host half of the device engine alone (no device needed; CPU tests): */
+typedef struct ddm_sn_host ddm_sn_host;
+int ddm_sn_host_create(int64_t n, const int64_t *rowptr, const int32_t *col, int64_t nblocks, const int64_t *block_ptr, ddm_sn_host **out);
+void ddm_sn_host_destroy(ddm_sn_host *H);
+/* sizes[4] = {supernodes, length of `rows`, panel entries (doubles), tree levels} of one block; *flops = multiply-adds */
+int ddm_sn_host_sizes(const ddm_sn_host *H, int64_t block, int64_t *sizes, double *flops);
+/* perm[n_b] (perm[new] = old, block-local), first[nsn + 1], rptr[nsn + 1], rows[], parent[nsn], level[nsn]; any pointer may be NULL */
+int ddm_sn_host_get(const ddm_sn_host *H, int64_t block, int32_t *perm, int32_t *first, int64_t *rptr, int32_t *rows, int32_t *parent, int32_t *level);
 int ddm_ilu0_is_direct(const ddm_ilu0 *F); /* 1 for a ddm_chol_create / ddm_direct_create factor */
 int64_t ddm_ilu0_nnz(const ddm_ilu0 *F);   /* stored factor entries (L + D + U) */
 /* The host part alone (no device needed; used by the CPU tests): va == NULL stops after the symbolic analysis.
