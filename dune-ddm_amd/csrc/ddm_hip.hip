@@ -1309,7 +1309,7 @@ static int sn_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, con
     flops += S.flops;
     entries += S.entries;
   }
-  double min_flops = 2e9;
+  double min_flops = 1e11; // below: ~10 s of the host factorisation, whose CSR level solves are the faster ones for small factors
   if (const char *e = std::getenv("DDM_DIRECT_DEVICE_MIN_FLOPS")) min_flops = std::atof(e);
   if (!force && flops < min_flops) return 1;
   if (max_flops > 0.0 && flops > max_flops)
@@ -1408,7 +1408,7 @@ extern "C" int ddm_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks
   if (A->nrows != A->ncols) return fail(ctx, DDM_EINVAL, "the sparse direct solver needs a square matrix");
   // Engine: "device" = supernodal factorisation and solves on the GPU (sn_chol.hpp; symmetric positive definite input), "host" = the
   // up-looking host factorisation with CSR level solves on the device.  Default: the device engine when the matrix is symmetric
-  // and the factorisation is worth a launch sequence (DDM_DIRECT_DEVICE_MIN_FLOPS, default 2e9); DDM_DIRECT_ENGINE overrides.
+  // and the factorisation is worth a launch sequence (DDM_DIRECT_DEVICE_MIN_FLOPS, default 1e11); DDM_DIRECT_ENGINE overrides.
   if (!general) {
     const char *eng = std::getenv("DDM_DIRECT_ENGINE");
     if (!eng || std::strcmp(eng, "host") != 0) {

@@ -43,7 +43,7 @@ extern "C" int ddm_geneo_params_default(ddm_geneo_params *p)
   p->extra = 4;
   p->seed = 0;
   p->preconditioner = 0;
-  p->max_direct_flops = 3e11;
+  p->max_direct_flops = 2e13; // multiply-adds: a few seconds of the device factorisation (sn_chol.hpp); the host engine is only taken below 1e11
   p->verbose = 0;
   p->raw = 0;
   return DDM_OK;

@@ -38,6 +38,7 @@ namespace sn {
 typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int TILE = 64;      // rows per panel / update tile
 constexpr int BWD_SMALL = 8;  // supernodes with at most this many row tiles do their backward reduction inside k_sn_bwd_diag
+constexpr int BWD_ROWS = 256; // rows per partial product of the others (one workgroup, four 64-row sub-tiles)
 
 struct Meta { // device pointers
   int32_t nsn;
@@ -277,29 +278,54 @@ __global__ __launch_bounds__(256) void k_sn_update(Meta M, const int32_t *__rest
 }
 
 // ---- solves ----------------------------------------------------------------------------------------------------------------------
-// Y_s = W_s B_s, in place in the work block (row-major, leading dimension ldb, m <= 48 columns)
+// All four are small dense products on the FP64 matrix cores: m <= 48 right-hand sides = up to three 16-column tiles, padded with
+// zeros in LDS (mpad = 16 ceil(m / 16)); a wavefront owns 16-row strips of the result.
+constexpr int SOLVE_MT = 3;
+// Y_s = W_s B_s, in place in the work block (row-major, leading dimension ldb)
 __global__ __launch_bounds__(256) void k_sn_fwd_diag(Meta M, const int32_t *__restrict__ lev_sn, int m, double *__restrict__ B, int64_t ldb)
 {
-  extern __shared__ __attribute__((aligned(16))) double bs[]; // nc x m
+  extern __shared__ __attribute__((aligned(16))) double bs[]; // nc x mpad
   const int32_t s = lev_sn[blockIdx.x];
   const int32_t f = M.first[s], nc = M.first[s + 1] - f;
   const int64_t ld = nc + M.nrow[s];
   const double *W = M.panels + M.pptr[s];
-  const int tid = threadIdx.x;
-  for (int idx = tid; idx < nc * m; idx += 256) bs[idx] = B[(int64_t)(f + idx / m) * ldb + idx % m];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 15, lr = lane >> 4;
+  const int mt = (m + 15) >> 4, mpad = mt << 4;
+  for (int idx = tid; idx < nc * mpad; idx += 256) {
+    const int k = idx / mpad, c = idx - k * mpad;
+    bs[idx] = c < m ? B[(int64_t)(f + k) * ldb + c] : 0.0;
+  }
   __syncthreads();
-  for (int idx = tid; idx < nc * m; idx += 256) {
-    const int i = idx / m, c = idx % m;
-    double acc = 0.0;
-    for (int k = 0; k <= i; ++k) acc += W[i + (int64_t)k * ld] * bs[k * m + c];
-    B[(int64_t)(f + i) * ldb + c] = acc;
+  const int ns = (nc + 15) >> 4;
+  for (int si = wave; si < ns; si += 4) {
+    v4d acc[SOLVE_MT];
+#pragma unroll
+    for (int t = 0; t < SOLVE_MT; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+    const int row = (si << 4) + lc;
+    const int kend = min(nc, (si + 1) << 4);
+    for (int k0 = 0; k0 < kend; k0 += 4) {
+      const int k = k0 + lr;
+      const double av = (row < nc && k <= row) ? W[row + (int64_t)k * ld] : 0.0;
+#pragma unroll
+      for (int t = 0; t < SOLVE_MT; ++t)
+        if (t < mt) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, k < nc ? bs[k * mpad + (t << 4) + lc] : 0.0, acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < SOLVE_MT; ++t) {
+      if (t >= mt) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = (si << 4) + lr + 4 * q, c = (t << 4) + lc;
+        if (r < nc && c < m) B[(int64_t)(f + r) * ldb + c] = acc[t][q];
+      }
+    }
   }
 }
 // B[rows] -= R_s Y_s, one workgroup per 64 rows of R_s
 __global__ __launch_bounds__(256) void k_sn_fwd_update(Meta M, const int32_t *__restrict__ lev_sn, const int32_t *__restrict__ pre, int cnt, int m,
                                                       double *__restrict__ B, int64_t ldb)
 {
-  extern __shared__ __attribute__((aligned(16))) double ys[]; // nc x m
+  extern __shared__ __attribute__((aligned(16))) double ys[]; // nc x mpad
   const int it = find_item(pre, cnt, (int32_t)blockIdx.x);
   const int32_t s = lev_sn[it];
   const int tile = (int)blockIdx.x - pre[it];
@@ -307,22 +333,57 @@ __global__ __launch_bounds__(256) void k_sn_fwd_update(Meta M, const int32_t *__
   const int64_t ld = nc + nr;
   const double *P = M.panels + M.pptr[s];
   const int32_t *R = M.rows + M.rptr[s];
-  const int tid = threadIdx.x;
-  for (int idx = tid; idx < nc * m; idx += 256) ys[idx] = B[(int64_t)(f + idx / m) * ldb + idx % m];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 15, lr = lane >> 4;
+  const int mt = (m + 15) >> 4, mpad = mt << 4;
+  for (int idx = tid; idx < nc * mpad; idx += 256) {
+    const int k = idx / mpad, c = idx - k * mpad;
+    ys[idx] = c < m ? B[(int64_t)(f + k) * ldb + c] : 0.0;
+  }
   __syncthreads();
-  for (int idx = tid; idx < TILE * m; idx += 256) {
-    const int r = tile * TILE + idx % TILE, c = idx / TILE;
-    if (r >= nr) continue;
-    double acc = 0.0;
-    for (int k = 0; k < nc; ++k) acc += P[nc + r + (int64_t)k * ld] * ys[k * m + c];
-    unsafeAtomicAdd(B + (int64_t)R[r] * ldb + c, -acc);
+  v4d acc[SOLVE_MT];
+#pragma unroll
+  for (int t = 0; t < SOLVE_MT; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+  const int row = tile * TILE + (wave << 4) + lc;
+  for (int k0 = 0; k0 < nc; k0 += 4) {
+    const int k = k0 + lr;
+    const double av = (row < nr && k < nc) ? P[nc + row + (int64_t)k * ld] : 0.0;
+#pragma unroll
+    for (int t = 0; t < SOLVE_MT; ++t)
+      if (t < mt) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, k < nc ? ys[k * mpad + (t << 4) + lc] : 0.0, acc[t], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < SOLVE_MT; ++t) {
+    if (t >= mt) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = tile * TILE + (wave << 4) + lr + 4 * q, c = (t << 4) + lc;
+      if (r < nr && c < m) unsafeAtomicAdd(B + (int64_t)R[r] * ldb + c, -acc[t][q]);
+    }
+  }
+}
+// one 64-row tile of R_s^T X_rows into the accumulators of the calling wavefront: strips si = wave, wave + 4 of the nc result rows
+__device__ __forceinline__ void bwd_tile_mfma(const double *__restrict__ P, int32_t nc, int64_t ld, int r0, int rn, const double *__restrict__ xr, int mpad, int mt, int wave,
+                                               int lc, int lr, v4d (&acc)[2][SOLVE_MT])
+{
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int si = wave + 4 * h;
+    const int kcol = (si << 4) + lc; // result row = column of the panel
+    if ((si << 4) >= nc) continue;
+    for (int rr = 0; rr < rn; rr += 4) {
+      const int r = rr + lr;
+      const double av = (kcol < nc && r < rn) ? P[nc + r0 + r + (int64_t)kcol * ld] : 0.0;
+#pragma unroll
+      for (int t = 0; t < SOLVE_MT; ++t)
+        if (t < mt) acc[h][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, r < rn ? xr[r * mpad + (t << 4) + lc] : 0.0, acc[h][t], 0, 0, 0);
+    }
   }
 }
 // partial[item][k * m + c] = sum over the rows r of the tile of R_s[r][k] X[rows[r]][c]   (supernodes with more than BWD_SMALL tiles)
 __global__ __launch_bounds__(256) void k_sn_bwd_partial(Meta M, const int32_t *__restrict__ big_sn, const int32_t *__restrict__ pre, int cnt, int m,
                                                        const double *__restrict__ X, int64_t ldb, double *__restrict__ partial)
 {
-  extern __shared__ __attribute__((aligned(16))) double xr[]; // 64 x m
+  extern __shared__ __attribute__((aligned(16))) double xr[]; // 64 x mpad
   const int it = find_item(pre, cnt, (int32_t)blockIdx.x);
   const int32_t s = big_sn[it];
   const int tile = (int)blockIdx.x - pre[it];
@@ -330,64 +391,118 @@ __global__ __launch_bounds__(256) void k_sn_bwd_partial(Meta M, const int32_t *_
   const int64_t ld = nc + nr;
   const double *P = M.panels + M.pptr[s];
   const int32_t *R = M.rows + M.rptr[s];
-  const int tid = threadIdx.x;
-  const int r0 = tile * TILE, rn = min(TILE, nr - r0);
-  for (int idx = tid; idx < rn * m; idx += 256) xr[idx] = X[(int64_t)R[r0 + idx / m] * ldb + idx % m];
-  __syncthreads();
-  double *out = partial + (int64_t)blockIdx.x * SN_MAX_COLS * m;
-  for (int idx = tid; idx < nc * m; idx += 256) {
-    const int k = idx / m, c = idx % m;
-    const double *col = P + nc + r0 + (int64_t)k * ld;
-    double acc = 0.0;
-    for (int r = 0; r < rn; ++r) acc += col[r] * xr[r * m + c];
-    out[idx] = acc;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 15, lr = lane >> 4;
+  const int mt = (m + 15) >> 4, mpad = mt << 4;
+  v4d acc[2][SOLVE_MT];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int t = 0; t < SOLVE_MT; ++t) acc[h][t] = v4d{0.0, 0.0, 0.0, 0.0};
+  for (int sub = 0; sub < BWD_ROWS / TILE; ++sub) {
+    const int r0 = tile * BWD_ROWS + sub * TILE, rn = min(TILE, nr - r0);
+    if (rn <= 0) break;
+    __syncthreads();
+    for (int idx = tid; idx < TILE * mpad; idx += 256) {
+      const int r = idx / mpad, c = idx - r * mpad;
+      xr[idx] = (r < rn && c < m) ? X[(int64_t)R[r0 + r] * ldb + c] : 0.0;
+    }
+    __syncthreads();
+    bwd_tile_mfma(P, nc, ld, r0, rn, xr, mpad, mt, wave, lc, lr, acc);
   }
+  double *out = partial + (int64_t)blockIdx.x * SN_MAX_COLS * m;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int t = 0; t < SOLVE_MT; ++t) {
+      if (t >= mt) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = ((wave + 4 * h) << 4) + lr + 4 * q, c = (t << 4) + lc;
+        if (k < nc && c < m) out[k * m + c] = acc[h][t][q];
+      }
+    }
 }
 // X_s = W_s^T (Y_s - R_s^T X_rows); big_index[s] >= 0: position of s in the level's list of big supernodes (partials), else -1
 __global__ __launch_bounds__(256) void k_sn_bwd_diag(Meta M, const int32_t *__restrict__ lev_sn, const int32_t *__restrict__ big_index, const int32_t *__restrict__ pre_big,
                                                     const double *__restrict__ partial, int m, double *__restrict__ B, int64_t ldb)
 {
-  extern __shared__ __attribute__((aligned(16))) double sh[]; // t: nc x m, then xr: 64 x m
+  extern __shared__ __attribute__((aligned(16))) double sh[]; // t: nc x mpad, then xr: 64 x mpad
   const int32_t s = lev_sn[blockIdx.x];
   const int32_t f = M.first[s], nc = M.first[s + 1] - f, nr = M.nrow[s];
   const int64_t ld = nc + nr;
   const double *P = M.panels + M.pptr[s];
   const int32_t *R = M.rows + M.rptr[s];
-  double *t = sh, *xr = sh + (int64_t)nc * m;
-  const int tid = threadIdx.x;
-  for (int idx = tid; idx < nc * m; idx += 256) t[idx] = B[(int64_t)(f + idx / m) * ldb + idx % m];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 15, lr = lane >> 4;
+  const int mt = (m + 15) >> 4, mpad = mt << 4;
+  double *t = sh, *xr = sh + (int64_t)nc * mpad;
+  for (int idx = tid; idx < nc * mpad; idx += 256) {
+    const int k = idx / mpad, c = idx - k * mpad;
+    t[idx] = c < m ? B[(int64_t)(f + k) * ldb + c] : 0.0;
+  }
   const int ntile = (nr + TILE - 1) / TILE;
   const int bi = big_index[blockIdx.x];
   if (bi >= 0) {
-    __syncthreads();
-    for (int idx = tid; idx < nc * m; idx += 256) {
+    for (int idx = tid; idx < nc * mpad; idx += 256) { // (same idx -> thread mapping as the load above)
+      const int k = idx / mpad, c = idx - k * mpad;
+      if (c >= m) continue;
       double acc = t[idx];
-      const double *pp = partial + (int64_t)pre_big[bi] * SN_MAX_COLS * m + idx;
-      for (int tl = 0; tl < ntile; ++tl) acc -= pp[(int64_t)tl * SN_MAX_COLS * m];
+      const double *pp = partial + (int64_t)pre_big[bi] * SN_MAX_COLS * m + k * m + c;
+      const int npart = (nr + BWD_ROWS - 1) / BWD_ROWS;
+      for (int tl = 0; tl < npart; ++tl) acc -= pp[(int64_t)tl * SN_MAX_COLS * m];
       t[idx] = acc;
     }
-  } else {
+  } else if (ntile > 0) {
+    v4d acc[2][SOLVE_MT];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int tt = 0; tt < SOLVE_MT; ++tt) acc[h][tt] = v4d{0.0, 0.0, 0.0, 0.0};
     for (int tl = 0; tl < ntile; ++tl) {
       const int r0 = tl * TILE, rn = min(TILE, nr - r0);
       __syncthreads();
-      for (int idx = tid; idx < rn * m; idx += 256) xr[idx] = B[(int64_t)R[r0 + idx / m] * ldb + idx % m];
-      __syncthreads();
-      for (int idx = tid; idx < nc * m; idx += 256) {
-        const int k = idx / m, c = idx % m;
-        const double *col = P + nc + r0 + (int64_t)k * ld;
-        double acc = 0.0;
-        for (int r = 0; r < rn; ++r) acc += col[r] * xr[r * m + c];
-        t[idx] -= acc;
+      for (int idx = tid; idx < TILE * mpad; idx += 256) {
+        const int r = idx / mpad, c = idx - r * mpad;
+        xr[idx] = (r < rn && c < m) ? B[(int64_t)R[r0 + r] * ldb + c] : 0.0;
       }
+      __syncthreads();
+      bwd_tile_mfma(P, nc, ld, r0, rn, xr, mpad, mt, wave, lc, lr, acc);
     }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int tt = 0; tt < SOLVE_MT; ++tt) {
+        if (tt >= mt) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int k = ((wave + 4 * h) << 4) + lr + 4 * q, c = (tt << 4) + lc;
+          if (k < nc) t[k * mpad + c] -= acc[h][tt][q]; // (every (k, c) belongs to exactly one lane)
+        }
+      }
   }
   __syncthreads();
-  for (int idx = tid; idx < nc * m; idx += 256) {
-    const int i = idx / m, c = idx % m;
-    const double *wc = P + (int64_t)i * ld; // column i of W: W[k][i], k >= i
-    double acc = 0.0;
-    for (int k = i; k < nc; ++k) acc += wc[k] * t[k * m + c];
-    B[(int64_t)(f + i) * ldb + c] = acc;
+  // X_s = W^T t:  A[i][k] = W[k][i] (k >= i), B[k][c] = t[k][c]
+  const int ns = (nc + 15) >> 4;
+  for (int si = wave; si < ns; si += 4) {
+    v4d acc[SOLVE_MT];
+#pragma unroll
+    for (int tt = 0; tt < SOLVE_MT; ++tt) acc[tt] = v4d{0.0, 0.0, 0.0, 0.0};
+    const int i = (si << 4) + lc;
+    for (int k0 = si << 4; k0 < nc; k0 += 4) {
+      const int k = k0 + lr;
+      const double av = (i < nc && k < nc && k >= i) ? P[k + (int64_t)i * ld] : 0.0;
+#pragma unroll
+      for (int tt = 0; tt < SOLVE_MT; ++tt)
+        if (tt < mt) acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, k < nc ? t[k * mpad + (tt << 4) + lc] : 0.0, acc[tt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int tt = 0; tt < SOLVE_MT; ++tt) {
+      if (tt >= mt) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = (si << 4) + lr + 4 * q, c = (tt << 4) + lc;
+        if (r < nc && c < m) B[(int64_t)(f + r) * ldb + c] = acc[tt][q];
+      }
+    }
   }
 }
 
@@ -497,7 +612,7 @@ static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *b
       if (T > BWD_SMALL) {
         big_index[(size_t)k] = (int32_t)(big_sn.size() - (size_t)F.lev_big_ptr[(size_t)l]);
         big_sn.push_back(s);
-        aB += T;
+        aB += (nrow[(size_t)s] + BWD_ROWS - 1) / BWD_ROWS;
         preB.push_back((int32_t)aB);
       }
       F.lev_maxnc[(size_t)l] = std::max(F.lev_maxnc[(size_t)l], first[(size_t)s + 1] - first[(size_t)s]);
@@ -582,11 +697,12 @@ static inline void solve(const Factor &F, hipStream_t st, int m, double *B, int6
     (void)hipFuncSetAttribute((const void *)k_sn_bwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (SN_MAX_COLS + TILE) * 48 * 8);
     attr_set = true;
   }
+  const int mpad = ((m + 15) / 16) * 16;
   for (int32_t l = 0; l < F.nlev; ++l) {
     const int32_t cnt = F.lev_ptr[(size_t)l + 1] - F.lev_ptr[(size_t)l];
     if (cnt == 0) continue;
     const int32_t *lsn = F.d_lev_sn + F.lev_ptr[(size_t)l];
-    const size_t lds = (size_t)F.lev_maxnc[(size_t)l] * m * 8;
+    const size_t lds = (size_t)F.lev_maxnc[(size_t)l] * mpad * 8;
     hipLaunchKernelGGL(k_sn_fwd_diag, dim3((unsigned)cnt), dim3(256), lds, st, F.M, lsn, m, B, ldb);
     if (F.h_tilesT[(size_t)l] > 0)
       hipLaunchKernelGGL(k_sn_fwd_update, dim3((unsigned)F.h_tilesT[(size_t)l]), dim3(256), lds, st, F.M, lsn, (const int32_t *)(F.d_preT + F.lev_ptr[(size_t)l] + l), cnt, m, B, ldb);
@@ -598,9 +714,9 @@ static inline void solve(const Factor &F, hipStream_t st, int m, double *B, int6
     const int32_t nbig = F.lev_big_ptr[(size_t)l + 1] - F.lev_big_ptr[(size_t)l];
     const int32_t *preB = F.d_preB + F.lev_big_ptr[(size_t)l] + l;
     if (nbig > 0)
-      hipLaunchKernelGGL(k_sn_bwd_partial, dim3((unsigned)F.h_tilesB[(size_t)l]), dim3(256), (size_t)TILE * m * 8, st, F.M, (const int32_t *)(F.d_big_sn + F.lev_big_ptr[(size_t)l]),
+      hipLaunchKernelGGL(k_sn_bwd_partial, dim3((unsigned)F.h_tilesB[(size_t)l]), dim3(256), (size_t)TILE * mpad * 8, st, F.M, (const int32_t *)(F.d_big_sn + F.lev_big_ptr[(size_t)l]),
                          preB, nbig, m, (const double *)B, ldb, F.d_partial);
-    hipLaunchKernelGGL(k_sn_bwd_diag, dim3((unsigned)cnt), dim3(256), (size_t)(F.lev_maxnc[(size_t)l] + TILE) * m * 8, st, F.M, lsn,
+    hipLaunchKernelGGL(k_sn_bwd_diag, dim3((unsigned)cnt), dim3(256), (size_t)(F.lev_maxnc[(size_t)l] + TILE) * mpad * 8, st, F.M, lsn,
                        (const int32_t *)(F.d_big_index + F.lev_ptr[(size_t)l]), preB, (const double *)F.d_partial, m, B, ldb);
   }
 }

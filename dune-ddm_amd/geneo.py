@@ -50,7 +50,7 @@ def geneo_basis_from_params(tl, eig_ptree=None, **kw):
 
 
 def geneo_basis(tl, nev=20, tol=1e-5, shift=1e-3, maxit=400, extra=4, seed=0, verbose=False, return_info=False, threshold=-0.5,
-                nev_max=None, preconditioner="auto", max_direct_flops=3e11, require_convergence=True):
+                nev_max=None, preconditioner="auto", max_direct_flops=2e13, require_convergence=True):
     """Returns {local subdomain id: (k, n_s) ndarray} ready for TwoLevelSchwarz.set_coarse_basis (POU-scaled, 2-normalised, zero at
     Dirichlet DoFs).  preconditioner: "auto" (sparse Cholesky of A_neu + shift C when affordable, else ILU(0)), "ilu0", "cholesky".
     Raises if the eigensolver did not converge (require_convergence=False returns the block it has, flagged in info)."""

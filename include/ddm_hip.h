@@ -148,7 +148,7 @@ int ddm_chol_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64
  * definite (the DG convection-diffusion operator; `type = umfpack`); DDM_ENUMERIC on a vanishing pivot.  general == 0 = ddm_chol_create. */
 int ddm_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, int general, double max_flops, ddm_ilu0 **out);
 /* Engines of ddm_chol_create / ddm_direct_create(general = 0), environment DDM_DIRECT_ENGINE = device | host (default: device when
- * the factorisation needs at least DDM_DIRECT_DEVICE_MIN_FLOPS = 2e9 multiply-adds):
+ * the factorisation needs at least DDM_DIRECT_DEVICE_MIN_FLOPS = 1e11 multiply-adds):
  *   device  SUPERNODAL Cholesky with numeric factorisation AND solves on the GPU (csrc/sn_chol.hpp): nested-dissection supernodes of
  *           at most 128 columns, dense panels, FP64-MFMA updates, level by level of the supernodal elimination tree; the host only
  *           orders and analyses.  Updates of one tree level are added with hardware FP64 atomics: results are reproducible to
@@ -278,7 +278,7 @@ typedef struct {
   int32_t extra;           /* guard vectors iterated beyond nev (4) */
   int32_t seed;            /* start block */
   int32_t preconditioner;  /* 0 = sparse Cholesky of A + shift C if its flop count <= max_direct_flops, else ILU(0); 1 = ILU(0); 2 = Cholesky */
-  double max_direct_flops; /* 3e11: about 10-20 s on 8 host threads */
+  double max_direct_flops; /* 2e13 multiply-adds: a few seconds of the device factorisation (the host engine is only taken below 1e11) */
   int32_t verbose;
   int32_t raw;             /* 1: return the eigenvectors normalised to ||v||_2 = 1 without the "v <- D v" of finalize_eigenvectors
                             * (the ring coarse spaces extend the ring eigenvectors first, coarse_spaces.hh:612-627) */
