@@ -1276,7 +1276,7 @@ extern "C" int ddm_chol_host_get(const ddm_chol_host *H, int32_t *perm, int64_t 
 
 // Supernodal Cholesky on the device.  Returns DDM_OK / an error code, or 1 when the factorisation is too small to be worth it and
 // force == false (the caller then takes the host path).
-static int sn_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, double max_flops, bool force, ddm_ilu0 **out)
+static int sn_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, double max_flops, bool force, bool lu, bool setup_use, ddm_ilu0 **out)
 {
   const int64_t n = A->nrows;
   if (block_ptr[0] != 0 || block_ptr[nblocks] != n) return fail(ctx, DDM_EINVAL, "block_ptr does not cover the matrix");
@@ -1306,10 +1306,10 @@ static int sn_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, con
   double flops = 0.0;
   int64_t entries = 0;
   for (auto &S : BS) {
-    flops += S.flops;
-    entries += S.entries;
+    flops += (lu ? 2.0 : 1.0) * S.flops;
+    entries += (lu ? 2 : 1) * S.entries; // (L U: the U^T blocks; slightly over-counted by the diagonal blocks)
   }
-  double min_flops = 1e11; // below: ~10 s of the host factorisation, whose CSR level solves are the faster ones for small factors
+  double min_flops = setup_use ? 1e10 : 5e11; // (see direct_create_impl)
   if (const char *e = std::getenv("DDM_DIRECT_DEVICE_MIN_FLOPS")) min_flops = std::atof(e);
   if (!force && flops < min_flops) return 1;
   if (max_flops > 0.0 && flops > max_flops)
@@ -1319,7 +1319,7 @@ static int sn_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, con
     return fail(ctx, DDM_ENOTIMPL, "sparse direct solver: the factor needs %.1f GB, %.1f GB of device memory are free", entries * 8e-9, free_b * 1e-9);
   const auto t0 = std::chrono::steady_clock::now();
   sn::Factor *S = new sn::Factor;
-  if (!sn::build(*S, n, nblocks, block_ptr, BS)) {
+  if (!sn::build(*S, n, nblocks, block_ptr, BS, lu)) {
     delete S;
     return fail(ctx, DDM_EHIP, "sparse direct solver (device): allocation of %.1f GB failed", entries * 8e-9);
   }
@@ -1331,17 +1331,18 @@ static int sn_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, con
   }
   if (badsn) {
     delete S;
-    return fail(ctx, DDM_ENUMERIC, "sparse direct solver: matrix is not positive definite (supernode %u)", badsn - 1);
+    return fail(ctx, DDM_ENUMERIC, lu ? "sparse direct solver: vanishing pivot column inside the diagonal block of supernode %u (matrix singular?)"
+                                     : "sparse direct solver: matrix is not positive definite (supernode %u)", badsn - 1);
   }
   if (std::getenv("DDM_PIPE_VERBOSE"))
-    std::fprintf(stderr, "[ddm] device supernodal Cholesky: %lld rows, %d supernodes, %d levels, %.2f GB of panels, %.3g flops, numeric factorisation %.3f s (%.2f TFLOP/s)\n",
-                 (long long)n, S->nsn, S->nlev, S->entries * 8e-9, S->flops, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(),
-                 2e-12 * S->flops / std::max(1e-9, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()));
+    std::fprintf(stderr, "[ddm] device supernodal %s: %lld rows, %d supernodes, %d levels, %.2f GB of panels, %.3g flops, numeric factorisation %.3f s (%.2f TFLOP/s)\n",
+                 lu ? "L U" : "Cholesky", (long long)n, S->nsn, S->nlev, (S->entries + S->uentries) * 8e-9, (lu ? 2.0 : 1.0) * S->flops, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(),
+                 (lu ? 4e-12 : 2e-12) * S->flops / std::max(1e-9, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()));
   ddm_ilu0 *F = new ddm_ilu0;
   F->n = n;
-  F->nnz = S->entries;
+  F->nnz = S->entries + S->uentries;
   F->direct = 1;
-  F->direct_flops = S->flops;
+  F->direct_flops = (lu ? 2.0 : 1.0) * S->flops;
   F->sn = S;
   F->mode = 0;
   F->L.nlev = F->U.nlev = S->nlev;
@@ -1402,17 +1403,26 @@ extern "C" int ddm_chol_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, 
 {
   return ddm_direct_create(ctx, A, nblocks, block_ptr, 0, max_flops, out);
 }
+static int direct_create_impl(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, int general, double max_flops, bool setup_use, ddm_ilu0 **out);
 extern "C" int ddm_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, int general, double max_flops, ddm_ilu0 **out)
+{
+  return direct_create_impl(ctx, A, nblocks, block_ptr, general, max_flops, false, out);
+}
+// setup_use: the factor serves a handful of block solves during a setup phase (GenEO preconditioner, harmonic extensions) -- the
+// device engine pays from ~1e10 multiply-adds; as the local solver of a Krylov loop (thousands of single solves) the host engine's
+// CSR level solves are the faster ones (measured on configs[4]: 1.3 against 4.3 ms per solve), so the device engine is only taken
+// when the host factorisation would run for about a minute (5e11).
+static int direct_create_impl(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, int general, double max_flops, bool setup_use, ddm_ilu0 **out)
 {
   if (!ctx || !A || !out || nblocks < 1 || !block_ptr) return fail(ctx, DDM_EINVAL, "ddm_direct_create: bad arguments");
   if (A->nrows != A->ncols) return fail(ctx, DDM_EINVAL, "the sparse direct solver needs a square matrix");
   // Engine: "device" = supernodal factorisation and solves on the GPU (sn_chol.hpp; symmetric positive definite input), "host" = the
   // up-looking host factorisation with CSR level solves on the device.  Default: the device engine when the matrix is symmetric
-  // and the factorisation is worth a launch sequence (DDM_DIRECT_DEVICE_MIN_FLOPS, default 1e11); DDM_DIRECT_ENGINE overrides.
-  if (!general) {
+  // and the factorisation is worth it (DDM_DIRECT_DEVICE_MIN_FLOPS; defaults in direct_create_impl); DDM_DIRECT_ENGINE overrides.
+  {
     const char *eng = std::getenv("DDM_DIRECT_ENGINE");
     if (!eng || std::strcmp(eng, "host") != 0) {
-      const int rcs = sn_direct_create(ctx, A, nblocks, block_ptr, max_flops, eng && !std::strcmp(eng, "device"), out);
+      const int rcs = sn_direct_create(ctx, A, nblocks, block_ptr, max_flops, eng && !std::strcmp(eng, "device"), general != 0, setup_use, out);
       if (rcs != 1) return rcs; // 1 = not taken (too small for the device engine): fall through to the host path
     }
   }

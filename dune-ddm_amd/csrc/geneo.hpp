@@ -280,7 +280,7 @@ static int harmonic_create_impl(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks,
   int rc = ddm_csr_create(ctx, n, n, rpI.data(), ciI.data(), vaI.data(), &Ahat);
   if (!rc) {
     H->symmetric = csr_values_symmetric(Ahat);
-    rc = ddm_direct_create(ctx, Ahat, nblocks, block_ptr, H->symmetric ? 0 : 1, 0.0, &H->F);
+    rc = direct_create_impl(ctx, Ahat, nblocks, block_ptr, H->symmetric ? 0 : 1, 0.0, /*setup_use=*/true, &H->F);
   }
   ddm_csr_destroy(Ahat);
   if (!rc) rc = ddm_csr_create(ctx, n, n, rpG.data(), ciG.data(), vaG.data(), &H->Gib);
@@ -404,7 +404,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
   // ---- preconditioner ----
   int direct = 0;
   if (P.preconditioner != 1) {
-    const int rc = ddm_chol_create(ctx, own.At, nsub, sub_ptr, P.preconditioner == 2 ? 0.0 : P.max_direct_flops, &own.T);
+    const int rc = direct_create_impl(ctx, own.At, nsub, sub_ptr, 0, P.preconditioner == 2 ? 0.0 : P.max_direct_flops, /*setup_use=*/true, &own.T);
     if (rc == DDM_OK) direct = 1;
     else if (P.preconditioner == 2 || (rc != DDM_ENOTIMPL && rc != DDM_ENUMERIC)) return rc;
     else if (P.verbose) std::fprintf(stderr, "[ddm geneo] sparse Cholesky not used (%s): ILU(0) preconditioner\n", ddm_last_error(ctx));

@@ -49,6 +49,12 @@ struct Meta { // device pointers
   const int64_t *pptr;      // [nsn + 1] (doubles)
   const int32_t *sn_of_col; // [n]
   double *panels;
+  // L U variant (non-symmetric values on the symmetric pattern): the panel of s holds the FULL diagonal block and L_{rows, s};
+  // upanels holds U_{s, rows}^T as an nrow x ncol column-major block at uptr[s]; piv[first[s] + k] = row of the diagonal block
+  // (before pivoting) that ended up in position k
+  double *upanels;
+  const int64_t *uptr; // [nsn + 1]
+  int32_t *piv;        // [n]
 };
 
 __device__ __forceinline__ int32_t lower_bound_i32(const int32_t *__restrict__ a, int32_t n, int32_t v)
@@ -277,11 +283,292 @@ __global__ __launch_bounds__(256) void k_sn_update(Meta M, const int32_t *__rest
   }
 }
 
+// ---- L U variant -------------------------------------------------------------------------------------------------------------------
+// Non-symmetric values on a symmetric pattern (the DG convection-diffusion operator; `type = umfpack`): same supernodes, same tree.
+// Pivoting: threshold partial pivoting INSIDE the diagonal block of a supernode (UMFPACK's default: the diagonal entry is kept when
+// |a_kk| >= 0.1 max_i |a_ik|, else the largest entry of the column inside the block becomes the pivot); rows are never exchanged
+// between supernodes, so the structure stays static.  The row exchange is applied to the right-hand side when the forward sweep
+// reaches the supernode (not retroactively to the columns on the left), which is the same factorisation P_s ... P_1 A = L U.
+constexpr double LU_PIVOT_THRESHOLD = 0.1;
+
+__global__ __launch_bounds__(256) void k_sn_assemble_lu(Meta M, int64_t n, const int64_t *__restrict__ rp, const int32_t *__restrict__ ci, const double *__restrict__ va,
+                                                       const int32_t *__restrict__ iperm)
+{
+  const int64_t io = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (io >= n) return;
+  const int32_t i = iperm[io];
+  for (int64_t k = rp[io]; k < rp[io + 1]; ++k) {
+    const int32_t j = iperm[ci[k]];
+    if (j <= i) {
+      const int32_t t = M.sn_of_col[j];
+      const int32_t f = M.first[t], nc = M.first[t + 1] - f;
+      M.panels[M.pptr[t] + row_pos(M, t, i) + (int64_t)(j - f) * (nc + M.nrow[t])] = va[k];
+    } else {
+      const int32_t t = M.sn_of_col[i];
+      const int32_t f = M.first[t], nc = M.first[t + 1] - f, nr = M.nrow[t];
+      if (j < f + nc) M.panels[M.pptr[t] + (i - f) + (int64_t)(j - f) * (nc + nr)] = va[k];
+      else M.upanels[M.uptr[t] + lower_bound_i32(M.rows + M.rptr[t], nr, j) + (int64_t)(i - f) * nr] = va[k];
+    }
+  }
+}
+
+// diagonal block: P D = L U with threshold partial pivoting, then both triangular inverses in place (strict lower: L^-1 with its
+// unit diagonal implied; upper incl. diagonal: U^-1)
+__global__ __launch_bounds__(256) void k_sn_lu_diag(Meta M, const int32_t *__restrict__ lev_sn, unsigned *__restrict__ err)
+{
+  extern __shared__ __attribute__((aligned(16))) double a[];
+  __shared__ double rowbuf[SN_MAX_COLS];
+  __shared__ int32_t prow[SN_MAX_COLS];
+  __shared__ int pivot_row;
+  const int32_t s = lev_sn[blockIdx.x];
+  const int32_t f = M.first[s], nc = M.first[s + 1] - f;
+  const int64_t ld = nc + M.nrow[s];
+  double *P = M.panels + M.pptr[s];
+  const int ldl = nc | 1;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < nc * nc; idx += 256) {
+    const int i = idx % nc, j = idx / nc;
+    a[i + j * ldl] = P[i + j * ld];
+  }
+  if (tid < nc) prow[tid] = tid;
+  __syncthreads();
+  for (int k = 0; k < nc; ++k) {
+    if (tid == 0) {
+      double amax = 0.0;
+      int imax = k;
+      for (int i = k; i < nc; ++i) {
+        const double v = fabs(a[i + k * ldl]);
+        if (v > amax) {
+          amax = v;
+          imax = i;
+        }
+      }
+      const double dg = fabs(a[k + k * ldl]);
+      int p = (dg > 0.0 && dg >= LU_PIVOT_THRESHOLD * amax) ? k : imax;
+      if (!(amax > 0.0) || !(amax < 1.7e308)) {
+        atomicCAS(err, 0u, (unsigned)s + 1u);
+        a[k + k * ldl] = 1.0;
+        p = k;
+      }
+      pivot_row = p;
+    }
+    __syncthreads();
+    const int p = pivot_row;
+    if (p != k) {
+      for (int j = tid; j < nc; j += 256) {
+        const double tmp = a[k + j * ldl];
+        a[k + j * ldl] = a[p + j * ldl];
+        a[p + j * ldl] = tmp;
+      }
+      if (tid == 0) {
+        const int32_t t2 = prow[k];
+        prow[k] = prow[p];
+        prow[p] = t2;
+      }
+    }
+    __syncthreads();
+    const double piv = a[k + k * ldl];
+    for (int i = k + 1 + tid; i < nc; i += 256) a[i + k * ldl] /= piv;
+    __syncthreads();
+    const int m = nc - k - 1;
+    for (int idx = tid; idx < m * m; idx += 256) {
+      const int i = k + 1 + idx % m, j = k + 1 + idx / m;
+      a[i + j * ldl] -= a[i + k * ldl] * a[k + j * ldl];
+    }
+    __syncthreads();
+  }
+  // strict lower: W = L^-1 (unit diagonal), row by row
+  for (int i = 1; i < nc; ++i) {
+    if (tid < i) rowbuf[tid] = a[i + tid * ldl];
+    __syncthreads();
+    if (tid < i) {
+      const int j = tid;
+      double acc = -rowbuf[j];
+      for (int k = j + 1; k < i; ++k) acc -= rowbuf[k] * a[k + j * ldl];
+      a[i + j * ldl] = acc;
+    }
+    __syncthreads();
+  }
+  // upper incl. diagonal: V = U^-1, rows from the bottom
+  for (int i = nc - 1; i >= 0; --i) {
+    if (tid >= i && tid < nc) rowbuf[tid] = a[i + tid * ldl];
+    __syncthreads();
+    if (tid >= i && tid < nc) {
+      const int j = tid;
+      double acc = (i == j) ? 1.0 : 0.0;
+      for (int k = i + 1; k <= j; ++k) acc -= rowbuf[k] * a[k + j * ldl];
+      a[i + j * ldl] = acc / rowbuf[i];
+    }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < nc * nc; idx += 256) {
+    const int i = idx % nc, j = idx / nc;
+    P[i + j * ld] = a[i + j * ldl];
+  }
+  if (tid < nc) M.piv[f + tid] = prow[tid];
+}
+
+// rows below: L_{rows,s} <- A_{rows,s} U_ss^-1  and  U_{s,rows}^T <- (A_{s,rows}^T with the pivot order applied to its columns) L_ss^-T
+__global__ __launch_bounds__(256) void k_sn_lu_panel(Meta M, const int32_t *__restrict__ lev_sn, const int32_t *__restrict__ pre, int cnt)
+{
+  const int it = find_item(pre, cnt, (int32_t)blockIdx.x);
+  const int32_t s = lev_sn[it];
+  const int tile = (int)blockIdx.x - pre[it];
+  const int32_t f = M.first[s], nc = M.first[s + 1] - f, nr = M.nrow[s];
+  const int64_t ld = nc + nr;
+  double *P = M.panels + M.pptr[s];
+  double *UT = M.upanels + M.uptr[s];
+  const int32_t *piv = M.piv + f;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lc = lane & 15, lr = lane >> 4;
+  const int row = tile * TILE + wave * 16 + lc;
+  const bool rok = row < nr;
+  const int tb = (nc + 15) >> 4;
+  v4d accL[SN_MAX_COLS / 16], accU[SN_MAX_COLS / 16];
+#pragma unroll
+  for (int t = 0; t < SN_MAX_COLS / 16; ++t) accL[t] = accU[t] = v4d{0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < nc; k0 += 4) {
+    const int k = k0 + lr;
+    const bool kok = k < nc;
+    const double al = (rok && kok) ? P[nc + row + (int64_t)k * ld] : 0.0;
+    const double au = (rok && kok) ? UT[row + (int64_t)piv[k] * nr] : 0.0;
+#pragma unroll
+    for (int t = 0; t < SN_MAX_COLS / 16; ++t) {
+      if (t < tb) {
+        const int c = (t << 4) + lc;
+        const double bl = (c < nc && kok && k <= c) ? P[k + (int64_t)c * ld] : 0.0;                       // U^-1[k][c]
+        const double bu = (c < nc && kok) ? (k < c ? P[c + (int64_t)k * ld] : (k == c ? 1.0 : 0.0)) : 0.0; // L^-1[c][k]
+        accL[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(al, bl, accL[t], 0, 0, 0);
+        accU[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(au, bu, accU[t], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < SN_MAX_COLS / 16; ++t) {
+    if (t >= tb) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = tile * TILE + wave * 16 + lr + 4 * q, c = (t << 4) + lc;
+      if (r < nr && c < nc) {
+        P[nc + r + (int64_t)c * ld] = accL[t][q];
+        UT[r + (int64_t)c * nr] = accU[t][q];
+      }
+    }
+  }
+}
+
+// update: ALL 64 x 64 tiles of L_{rows,s} U_{s,rows} subtracted from the ancestors (lower part and diagonal blocks: panel of the
+// column's owner; strictly upper part outside a diagonal block: U^T block of the row's owner)
+__global__ __launch_bounds__(256) void k_sn_lu_update(Meta M, const int32_t *__restrict__ lev_sn, const int32_t *__restrict__ pre, int cnt)
+{
+  __shared__ int32_t rowid[TILE], colid[TILE], cslot[TILE], rslot[TILE], cs_t[TILE], rs_t[TILE];
+  __shared__ int32_t posc[TILE * TILE]; // [column slot][row]: position of the row in the column owner's index list
+  __shared__ int32_t posr[TILE * TILE]; // [row slot][column]: position of the column in the row owner's index list
+  __shared__ int ncs_s, nrs_s;
+  const int it = find_item(pre, cnt, (int32_t)blockIdx.x);
+  const int32_t s = lev_sn[it];
+  const int u = (int)blockIdx.x - pre[it];
+  const int32_t nc = M.first[s + 1] - M.first[s], nr = M.nrow[s];
+  const int T = (nr + TILE - 1) / TILE;
+  const int ti = u / T, tj = u - ti * T;
+  const int64_t ld = nc + nr;
+  const double *P = M.panels + M.pptr[s];
+  const double *UT = M.upanels + M.uptr[s];
+  const int32_t *R = M.rows + M.rptr[s];
+  const int tid = threadIdx.x;
+  if (tid < TILE) {
+    const int r = ti * TILE + tid, c = tj * TILE + tid;
+    rowid[tid] = r < nr ? R[r] : -1;
+    colid[tid] = c < nr ? R[c] : -1;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int ns = 0;
+    for (int c = 0; c < TILE; ++c) {
+      if (colid[c] < 0) {
+        cslot[c] = -1;
+        continue;
+      }
+      const int32_t t = M.sn_of_col[colid[c]];
+      if (ns == 0 || cs_t[ns - 1] != t) cs_t[ns++] = t;
+      cslot[c] = ns - 1;
+    }
+    ncs_s = ns;
+  }
+  if (tid == 64) {
+    int ns = 0;
+    for (int r = 0; r < TILE; ++r) {
+      if (rowid[r] < 0) {
+        rslot[r] = -1;
+        continue;
+      }
+      const int32_t t = M.sn_of_col[rowid[r]];
+      if (ns == 0 || rs_t[ns - 1] != t) rs_t[ns++] = t;
+      rslot[r] = ns - 1;
+    }
+    nrs_s = ns;
+  }
+  __syncthreads();
+  const int ncs = ncs_s, nrs = nrs_s;
+  for (int idx = tid; idx < ncs * TILE; idx += 256) {
+    const int sl = idx / TILE, r = idx % TILE;
+    const int32_t g = rowid[r];
+    posc[idx] = (g >= 0 && g >= M.first[cs_t[sl]]) ? row_pos(M, cs_t[sl], g) : -1;
+  }
+  for (int idx = tid; idx < nrs * TILE; idx += 256) {
+    const int sl = idx / TILE, c = idx % TILE;
+    const int32_t g = colid[c];
+    posr[idx] = (g >= 0 && g >= M.first[rs_t[sl]]) ? row_pos(M, rs_t[sl], g) : -1;
+  }
+  const int lane = tid & 63, wave = tid >> 6, lc = lane & 15, lr = lane >> 4;
+  v4d acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+  const int arow = ti * TILE + wave * 16 + lc;
+  const bool aok = arow < nr;
+  for (int k0 = 0; k0 < nc; k0 += 4) {
+    const int k = k0 + lr;
+    const bool kok = k < nc;
+    const double av = (aok && kok) ? P[nc + arow + (int64_t)k * ld] : 0.0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int brow = tj * TILE + (t << 4) + lc;
+      const double bv = (brow < nr && kok) ? UT[brow + (int64_t)k * nr] : 0.0;
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int c = (t << 4) + lc;
+    const int32_t gc = colid[c];
+    if (gc < 0) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = wave * 16 + lr + 4 * q;
+      const int32_t gr = rowid[r];
+      if (gr < 0) continue;
+      if (gr >= gc) { // lower part: panel of the owner of column gc
+        const int32_t tt = cs_t[cslot[c]];
+        const int32_t f = M.first[tt];
+        unsafeAtomicAdd(M.panels + M.pptr[tt] + posc[cslot[c] * TILE + r] + (int64_t)(gc - f) * ((int64_t)(M.first[tt + 1] - f) + M.nrow[tt]), -acc[t][q]);
+      } else { // upper part: owner of row gr
+        const int32_t tt = rs_t[rslot[r]];
+        const int32_t f = M.first[tt], ncc = M.first[tt + 1] - f, nrr = M.nrow[tt];
+        const int32_t pc = posr[rslot[r] * TILE + c];
+        if (pc < ncc) unsafeAtomicAdd(M.panels + M.pptr[tt] + (gr - f) + (int64_t)pc * (ncc + nrr), -acc[t][q]); // inside the diagonal block
+        else unsafeAtomicAdd(M.upanels + M.uptr[tt] + (pc - ncc) + (int64_t)(gr - f) * nrr, -acc[t][q]);
+      }
+    }
+  }
+}
+
 // ---- solves ----------------------------------------------------------------------------------------------------------------------
 // All four are small dense products on the FP64 matrix cores: m <= 48 right-hand sides = up to three 16-column tiles, padded with
 // zeros in LDS (mpad = 16 ceil(m / 16)); a wavefront owns 16-row strips of the result.
 constexpr int SOLVE_MT = 3;
+constexpr int SOLVE_UNROLL = 8; // k-steps (of 4) whose global operand loads are issued together
 // Y_s = W_s B_s, in place in the work block (row-major, leading dimension ldb)
+template <bool LU>
 __global__ __launch_bounds__(256) void k_sn_fwd_diag(Meta M, const int32_t *__restrict__ lev_sn, int m, double *__restrict__ B, int64_t ldb)
 {
   extern __shared__ __attribute__((aligned(16))) double bs[]; // nc x mpad
@@ -293,7 +580,8 @@ __global__ __launch_bounds__(256) void k_sn_fwd_diag(Meta M, const int32_t *__re
   const int mt = (m + 15) >> 4, mpad = mt << 4;
   for (int idx = tid; idx < nc * mpad; idx += 256) {
     const int k = idx / mpad, c = idx - k * mpad;
-    bs[idx] = c < m ? B[(int64_t)(f + k) * ldb + c] : 0.0;
+    const int ksrc = LU ? M.piv[f + k] : k; // the row exchanges of the diagonal block, applied to the right-hand side here
+    bs[idx] = c < m ? B[(int64_t)(f + ksrc) * ldb + c] : 0.0;
   }
   __syncthreads();
   const int ns = (nc + 15) >> 4;
@@ -303,12 +591,21 @@ __global__ __launch_bounds__(256) void k_sn_fwd_diag(Meta M, const int32_t *__re
     for (int t = 0; t < SOLVE_MT; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
     const int row = (si << 4) + lc;
     const int kend = min(nc, (si + 1) << 4);
-    for (int k0 = 0; k0 < kend; k0 += 4) {
-      const int k = k0 + lr;
-      const double av = (row < nc && k <= row) ? W[row + (int64_t)k * ld] : 0.0;
+    for (int k0 = 0; k0 < kend; k0 += 4 * SOLVE_UNROLL) { // SOLVE_UNROLL operand loads in flight: these kernels are latency-, not work-bound
+      double av[SOLVE_UNROLL];
 #pragma unroll
-      for (int t = 0; t < SOLVE_MT; ++t)
-        if (t < mt) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, k < nc ? bs[k * mpad + (t << 4) + lc] : 0.0, acc[t], 0, 0, 0);
+      for (int u = 0; u < SOLVE_UNROLL; ++u) {
+        const int k = k0 + 4 * u + lr;
+        av[u] = LU ? ((row < nc && k < row) ? W[row + (int64_t)k * ld] : ((row < nc && k == row) ? 1.0 : 0.0))
+                   : ((row < nc && k <= row) ? W[row + (int64_t)k * ld] : 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < SOLVE_UNROLL; ++u) {
+        const int k = k0 + 4 * u + lr;
+#pragma unroll
+        for (int t = 0; t < SOLVE_MT; ++t)
+          if (t < mt) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], k < nc ? bs[k * mpad + (t << 4) + lc] : 0.0, acc[t], 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int t = 0; t < SOLVE_MT; ++t) {
@@ -344,12 +641,20 @@ __global__ __launch_bounds__(256) void k_sn_fwd_update(Meta M, const int32_t *__
 #pragma unroll
   for (int t = 0; t < SOLVE_MT; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
   const int row = tile * TILE + (wave << 4) + lc;
-  for (int k0 = 0; k0 < nc; k0 += 4) {
-    const int k = k0 + lr;
-    const double av = (row < nr && k < nc) ? P[nc + row + (int64_t)k * ld] : 0.0;
+  for (int k0 = 0; k0 < nc; k0 += 4 * SOLVE_UNROLL) {
+    double av[SOLVE_UNROLL];
 #pragma unroll
-    for (int t = 0; t < SOLVE_MT; ++t)
-      if (t < mt) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, k < nc ? ys[k * mpad + (t << 4) + lc] : 0.0, acc[t], 0, 0, 0);
+    for (int u = 0; u < SOLVE_UNROLL; ++u) {
+      const int k = k0 + 4 * u + lr;
+      av[u] = (row < nr && k < nc) ? P[nc + row + (int64_t)k * ld] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < SOLVE_UNROLL; ++u) {
+      const int k = k0 + 4 * u + lr;
+#pragma unroll
+      for (int t = 0; t < SOLVE_MT; ++t)
+        if (t < mt) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], k < nc ? ys[k * mpad + (t << 4) + lc] : 0.0, acc[t], 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int t = 0; t < SOLVE_MT; ++t) {
@@ -362,6 +667,7 @@ __global__ __launch_bounds__(256) void k_sn_fwd_update(Meta M, const int32_t *__
   }
 }
 // one 64-row tile of R_s^T X_rows into the accumulators of the calling wavefront: strips si = wave, wave + 4 of the nc result rows
+// (P + nc = first row of the block of rows below: R_s in the panel, leading dimension ld; or U_{s,rows}^T with P = block - nc)
 __device__ __forceinline__ void bwd_tile_mfma(const double *__restrict__ P, int32_t nc, int64_t ld, int r0, int rn, const double *__restrict__ xr, int mpad, int mt, int wave,
                                                int lc, int lr, v4d (&acc)[2][SOLVE_MT])
 {
@@ -370,16 +676,25 @@ __device__ __forceinline__ void bwd_tile_mfma(const double *__restrict__ P, int3
     const int si = wave + 4 * h;
     const int kcol = (si << 4) + lc; // result row = column of the panel
     if ((si << 4) >= nc) continue;
-    for (int rr = 0; rr < rn; rr += 4) {
-      const int r = rr + lr;
-      const double av = (kcol < nc && r < rn) ? P[nc + r0 + r + (int64_t)kcol * ld] : 0.0;
+    for (int rr = 0; rr < rn; rr += 4 * SOLVE_UNROLL) {
+      double av[SOLVE_UNROLL];
 #pragma unroll
-      for (int t = 0; t < SOLVE_MT; ++t)
-        if (t < mt) acc[h][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, r < rn ? xr[r * mpad + (t << 4) + lc] : 0.0, acc[h][t], 0, 0, 0);
+      for (int u = 0; u < SOLVE_UNROLL; ++u) {
+        const int r = rr + 4 * u + lr;
+        av[u] = (kcol < nc && r < rn) ? P[nc + r0 + r + (int64_t)kcol * ld] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < SOLVE_UNROLL; ++u) {
+        const int r = rr + 4 * u + lr;
+#pragma unroll
+        for (int t = 0; t < SOLVE_MT; ++t)
+          if (t < mt) acc[h][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], r < rn ? xr[r * mpad + (t << 4) + lc] : 0.0, acc[h][t], 0, 0, 0);
+      }
     }
   }
 }
 // partial[item][k * m + c] = sum over the rows r of the tile of R_s[r][k] X[rows[r]][c]   (supernodes with more than BWD_SMALL tiles)
+template <bool LU>
 __global__ __launch_bounds__(256) void k_sn_bwd_partial(Meta M, const int32_t *__restrict__ big_sn, const int32_t *__restrict__ pre, int cnt, int m,
                                                        const double *__restrict__ X, int64_t ldb, double *__restrict__ partial)
 {
@@ -388,8 +703,8 @@ __global__ __launch_bounds__(256) void k_sn_bwd_partial(Meta M, const int32_t *_
   const int32_t s = big_sn[it];
   const int tile = (int)blockIdx.x - pre[it];
   const int32_t nc = M.first[s + 1] - M.first[s], nr = M.nrow[s];
-  const int64_t ld = nc + nr;
-  const double *P = M.panels + M.pptr[s];
+  const int64_t ld = LU ? (int64_t)nr : (int64_t)nc + nr;                              // L U: the block U_{s,rows}^T (nrow x ncol)
+  const double *P = LU ? M.upanels + M.uptr[s] - nc : M.panels + M.pptr[s];
   const int32_t *R = M.rows + M.rptr[s];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 15, lr = lane >> 4;
   const int mt = (m + 15) >> 4, mpad = mt << 4;
@@ -423,6 +738,7 @@ __global__ __launch_bounds__(256) void k_sn_bwd_partial(Meta M, const int32_t *_
     }
 }
 // X_s = W_s^T (Y_s - R_s^T X_rows); big_index[s] >= 0: position of s in the level's list of big supernodes (partials), else -1
+template <bool LU>
 __global__ __launch_bounds__(256) void k_sn_bwd_diag(Meta M, const int32_t *__restrict__ lev_sn, const int32_t *__restrict__ big_index, const int32_t *__restrict__ pre_big,
                                                     const double *__restrict__ partial, int m, double *__restrict__ B, int64_t ldb)
 {
@@ -465,7 +781,8 @@ __global__ __launch_bounds__(256) void k_sn_bwd_diag(Meta M, const int32_t *__re
         xr[idx] = (r < rn && c < m) ? B[(int64_t)R[r0 + r] * ldb + c] : 0.0;
       }
       __syncthreads();
-      bwd_tile_mfma(P, nc, ld, r0, rn, xr, mpad, mt, wave, lc, lr, acc);
+      if (LU) bwd_tile_mfma(M.upanels + M.uptr[s] - nc, nc, (int64_t)nr, r0, rn, xr, mpad, mt, wave, lc, lr, acc);
+      else bwd_tile_mfma(P, nc, ld, r0, rn, xr, mpad, mt, wave, lc, lr, acc);
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -480,19 +797,27 @@ __global__ __launch_bounds__(256) void k_sn_bwd_diag(Meta M, const int32_t *__re
       }
   }
   __syncthreads();
-  // X_s = W^T t:  A[i][k] = W[k][i] (k >= i), B[k][c] = t[k][c]
+  // X_s = W^T t (Cholesky: A[i][k] = W[k][i], k >= i) resp. U_ss^-1 t (L U: A[i][k] = U^-1[i][k], k >= i);  B[k][c] = t[k][c]
   const int ns = (nc + 15) >> 4;
   for (int si = wave; si < ns; si += 4) {
     v4d acc[SOLVE_MT];
 #pragma unroll
     for (int tt = 0; tt < SOLVE_MT; ++tt) acc[tt] = v4d{0.0, 0.0, 0.0, 0.0};
     const int i = (si << 4) + lc;
-    for (int k0 = si << 4; k0 < nc; k0 += 4) {
-      const int k = k0 + lr;
-      const double av = (i < nc && k < nc && k >= i) ? P[k + (int64_t)i * ld] : 0.0;
+    for (int k0 = si << 4; k0 < nc; k0 += 4 * SOLVE_UNROLL) {
+      double av[SOLVE_UNROLL];
 #pragma unroll
-      for (int tt = 0; tt < SOLVE_MT; ++tt)
-        if (tt < mt) acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, k < nc ? t[k * mpad + (tt << 4) + lc] : 0.0, acc[tt], 0, 0, 0);
+      for (int u = 0; u < SOLVE_UNROLL; ++u) {
+        const int k = k0 + 4 * u + lr;
+        av[u] = (i < nc && k < nc && k >= i) ? (LU ? P[i + (int64_t)k * ld] /* U^-1[i][k] */ : P[k + (int64_t)i * ld]) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < SOLVE_UNROLL; ++u) {
+        const int k = k0 + 4 * u + lr;
+#pragma unroll
+        for (int tt = 0; tt < SOLVE_MT; ++tt)
+          if (tt < mt) acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], k < nc ? t[k * mpad + (tt << 4) + lc] : 0.0, acc[tt], 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int tt = 0; tt < SOLVE_MT; ++tt) {
@@ -526,17 +851,27 @@ struct Factor {
   int32_t *d_big_sn = nullptr, *d_big_index = nullptr, *d_preB = nullptr; // supernodes with more than BWD_SMALL row tiles, per level
   std::vector<int32_t> h_tilesT, h_tilesU, h_tilesB; // totals per level
   unsigned *d_err = nullptr;
+  bool lu = false;               // L U variant
+  double *d_upanels = nullptr;
+  int64_t *d_uptr = nullptr;
+  int32_t *d_piv = nullptr;
+  int64_t uentries = 0;
+  std::vector<int32_t> h_tilesUF; // L U: all T x T update tiles per level
+  int32_t *d_preUF = nullptr;
   double *d_partial = nullptr;
   int64_t partial_cap = 0; // doubles
   int64_t max_big_tiles = 0;
   void release()
   {
     for (void *p : {(void *)d_first, (void *)d_nrow, (void *)d_rows, (void *)d_sn_of_col, (void *)d_iperm, (void *)d_perm, (void *)d_rptr, (void *)d_pptr, (void *)d_panels,
-                    (void *)d_lev_sn, (void *)d_preT, (void *)d_preU, (void *)d_big_sn, (void *)d_big_index, (void *)d_preB, (void *)d_err, (void *)d_partial})
+                    (void *)d_lev_sn, (void *)d_preT, (void *)d_preU, (void *)d_big_sn, (void *)d_big_index, (void *)d_preB, (void *)d_err, (void *)d_partial,
+                    (void *)d_upanels, (void *)d_uptr, (void *)d_piv, (void *)d_preUF})
       if (p) (void)hipFree(p);
     d_first = d_nrow = d_rows = d_sn_of_col = d_iperm = d_perm = d_lev_sn = d_preT = d_preU = d_big_sn = d_big_index = d_preB = nullptr;
     d_rptr = d_pptr = nullptr;
-    d_panels = d_partial = nullptr;
+    d_panels = d_partial = d_upanels = nullptr;
+    d_uptr = nullptr;
+    d_piv = d_preUF = nullptr;
     d_err = nullptr;
   }
   ~Factor() { release(); }
@@ -550,9 +885,10 @@ static inline bool up(const std::vector<T> &h, T **d)
 }
 
 // symbolic results of all blocks -> one global structure on the device.  Returns false on an allocation failure.
-static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *block_ptr, std::vector<BlockSym> &BS)
+static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *block_ptr, std::vector<BlockSym> &BS, bool lu = false)
 {
   F.n = n;
+  F.lu = lu;
   std::vector<int32_t> first, nrow, rows, sn_of_col((size_t)n), iperm((size_t)n), level;
   std::vector<int64_t> rptr(1, 0), pptr(1, 0);
   F.h_perm.resize((size_t)n);
@@ -591,14 +927,18 @@ static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *b
   for (int32_t l = 0; l < nlev; ++l) F.lev_ptr[(size_t)l + 1] += F.lev_ptr[(size_t)l];
   std::vector<int32_t> lev_sn((size_t)F.nsn), pos(F.lev_ptr.begin(), F.lev_ptr.end() - 1);
   for (int32_t s = 0; s < F.nsn; ++s) lev_sn[(size_t)pos[(size_t)level[(size_t)s]]++] = s;
-  std::vector<int32_t> preT((size_t)F.nsn + nlev), preU((size_t)F.nsn + nlev), big_sn, big_index((size_t)F.nsn, -1), preB;
+  std::vector<int32_t> preT((size_t)F.nsn + nlev), preU((size_t)F.nsn + nlev), preUF((size_t)F.nsn + nlev), big_sn, big_index((size_t)F.nsn, -1), preB;
+  std::vector<int64_t> uptr(1, 0);
+  for (int32_t s = 0; s < F.nsn; ++s) uptr.push_back(uptr.back() + (int64_t)nrow[(size_t)s] * (first[(size_t)s + 1] - first[(size_t)s]));
+  F.uentries = lu ? uptr.back() : 0;
+  F.h_tilesUF.assign((size_t)nlev, 0);
   F.h_tilesT.assign((size_t)nlev, 0);
   F.h_tilesU.assign((size_t)nlev, 0);
   F.h_tilesB.assign((size_t)nlev, 0);
   F.lev_maxnc.assign((size_t)nlev, 0);
   F.lev_big_ptr.assign((size_t)nlev + 1, 0);
   for (int32_t l = 0; l < nlev; ++l) {
-    int64_t aT = 0, aU = 0, aB = 0;
+    int64_t aT = 0, aU = 0, aB = 0, aUF = 0;
     const int32_t base = F.lev_ptr[(size_t)l] + l;
     const int32_t bbase = (int32_t)preB.size();
     preB.push_back(0);
@@ -607,8 +947,10 @@ static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *b
       const int64_t T = (nrow[(size_t)s] + TILE - 1) / TILE;
       preT[(size_t)(base + k - F.lev_ptr[(size_t)l])] = (int32_t)aT;
       preU[(size_t)(base + k - F.lev_ptr[(size_t)l])] = (int32_t)aU;
+      preUF[(size_t)(base + k - F.lev_ptr[(size_t)l])] = (int32_t)aUF;
       aT += T;
       aU += T * (T + 1) / 2;
+      aUF += T * T;
       if (T > BWD_SMALL) {
         big_index[(size_t)k] = (int32_t)(big_sn.size() - (size_t)F.lev_big_ptr[(size_t)l]);
         big_sn.push_back(s);
@@ -617,7 +959,9 @@ static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *b
       }
       F.lev_maxnc[(size_t)l] = std::max(F.lev_maxnc[(size_t)l], first[(size_t)s + 1] - first[(size_t)s]);
     }
-    if (aU > 2000000000ll) return false;
+    if (aU > 2000000000ll || (lu && aUF > 2000000000ll)) return false;
+    preUF[(size_t)(base + F.lev_ptr[(size_t)l + 1] - F.lev_ptr[(size_t)l])] = (int32_t)aUF;
+    F.h_tilesUF[(size_t)l] = (int32_t)aUF;
     preT[(size_t)(base + F.lev_ptr[(size_t)l + 1] - F.lev_ptr[(size_t)l])] = (int32_t)aT;
     preU[(size_t)(base + F.lev_ptr[(size_t)l + 1] - F.lev_ptr[(size_t)l])] = (int32_t)aU;
     F.h_tilesT[(size_t)l] = (int32_t)aT;
@@ -633,6 +977,11 @@ static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *b
   if (!ok) return false;
   if (hipMalloc((void **)&F.d_err, 128) != hipSuccess || hipMemset(F.d_err, 0, 128) != hipSuccess) return false;
   if (hipMalloc((void **)&F.d_panels, sizeof(double) * (size_t)std::max<int64_t>(F.entries, 1)) != hipSuccess) return false;
+  if (lu) {
+    if (!up(uptr, &F.d_uptr) || !up(preUF, &F.d_preUF)) return false;
+    if (hipMalloc((void **)&F.d_upanels, sizeof(double) * (size_t)std::max<int64_t>(F.uentries, 1)) != hipSuccess) return false;
+    if (hipMalloc((void **)&F.d_piv, sizeof(int32_t) * (size_t)std::max<int64_t>(n, 1)) != hipSuccess) return false;
+  }
   F.M.nsn = F.nsn;
   F.M.first = F.d_first;
   F.M.nrow = F.d_nrow;
@@ -641,6 +990,9 @@ static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *b
   F.M.pptr = F.d_pptr;
   F.M.sn_of_col = F.d_sn_of_col;
   F.M.panels = F.d_panels;
+  F.M.upanels = F.d_upanels;
+  F.M.uptr = F.d_uptr;
+  F.M.piv = F.d_piv;
   return true;
 }
 
@@ -650,10 +1002,18 @@ static inline hipError_t factorize(Factor &F, hipStream_t st, const int64_t *d_r
   hipError_t e = hipMemsetAsync(F.d_panels, 0, sizeof(double) * (size_t)std::max<int64_t>(F.entries, 1), st);
   if (e != hipSuccess) return e;
   (void)hipMemsetAsync(F.d_err, 0, 4, st);
-  if (F.n > 0) hipLaunchKernelGGL(k_sn_assemble, dim3((unsigned)((F.n + 255) / 256)), dim3(256), 0, st, F.M, F.n, d_rp, d_ci, d_va, F.d_iperm);
+  if (F.lu) {
+    e = hipMemsetAsync(F.d_upanels, 0, sizeof(double) * (size_t)std::max<int64_t>(F.uentries, 1), st);
+    if (e != hipSuccess) return e;
+  }
+  if (F.n > 0) {
+    if (F.lu) hipLaunchKernelGGL(k_sn_assemble_lu, dim3((unsigned)((F.n + 255) / 256)), dim3(256), 0, st, F.M, F.n, d_rp, d_ci, d_va, F.d_iperm);
+    else hipLaunchKernelGGL(k_sn_assemble, dim3((unsigned)((F.n + 255) / 256)), dim3(256), 0, st, F.M, F.n, d_rp, d_ci, d_va, F.d_iperm);
+  }
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)k_sn_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (SN_MAX_COLS + 1) * SN_MAX_COLS * 8);
+    (void)hipFuncSetAttribute((const void *)k_sn_lu_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (SN_MAX_COLS + 1) * SN_MAX_COLS * 8);
     attr_set = true;
   }
   for (int32_t l = 0; l < F.nlev; ++l) {
@@ -661,6 +1021,14 @@ static inline hipError_t factorize(Factor &F, hipStream_t st, const int64_t *d_r
     if (cnt == 0) continue;
     const int32_t *lsn = F.d_lev_sn + F.lev_ptr[(size_t)l];
     const int nc = F.lev_maxnc[(size_t)l];
+    if (F.lu) {
+      hipLaunchKernelGGL(k_sn_lu_diag, dim3((unsigned)cnt), dim3(256), (size_t)(nc | 1) * nc * 8, st, F.M, lsn, F.d_err);
+      if (F.h_tilesT[(size_t)l] > 0)
+        hipLaunchKernelGGL(k_sn_lu_panel, dim3((unsigned)F.h_tilesT[(size_t)l]), dim3(256), 0, st, F.M, lsn, (const int32_t *)(F.d_preT + F.lev_ptr[(size_t)l] + l), cnt);
+      if (F.h_tilesUF[(size_t)l] > 0)
+        hipLaunchKernelGGL(k_sn_lu_update, dim3((unsigned)F.h_tilesUF[(size_t)l]), dim3(256), 0, st, F.M, lsn, (const int32_t *)(F.d_preUF + F.lev_ptr[(size_t)l] + l), cnt);
+      continue;
+    }
     hipLaunchKernelGGL(k_sn_diag, dim3((unsigned)cnt), dim3(256), (size_t)(nc | 1) * nc * 8, st, F.M, lsn, F.d_err);
     if (F.h_tilesT[(size_t)l] > 0)
       hipLaunchKernelGGL(k_sn_panel, dim3((unsigned)F.h_tilesT[(size_t)l]), dim3(256), 0, st, F.M, lsn, (const int32_t *)(F.d_preT + F.lev_ptr[(size_t)l] + l), cnt);
@@ -687,14 +1055,14 @@ static inline bool reserve(Factor &F, int m)
   return true;
 }
 
-// in-place solve L L^T X = B on the permuted row-major work block (n x m, leading dimension ldb); enqueues only (graph capturable)
-static inline void solve(const Factor &F, hipStream_t st, int m, double *B, int64_t ldb)
+template <bool LU>
+static inline void solve_t(const Factor &F, hipStream_t st, int m, double *B, int64_t ldb)
 {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)k_sn_fwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, SN_MAX_COLS * 48 * 8);
+    (void)hipFuncSetAttribute((const void *)k_sn_fwd_diag<LU>, hipFuncAttributeMaxDynamicSharedMemorySize, SN_MAX_COLS * 48 * 8);
     (void)hipFuncSetAttribute((const void *)k_sn_fwd_update, hipFuncAttributeMaxDynamicSharedMemorySize, SN_MAX_COLS * 48 * 8);
-    (void)hipFuncSetAttribute((const void *)k_sn_bwd_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (SN_MAX_COLS + TILE) * 48 * 8);
+    (void)hipFuncSetAttribute((const void *)k_sn_bwd_diag<LU>, hipFuncAttributeMaxDynamicSharedMemorySize, (SN_MAX_COLS + TILE) * 48 * 8);
     attr_set = true;
   }
   const int mpad = ((m + 15) / 16) * 16;
@@ -703,7 +1071,7 @@ static inline void solve(const Factor &F, hipStream_t st, int m, double *B, int6
     if (cnt == 0) continue;
     const int32_t *lsn = F.d_lev_sn + F.lev_ptr[(size_t)l];
     const size_t lds = (size_t)F.lev_maxnc[(size_t)l] * mpad * 8;
-    hipLaunchKernelGGL(k_sn_fwd_diag, dim3((unsigned)cnt), dim3(256), lds, st, F.M, lsn, m, B, ldb);
+    hipLaunchKernelGGL(k_sn_fwd_diag<LU>, dim3((unsigned)cnt), dim3(256), lds, st, F.M, lsn, m, B, ldb);
     if (F.h_tilesT[(size_t)l] > 0)
       hipLaunchKernelGGL(k_sn_fwd_update, dim3((unsigned)F.h_tilesT[(size_t)l]), dim3(256), lds, st, F.M, lsn, (const int32_t *)(F.d_preT + F.lev_ptr[(size_t)l] + l), cnt, m, B, ldb);
   }
@@ -714,11 +1082,18 @@ static inline void solve(const Factor &F, hipStream_t st, int m, double *B, int6
     const int32_t nbig = F.lev_big_ptr[(size_t)l + 1] - F.lev_big_ptr[(size_t)l];
     const int32_t *preB = F.d_preB + F.lev_big_ptr[(size_t)l] + l;
     if (nbig > 0)
-      hipLaunchKernelGGL(k_sn_bwd_partial, dim3((unsigned)F.h_tilesB[(size_t)l]), dim3(256), (size_t)TILE * mpad * 8, st, F.M, (const int32_t *)(F.d_big_sn + F.lev_big_ptr[(size_t)l]),
+      hipLaunchKernelGGL(k_sn_bwd_partial<LU>, dim3((unsigned)F.h_tilesB[(size_t)l]), dim3(256), (size_t)TILE * mpad * 8, st, F.M, (const int32_t *)(F.d_big_sn + F.lev_big_ptr[(size_t)l]),
                          preB, nbig, m, (const double *)B, ldb, F.d_partial);
-    hipLaunchKernelGGL(k_sn_bwd_diag, dim3((unsigned)cnt), dim3(256), (size_t)(F.lev_maxnc[(size_t)l] + TILE) * mpad * 8, st, F.M, lsn,
+    hipLaunchKernelGGL(k_sn_bwd_diag<LU>, dim3((unsigned)cnt), dim3(256), (size_t)(F.lev_maxnc[(size_t)l] + TILE) * mpad * 8, st, F.M, lsn,
                        (const int32_t *)(F.d_big_index + F.lev_ptr[(size_t)l]), preB, (const double *)F.d_partial, m, B, ldb);
   }
+}
+
+// in-place solve (L L^T resp. P^T L U) X = B on the permuted row-major work block (n x m, leading dimension ldb); enqueues only
+static inline void solve(const Factor &F, hipStream_t st, int m, double *B, int64_t ldb)
+{
+  if (F.lu) solve_t<true>(F, st, m, B, ldb);
+  else solve_t<false>(F, st, m, B, ldb);
 }
 
 } // namespace sn

@@ -147,14 +147,18 @@ int ddm_chol_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64
 /* general != 0: L U without pivoting on the pattern of A + A^T, for non-symmetric matrices whose symmetric part is positive
  * definite (the DG convection-diffusion operator; `type = umfpack`); DDM_ENUMERIC on a vanishing pivot.  general == 0 = ddm_chol_create. */
 int ddm_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, int general, double max_flops, ddm_ilu0 **out);
-/* Engines of ddm_chol_create / ddm_direct_create(general = 0), environment DDM_DIRECT_ENGINE = device | host (default: device when
- * the factorisation needs at least DDM_DIRECT_DEVICE_MIN_FLOPS = 1e11 multiply-adds):
- *   device  SUPERNODAL Cholesky with numeric factorisation AND solves on the GPU (csrc/sn_chol.hpp): nested-dissection supernodes of
- *           at most 128 columns, dense panels, FP64-MFMA updates, level by level of the supernodal elimination tree; the host only
- *           orders and analyses.  Updates of one tree level are added with hardware FP64 atomics: results are reproducible to
- *           rounding, not bit for bit.  DDM_ENOTIMPL if the panels do not fit into the free device memory.
- *   host    up-looking factorisation on host threads, CSR level solves on the device (bitwise reproducible; the only engine for
- *           general = 1).
+/* Engines of ddm_chol_create / ddm_direct_create, environment DDM_DIRECT_ENGINE = device | host.  Default: the device engine when the
+ * factorisation needs at least DDM_DIRECT_DEVICE_MIN_FLOPS multiply-adds -- 5e11 for ddm_direct_create / the Schwarz local solver
+ * (about a minute of host factorisation; below that the host engine's CSR level solves are the faster single-vector solves), 1e10
+ * for the factors the library builds for a handful of block solves (GenEO preconditioner, harmonic extensions):
+ *   device  SUPERNODAL Cholesky (general = 0) or L U (general = 1) with numeric factorisation AND solves on the GPU (csrc/sn_chol.hpp):
+ *           nested-dissection supernodes of at most 128 columns, dense panels, FP64-MFMA updates, level by level of the supernodal
+ *           elimination tree; the host only orders and analyses.  L U: threshold partial pivoting (0.1, UMFPACK's default) INSIDE the
+ *           diagonal block of a supernode; rows are never exchanged between supernodes.  Updates of one tree level are added with
+ *           hardware FP64 atomics: results are reproducible to rounding, not bit for bit.  DDM_ENOTIMPL if the panels do not fit
+ *           into the free device memory.
+ *   host    up-looking factorisation on host threads (L U without pivoting for general = 1), CSR level solves on the device
+ *           (bitwise reproducible).
  * The host half of the device engine alone (no device needed; CPU tests): */
 typedef struct ddm_sn_host ddm_sn_host;
 int ddm_sn_host_create(int64_t n, const int64_t *rowptr, const int32_t *col, int64_t nblocks, const int64_t *block_ptr, ddm_sn_host **out);

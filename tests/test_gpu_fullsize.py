@@ -127,7 +127,7 @@ def test_full_length_cg_parity_geneo_96(ddm):
           [(k, f"{ho[k] / ho[0]:.1e}", f"{rel[k]:.1e}", f"{env[k]:.1e}") for k in range(0, m, 10)])
     early = ho[:m] >= 2e-3 * ho[0]
     assert early.sum() >= 30 and (dev[early] <= 1e-8 * ho[:m][early]).all(), float(np.max(dev[early] / ho[:m][early]))
-    ENVELOPE_FACTOR = 5.0             # measured: 0.70 (the HIP run deviates LESS from the oracle than the oracle from its re-ordered self)
+    ENVELOPE_FACTOR = 10.0            # measured: 0.70 and 2.59 in two runs (the HIP run deviates about as much from the oracle as the oracle from its re-ordered self)
     bound = np.maximum(1e-8, ENVELOPE_FACTOR * env)
     worst = int(np.argmax(rel / bound))
     print(f"[96^3 GenEO] max over k of (hip-vs-oracle deviation) / max(1e-8, envelope): {np.max(rel / np.maximum(1e-8, env)):.2f} at k = {int(np.argmax(rel / np.maximum(1e-8, env)))}")
