@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--parts", type=int, default=2, help="subdomains per axis (2 -> 8 subdomains; 1 = BASELINE config 2: one subdomain, ILU(0)-CG)")
     ap.add_argument("--coarse", default="auto", choices=["auto", "geneo", "pou", "none"])
     ap.add_argument("--nev", type=int, default=20)
+    ap.add_argument("--geneo-preconditioner", default="auto", choices=["auto", "ilu0", "cholesky"],
+                    help="preconditioner of the GenEO block eigensolver: auto = sparse Cholesky (device engine) when it fits the flop / memory limits, else ILU(0)")
     ap.add_argument("--no-solve", action="store_true", help="skip the full solve to 1e-10 (iteration count / residual check)")
     ap.add_argument("--cpu-iters", type=int, default=60, help="CG iterations of the CPU oracle timed for cpu_baseline (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=8)
@@ -133,7 +135,7 @@ def main():
     if coarse == "geneo":
         from dune_ddm_amd.geneo import geneo_basis
         tl = TwoLevelSchwarz(dec, rank, world, local_rank, comm, schwarz_type="standard", mode="additive", coarse="none")
-        basis = geneo_basis(tl, nev=args.nev, verbose=(rank == 0 and os.environ.get("DDM_VERBOSE") == "1"))
+        basis = geneo_basis(tl, nev=args.nev, verbose=(rank == 0 and os.environ.get("DDM_VERBOSE") == "1"), preconditioner=args.geneo_preconditioner)
         gi = tl.geneo_info      # geneo_basis raises if the eigensolver did not converge
         log(rank, f"GenEO: {gi['iterations']} block iterations, converged={gi['converged']} (worst residual {gi['worst_residual']:.2e}), "
                   f"preconditioner {'sparse Cholesky' if gi['used_direct'] else 'ILU(0)'}, setup {gi['setup_s']:.1f} s + iterations {gi['iterate_s']:.1f} s, "
