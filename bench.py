@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--parts", type=int, default=2, help="subdomains per axis (2 -> 8 subdomains; 1 = BASELINE config 2: one subdomain, ILU(0)-CG)")
     ap.add_argument("--coarse", default="auto", choices=["auto", "geneo", "pou", "none"])
     ap.add_argument("--nev", type=int, default=20)
+    ap.add_argument("--local-solver", default="ilu0", choices=["ilu0", "cholmod"],
+                    help="[schwarz.subdomain_solver] type: ilu0 (the benchmark's configuration) or cholmod (the reference's shipped .ini: sparse Cholesky, "
+                         "factorised on the device from 5e11 multiply-adds on)")
     ap.add_argument("--geneo-preconditioner", default="auto", choices=["auto", "ilu0", "cholesky"],
                     help="preconditioner of the GenEO block eigensolver: auto = sparse Cholesky (device engine) when it fits the flop / memory limits, else ILU(0)")
     ap.add_argument("--no-solve", action="store_true", help="skip the full solve to 1e-10 (iteration count / residual check)")
@@ -134,7 +137,7 @@ def main():
     t1 = time.perf_counter()
     if coarse == "geneo":
         from dune_ddm_amd.geneo import geneo_basis
-        tl = TwoLevelSchwarz(dec, rank, world, local_rank, comm, schwarz_type="standard", mode="additive", coarse="none")
+        tl = TwoLevelSchwarz(dec, rank, world, local_rank, comm, schwarz_type="standard", mode="additive", coarse="none", subdomain_solver=args.local_solver)
         basis = geneo_basis(tl, nev=args.nev, verbose=(rank == 0 and os.environ.get("DDM_VERBOSE") == "1"), preconditioner=args.geneo_preconditioner)
         gi = tl.geneo_info      # geneo_basis raises if the eigensolver did not converge
         log(rank, f"GenEO: {gi['iterations']} block iterations, converged={gi['converged']} (worst residual {gi['worst_residual']:.2e}), "
@@ -157,7 +160,7 @@ def main():
         tl.set_coarse_basis(basis)
         tl.rebuild_combined("additive")
     else:
-        tl = TwoLevelSchwarz(dec, rank, world, local_rank, comm, schwarz_type="standard", mode="additive", coarse=coarse)
+        tl = TwoLevelSchwarz(dec, rank, world, local_rank, comm, schwarz_type="standard", mode="additive", coarse=coarse, subdomain_solver=args.local_solver)
     tl.ctx.sync()
     t_dev = time.perf_counter() - t1 - (geneo_check["seconds"] if geneo_check else 0.0)
     log(rank, f"device setup (upload, ILU(0), level schedule, coarse space '{coarse}', R A R^T): {t_dev:.1f} s; "
@@ -209,17 +212,19 @@ def main():
     # + 40 B per row (d read, x written, x read + written by the backward sweep, inverse pivot).
     z, n = tl.A_dir.nnz, tl.rl.n
     alg_bytes = 12.0 * z + 40.0 * n
+    if args.local_solver != "ilu0":      # direct factor: its stored entries once per sweep (8 B each in the device engine's panels)
+        alg_bytes = 16.0 * tl.schwarz.factor_nnz() + 40.0 * n
     roofline = None
     if local_cnt > 0:
         avg_ms = local_ms / local_cnt
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        engine = os.environ.get("DDM_TRSV_MODE", "pipe")
+        engine = os.environ.get("DDM_TRSV_MODE", "pipe") if args.local_solver == "ilu0" else "direct"
         kname = {"levels": "k_trsv_lower_level + k_trsv_upper_level + k_trsv_small_levels (one launch per level, HIP graph)",
-                 "xcd2": "k_trsv_xcd2"}.get(engine, "k_trsv_pipe (+ k_pipe_permute_in/out)")
+                 "xcd2": "k_trsv_xcd2", "direct": "sparse direct factor (sn_chol.hpp panel solves or CSR level solves)"}.get(engine, "k_trsv_pipe (+ k_pipe_permute_in/out)")
         traffic, traffic_source = None, None
         try:   # HBM bytes per launch: NOT measured in this run -- read from the committed rocprofv3 --pmc passes of this command
             #    (profiles/, separate FETCH_SIZE / WRITE_SIZE runs, gfx950-corrected: 2 x FETCH_SIZE + WRITE_SIZE); the file is named in the line
-            traffic_source = "profiles/r02_pmc_traffic_grid216_geneo.json"
+            traffic_source = "profiles/r03_pmc_traffic_grid216_geneo.json"
             if not os.path.exists(os.path.join(ROOT, traffic_source)):
                 traffic_source = "profiles/r01_h_pmc_traffic_grid216_pipe.json"
             pmc = json.load(open(os.path.join(ROOT, traffic_source)))
@@ -227,7 +232,7 @@ def main():
                 traffic = pmc["kernels"][pmc["engine_kernels"][engine]]["hbm_bytes_per_dispatch_corrected"] / world
         except Exception:
             traffic = None
-        roofline = {"bound": "hbm", "kernel": f"ILU(0) triangular solve: {kname}",
+        roofline = {"bound": "hbm", "kernel": f"{'ILU(0)' if args.local_solver == 'ilu0' else args.local_solver} triangular solve: {kname}",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
                     "launches_timed": int(local_cnt)}
@@ -240,7 +245,7 @@ def main():
 
     # ---- CPU baseline: the oracle (port of the reference's CPU path) on the host cores ----------
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_iters > 0:
+    if rank == 0 and world == 1 and args.cpu_iters > 0 and args.local_solver == "ilu0":   # (the oracle's exact local solver is SuperLU: minutes at these sizes)
         from oracle import apply_oracle as ao
         from tests.oracle_bridge import oracle_time_iterations
         threads = max(1, min(args.cpu_threads, os.cpu_count() or 1, dec.nsub))
@@ -310,7 +315,7 @@ def main():
             "exchange": tl.exchange, "rccl_comm_size": tl.ctx.rccl_size(), "ranks_share_devices": bool(shared), "visible_devices": ndev,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"3D Q1 Poisson {G}^3 = {ndof} DoF, {P ** 3} overlapping subdomains ({P}x{P}x{P}, overlap {args.overlap}), "
-                                   f"ILU(0) subdomain solves, coarse space '{coarse}' (K = {0 if tl.galerkin is None else tl.K}), additive, CG",
+                                   f"{'ILU(0)' if args.local_solver == 'ilu0' else args.local_solver} subdomain solves, coarse space '{coarse}' (K = {0 if tl.galerkin is None else tl.K}), additive, CG",
                        "subdomains_per_gpu": (P ** 3) // world, "parallelism": f"dd{world}"},
             "dof_iters_per_sec": ndof * its_per_s,
             "solve": solve_info,

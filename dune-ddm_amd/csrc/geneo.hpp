@@ -382,6 +382,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
   std::vector<int32_t> ciT;
   std::vector<double> vaT, vaC;
   build_pencil_host(A_neu, B_neu, pou_pencil_host ? pou_pencil_host : pou_host, dirichlet_host, P.shift, rpT, ciT, vaT, vaC);
+  const double t_pencil = since(t_begin);
   struct Owned {
     ddm_csr *At = nullptr, *C = nullptr;
     ddm_ilu0 *T = nullptr;
@@ -395,6 +396,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
   DDMCHECK(ddm_csr_create(ctx, n, n, rpT.data(), ciT.data(), vaT.data(), &own.At));
   DDMCHECK(ddm_csr_create(ctx, n, n, rpT.data(), ciT.data(), vaC.data(), &own.C));
   { std::vector<double>().swap(vaT); std::vector<double>().swap(vaC); }
+  const double t_upload = since(t_begin);
   // A~ X and C~ X of the same block in one pass (the two matrices share their pattern: build_pencil_host)
   auto apply_AC = [&](int mm, const double *X, int64_t ldx, double *YA, double *YC, int64_t ldy) -> int {
     if (!op_C) return csr_mm2_ld(ctx, own.At, own.C, mm, X, ldx, YA, YC, ldy);
@@ -409,8 +411,12 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
     else if (P.preconditioner == 2 || (rc != DDM_ENOTIMPL && rc != DDM_ENUMERIC)) return rc;
     else if (P.verbose) std::fprintf(stderr, "[ddm geneo] sparse Cholesky not used (%s): ILU(0) preconditioner\n", ddm_last_error(ctx));
   }
+  const double t_direct = since(t_begin);
   if (!direct) DDMCHECK(ilu0_create_impl(ctx, own.At, nsub, sub_ptr, /*multi_rhs_only=*/true, &own.T));
   const double t_setup = since(t_begin);
+  if (P.verbose)
+    std::fprintf(stderr, "[ddm geneo] setup: pencil %.2f s, two CSR uploads %.2f s, sparse direct attempt %.2f s (%s), ILU(0) %.2f s\n", t_pencil, t_upload - t_pencil,
+                 t_direct - t_upload, direct ? "used" : "declined", t_setup - t_direct);
   // ---- work space ----
   GeneoWork W;
   W.ctx = ctx;

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(WG) void k_spmm_rowmajor(int64_t n, int nrhs, const
                                                        const int32_t *__restrict__ ci, const double *__restrict__ va,
                                                        const double *__restrict__ x, int64_t ldx, double *__restrict__ y, int64_t ldy)
 {
-  const int64_t t = (int64_t)xcd_remap((int)blockIdx.x, (int)gridDim.x) * WG + threadIdx.x; // (see k_spmm_rowmajor4)
+  const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x;
   const int64_t row = t / nrhs;
   if (row >= n) return;
   const int j = (int)(t - row * nrhs);
@@ -255,10 +255,11 @@ __global__ __launch_bounds__(WG) void k_spmm_rowmajor4(int64_t n, int nq /* nrhs
                                                         double *__restrict__ y, double *__restrict__ y2, int64_t ldy)
 {
   typedef double d4 __attribute__((ext_vector_type(4)));
-  // XCD-aware block order: each XCD walks ONE contiguous eighth of the rows, so the rows of X a workgroup gathers (the 27 stencil
-  // neighbours: reuse distance two grid planes) are shared through that XCD's L2 instead of being fetched by all eight L2s
-  // (round 2: 30 GB of L2 fills per call for ~12 GB of algorithmic traffic)
-  const int64_t t = (int64_t)xcd_remap((int)blockIdx.x, (int)gridDim.x) * WG + threadIdx.x;
+  // (An XCD-contiguous block order was measured in round 3 and changes nothing: 29.7 GB of L2 fills per call either way, 8.7 ms.  The
+  // misses are not the eight L2s duplicating each other but the reuse distance itself -- two grid planes of X rows, 8 MB with the
+  // 576-byte row stride of the [X | W | P] array, against 4 MB of L2: every row of X is fetched once per plane.  What would help is a
+  // cache-blocked ROW ORDER (bricks instead of planes), i.e. a host-side permutation of the processing order.)
+  const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x;
   const int64_t row = t / nq;
   if (row >= n) return;
   const int j = 4 * (int)(t - row * nq);
