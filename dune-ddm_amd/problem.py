@@ -52,6 +52,19 @@ class Decomposition:
         return len(self.subs)
 
 
+def _pmap(fn, items):
+    """[fn(x) for x in items] on host threads: the per-subdomain matrix generation is large numpy array arithmetic, which releases
+    the GIL (216^3: 34 s of the run time of bench.py were this loop, sequential).  DDM_HOST_THREADS = 1 switches it off."""
+    import os
+    items = list(items)
+    nt = min(len(items), int(os.environ.get("DDM_HOST_THREADS", min(8, os.cpu_count() or 1))))
+    if nt <= 1:
+        return [fn(x) for x in items]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(nt) as ex:
+        return list(ex.map(fn, items))
+
+
 def build_structured(grid, overlap=2, pou_type="distance", shrink=0, neumann=False, second_region="overlap") -> Decomposition:
     """Runs the L3 setup of the reference (make_communication ->
     make_overlapping_communication -> assemble_overlapping_matrices -> PartitionOfUnity) on one of the
@@ -59,7 +72,7 @@ def build_structured(grid, overlap=2, pou_type="distance", shrink=0, neumann=Fal
     A_neu (NeumannRegion::All) and B_neu: on NeumannRegion::Overlap as examples/poisson.cc:206 and
     examples/pdelab_schwarz.hh:62 request for GenEO, or, with second_region="all", the same matrix as A_neu
     (examples/linearelasticity.hh:222)."""
-    nov = grid.subdomains()
+    nov = _pmap(grid.subdomain, range(grid.nranks)) if hasattr(grid, "subdomain") else grid.subdomains()
     ng = grid.nglobal
     if grid.nranks == 1:
         s = nov[0]
@@ -72,12 +85,12 @@ def build_structured(grid, overlap=2, pou_type="distance", shrink=0, neumann=Fal
     ovlp_all = sh.interface_pairs(idx, ng, "all_to_all")
     ovlp_owner = sh.interface_pairs(idx, ng, "owner_to_all")
     dmask = [grid.dirichlet_of(i.glob) for i in idx]
-    A_dir = [grid.dirichlet_matrix(i.glob, dm) for i, dm in zip(idx, dmask)]
+    A_dir = _pmap(lambda t: grid.dirichlet_matrix(t[0].glob, t[1]), list(zip(idx, dmask)))
     pou, bmask, dist = sh.partition_of_unity(idx, A_dir, ovlp_all, ng, pou_type, shrink, overlap)
     if bmask is None and neumann:
         bmask = sh.subdomain_boundary(idx, A_dir, ng)
-    subs = []
-    for r, (s, i) in enumerate(zip(nov, idx)):
+    def one(r):
+        s, i = nov[r], idx[r]
         sd = SubdomainData(r, i.n_o, len(i.glob), i.glob, s.A, s.owner, s.b, A_dir[r], i.owner, dmask[r], pou[r])
         if bmask is not None:
             sd.boundary = np.asarray(bmask[r], dtype=bool)
@@ -86,7 +99,9 @@ def build_structured(grid, overlap=2, pou_type="distance", shrink=0, neumann=Fal
             sd.boundary_dist = d
             sd.A_neu = grid.neumann_matrix(i.glob, None, dmask[r])
             sd.B_neu = sd.A_neu if second_region == "all" else grid.neumann_matrix(i.glob, d <= 2 * overlap, dmask[r])
-        subs.append(sd)
+        return sd
+
+    subs = _pmap(one, range(len(nov)))
     return Decomposition(subs, novlp_all, ovlp_owner, ovlp_all, overlap, ng,
                          {"pou_type": pou_type, "shrink": shrink, "ext_boundary": [i.ext_boundary for i in idx],
                           "boundary": bmask})
