@@ -1284,6 +1284,7 @@ static int sn_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, con
   const int32_t *ci = A->h_ci.data();
   std::vector<sn::BlockSym> BS((size_t)nblocks);
   std::vector<int> bad((size_t)nblocks, 0);
+  std::vector<double> quick((size_t)nblocks, 0.0);
   {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const int nthreads = (int)std::min<int64_t>(nblocks, hw);
@@ -1296,13 +1297,24 @@ static int sn_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, con
             for (int64_t k = rp[i]; k < rp[i + 1]; ++k)
               if (ci[k] < r0 || ci[k] >= r1) bad[(size_t)b] = 1;
           if (bad[(size_t)b]) continue;
-          BS[(size_t)b] = sn::analyse(chol::block_graph(rp, ci, r0, r1));
+          const chol::Graph G = chol::block_graph(rp, ci, r0, r1);
+          if (max_flops > 0.0) { // early decline from the first separator alone: a factor of four beyond the limit is not worth the full ordering
+            quick[(size_t)b] = (lu ? 2.0 : 1.0) * sn::estimate_flops(G);
+            if (quick[(size_t)b] * (double)nblocks > 4.0 * max_flops) continue;
+          }
+          BS[(size_t)b] = sn::analyse(G);
         }
       });
     for (auto &t : th) t.join();
   }
   for (int64_t b = 0; b < nblocks; ++b)
     if (bad[(size_t)b]) return fail(ctx, DDM_EINVAL, "sparse direct solver: block %lld has entries outside its diagonal block", (long long)b);
+  if (max_flops > 0.0) {
+    double q = 0.0;
+    for (double v : quick) q = std::max(q, v);
+    if (q * (double)nblocks > 4.0 * max_flops)
+      return fail(ctx, DDM_ENOTIMPL, "sparse direct solver: the factorisation needs about %.1g flops (estimate from the first separator; limit %.3g)", q * (double)nblocks, max_flops);
+  }
   double flops = 0.0;
   int64_t entries = 0;
   for (auto &S : BS) {

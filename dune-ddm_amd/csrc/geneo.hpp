@@ -98,7 +98,8 @@ struct GeneoWork {
     return DDM_OK;
   }
   // Out_k[:, 0:q) = (Base_k -) U_k[:, 0:pk) Y[sub]  for k < narr
-  int rotate(int narr, const double *const *U, double *const *Out, const double *const *Base, int64_t ldu, int pk, const double *Y, int q, int64_t ldo, int64_t ldb)
+  int rotate(int narr, const double *const *U, double *const *Out, const double *const *Base, int64_t ldu, int pk, const double *Y, int q, int64_t ldo, int64_t ldb,
+             int gap_from = 1 << 30, int gap = 0)
   {
     if (q > 16 * ROT_TQ) return fail(ctx, DDM_ENOTIMPL, "GenEO: more than %d columns in a rotation", 16 * ROT_TQ);
     RotArgs a;
@@ -109,7 +110,7 @@ struct GeneoWork {
     }
     const int p4 = (pk + 3) & ~3, q16 = ((q + 15) >> 4) << 4;
     const size_t lds = sizeof(double) * ((size_t)p4 * q16 + 4 * 16 * (size_t)(p4 + 1));
-    hipLaunchKernelGGL((k_rotate_mfma<0>), dim3(nchunk, narr), dim3(256), lds, ctx->stream, chunks, a, ldu, pk, Y, q, ldo, ldb);
+    hipLaunchKernelGGL((k_rotate_mfma<0>), dim3(nchunk, narr), dim3(256), lds, ctx->stream, chunks, a, ldu, pk, Y, q, ldo, ldb, gap_from, gap);
     HIPCHECK(ctx, hipGetLastError());
     return DDM_OK;
   }
@@ -121,24 +122,30 @@ static void build_pencil_host(const ddm_csr *A, const ddm_csr *B, const double *
 {
   const int64_t n = A->nrows;
   rpT.assign((size_t)n + 1, 0);
-  // pass 1: sizes of the merged rows
-  for (int64_t i = 0; i < n; ++i) {
-    int64_t a = A->h_rp[i], b = B->h_rp[i], cnt = 0;
-    const int64_t a1 = A->h_rp[i + 1], b1 = B->h_rp[i + 1];
-    while (a < a1 || b < b1) {
-      const int32_t ca = a < a1 ? A->h_ci[a] : INT32_MAX, cb = b < b1 ? B->h_ci[b] : INT32_MAX;
-      a += ca <= cb;
-      b += cb <= ca;
-      ++cnt;
-    }
-    rpT[i + 1] = rpT[i] + cnt;
-  }
-  ciT.resize((size_t)rpT[n]);
-  vaT.resize((size_t)rpT[n]);
-  vaC.resize((size_t)rpT[n]);
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
   const int nth = (int)std::min<int64_t>(hw, std::max<int64_t>(1, n / 65536));
   std::vector<std::thread> th;
+  // pass 1: sizes of the merged rows (threads), then the prefix sum
+  for (int t = 0; t < nth; ++t)
+    th.emplace_back([&, t]() {
+      for (int64_t i = n * t / nth; i < n * (t + 1) / nth; ++i) {
+        int64_t a = A->h_rp[i], b = B->h_rp[i], cnt = 0;
+        const int64_t a1 = A->h_rp[i + 1], b1 = B->h_rp[i + 1];
+        while (a < a1 || b < b1) {
+          const int32_t ca = a < a1 ? A->h_ci[a] : INT32_MAX, cb = b < b1 ? B->h_ci[b] : INT32_MAX;
+          a += ca <= cb;
+          b += cb <= ca;
+          ++cnt;
+        }
+        rpT[i + 1] = cnt;
+      }
+    });
+  for (auto &t : th) t.join();
+  th.clear();
+  for (int64_t i = 0; i < n; ++i) rpT[i + 1] += rpT[i];
+  ciT.resize((size_t)rpT[n]);
+  vaT.resize((size_t)rpT[n]);
+  vaC.resize((size_t)rpT[n]);
   for (int t = 0; t < nth; ++t)
     th.emplace_back([&, t]() {
       for (int64_t i = n * t / nth; i < n * (t + 1) / nth; ++i) {
@@ -577,13 +584,8 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
       const int nxt = cur ^ 1;
       const double *U3[3] = {S[cur], AS[cur], CS[cur]};
       double *O3[3] = {S[nxt], AS[nxt], CS[nxt]};
-      // first m output columns -> X slot
-      DDMCHECK(W.rotate(3, U3, O3, nullptr, ld, p, Yd, q2, ld, ld));
-      // the rotation wrote columns [0, 2m): move the second half into the P slot and clear the W slot
-      // (done by writing directly: the kernel writes q2 contiguous columns, so P_new lands in the W slot; shift it)
-      for (int k = 0; k < 3; ++k) {
-        hipLaunchKernelGGL(k_geneo_copy_cols, dim3(gnm), dim3(256), 0, ctx->stream, n, m, (const double *)(O3[k] + m), ld, O3[k] + 2 * m, ld);
-      }
+      // first m output columns -> X slot, the other m -> P slot (the W slot in between is overwritten by the next preconditioner solve)
+      DDMCHECK(W.rotate(3, U3, O3, nullptr, ld, p, Yd, q2, ld, ld, /*gap_from=*/m, /*gap=*/m));
       cur = nxt;
     }
     if (it > 0 && it % 8 == 0) { // refresh A~X, C X from X: the recursions drift

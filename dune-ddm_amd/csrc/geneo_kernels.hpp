@@ -98,8 +98,10 @@ struct RotArgs {
 };
 constexpr int ROT_TQ = 3; // q <= 48
 template <int DUMMY>
+// Output columns j >= gap_from are written `gap` columns further right (the fused Rayleigh-Ritz rotation writes X_new to the X slot
+// and P_new straight into the P slot, two slots further: no copy kernel behind it).
 __global__ __launch_bounds__(256) void k_rotate_mfma(const GChunk *__restrict__ chunks, RotArgs args, int64_t ldu, int p, const double *__restrict__ Yall,
-                                                    int q, int64_t ldo, int64_t ldb)
+                                                    int q, int64_t ldo, int64_t ldb, int gap_from, int gap)
 {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const GChunk c = chunks[blockIdx.x];
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256) void k_rotate_mfma(const GChunk *__restrict__ 
       for (int v = 0; v < 4; ++v) {
         const int64_t row = r0 + lr + 4 * v;
         const int j = (t << 4) + lc;
-        if (row < c.r1 && j < q) Out[row * ldo + j] = Base ? Base[row * ldb + j] - acc[t][v] : acc[t][v];
+        if (row < c.r1 && j < q) Out[row * ldo + (j < gap_from ? j : j + gap)] = Base ? Base[row * ldb + j] - acc[t][v] : acc[t][v];
       }
     }
     __builtin_amdgcn_wave_barrier(); // all lanes are done with Us before the next slab overwrites it

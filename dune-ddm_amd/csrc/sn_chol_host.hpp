@@ -33,6 +33,17 @@ struct BlockSym { // one diagonal block (subdomain), local permuted numbering
   int64_t entries = 0; // doubles in the panels
 };
 
+// Rough multiply-add count of the factorisation from the first separator alone: nested dissection costs c * s^3 with s the top
+// separator (s = n^(2/3) in 3-D: 14 n^2 = 14 s^3 measured on 27-point grids; s = n^(1/2) in 2-D: ~10-30 s^3).  Used only to DECLINE
+// hopeless sizes early (the caller compares 10 s^3 against a multiple of its limit); 0 if the block is too small to split.
+inline double estimate_flops(const chol::Graph &G, int leaf = 48)
+{
+  if (G.n <= leaf) return 0.0;
+  int64_t sep = -1;
+  (void)chol::nested_dissection(G, leaf, nullptr, &sep);
+  return sep > 0 ? 10.0 * (double)sep * (double)sep * (double)sep : 0.0;
+}
+
 // G: symmetric pattern of the block without the diagonal (chol::block_graph)
 inline BlockSym analyse(const chol::Graph &G, int leaf = 48)
 {

@@ -71,7 +71,9 @@ inline Graph block_graph(const int64_t *rp, const int32_t *ci, int64_t r0, int64
 // Nested-dissection elimination order: perm[new] = old (local indices).
 // group_ends (optional): perm.size() after every emitted group (a leaf region or a separator) -- the candidate supernodes of the
 // supernodal device factorisation (sn_chol_host.hpp): the vertices of one group are eliminated consecutively.
-inline std::vector<int32_t> nested_dissection(const Graph &G, int leaf = 48, std::vector<int32_t> *group_ends = nullptr)
+// probe_first_separator (optional): return right after the FIRST split with the size of its separator in it (perm stays empty) -- a
+// cheap look at how expensive the factorisation is going to be (sn::estimate_flops) before the whole ordering is computed.
+inline std::vector<int32_t> nested_dissection(const Graph &G, int leaf = 48, std::vector<int32_t> *group_ends = nullptr, int64_t *probe_first_separator = nullptr)
 {
   const int32_t n = G.n;
   std::vector<int32_t> perm;
@@ -186,6 +188,10 @@ inline std::vector<int32_t> nested_dissection(const Graph &G, int leaf = 48, std
       }
     }
     for (int32_t v : reach) level[v] = -1;
+    if (probe_first_separator) {
+      *probe_first_separator = (int64_t)S.verts.size();
+      return std::vector<int32_t>();
+    }
     stack.push_back(std::move(S)); // popped last => ordered last
     stack.push_back(std::move(B));
     stack.push_back(std::move(A));
