@@ -110,7 +110,10 @@ struct GeneoWork {
     }
     const int p4 = (pk + 3) & ~3, q16 = ((q + 15) >> 4) << 4;
     const size_t lds = sizeof(double) * ((size_t)p4 * q16 + 4 * 16 * (size_t)(p4 + 1));
-    hipLaunchKernelGGL((k_rotate_mfma<0>), dim3(nchunk, narr), dim3(256), lds, ctx->stream, chunks, a, ldu, pk, Y, q, ldo, ldb, gap_from, gap);
+    if (16 * p4 <= 20 * 64)
+      hipLaunchKernelGGL((k_rotate_mfma<20>), dim3(nchunk, narr), dim3(256), lds, ctx->stream, chunks, a, ldu, pk, Y, q, ldo, ldb, gap_from, gap);
+    else
+      hipLaunchKernelGGL((k_rotate_mfma<0>), dim3(nchunk, narr), dim3(256), lds, ctx->stream, chunks, a, ldu, pk, Y, q, ldo, ldb, gap_from, gap);
     HIPCHECK(ctx, hipGetLastError());
     return DDM_OK;
   }

@@ -39,25 +39,31 @@ __global__ __launch_bounds__(256) void k_gram_mfma(const GChunk *__restrict__ ch
   for (int a = 0; a < TAW; ++a)
 #pragma unroll
     for (int b = 0; b < TB; ++b) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
-  for (int64_t r = c.r0; r < c.r1; r += 4) {
-    const int64_t row = r + lr;
-    const bool rok = row < c.r1;
-    double av[TAW], bv[TB];
+  constexpr int GU = (TAW + TB <= 7) ? 4 : 2; // 4-row slabs whose operand loads are issued together (the kernel is HBM-latency bound otherwise)
+  for (int64_t r = c.r0; r < c.r1; r += 4 * GU) {
+    double av[GU][TAW], bv[GU][TB];
 #pragma unroll
-    for (int a = 0; a < TAW; ++a) {
-      const int col = ((wave + 4 * a) << 4) + lc;
-      av[a] = (rok && wave + 4 * a < ta_n && col < pu) ? U[row * ldu + col] : 0.0;
+    for (int g = 0; g < GU; ++g) {
+      const int64_t row = r + 4 * g + lr;
+      const bool rok = row < c.r1;
+#pragma unroll
+      for (int a = 0; a < TAW; ++a) {
+        const int col = ((wave + 4 * a) << 4) + lc;
+        av[g][a] = (rok && wave + 4 * a < ta_n && col < pu) ? U[row * ldu + col] : 0.0;
+      }
+#pragma unroll
+      for (int b = 0; b < TB; ++b) {
+        const int col = (b << 4) + lc;
+        bv[g][b] = (rok && b < tb_n && col < pv) ? V[row * ldv + col] : 0.0;
+      }
     }
 #pragma unroll
-    for (int b = 0; b < TB; ++b) {
-      const int col = (b << 4) + lc;
-      bv[b] = (rok && b < tb_n && col < pv) ? V[row * ldv + col] : 0.0;
-    }
+    for (int g = 0; g < GU; ++g)
 #pragma unroll
-    for (int a = 0; a < TAW; ++a)
+      for (int a = 0; a < TAW; ++a)
 #pragma unroll
-      for (int b = 0; b < TB; ++b)
-        if (wave + 4 * a < ta_n && b < tb_n) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < TB; ++b)
+          if (wave + 4 * a < ta_n && b < tb_n) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g][a], bv[g][b], acc[a][b], 0, 0, 0);
   }
   double *out = partial + (int64_t)blockIdx.x * pu * pv;
 #pragma unroll
@@ -97,9 +103,9 @@ struct RotArgs {
   const double *Base[3]; // nullptr: plain product; else Out = Base - U Y
 };
 constexpr int ROT_TQ = 3; // q <= 48
-template <int DUMMY>
 // Output columns j >= gap_from are written `gap` columns further right (the fused Rayleigh-Ritz rotation writes X_new to the X slot
 // and P_new straight into the P slot, two slots further: no copy kernel behind it).
+template <int ROT_PRE> // registers per lane for the prefetched slab: 20 (p <= 80), or 0 = row-by-row staging without prefetch (any p <= 144)
 __global__ __launch_bounds__(256) void k_rotate_mfma(const GChunk *__restrict__ chunks, RotArgs args, int64_t ldu, int p, const double *__restrict__ Yall,
                                                     int q, int64_t ldo, int64_t ldb, int gap_from, int gap)
 {
@@ -122,14 +128,40 @@ __global__ __launch_bounds__(256) void k_rotate_mfma(const GChunk *__restrict__ 
   }
   __syncthreads();
   const int tq_n = q16 >> 4;
+  // The 16 x p4 slab of U is read as ONE flat run of 16 p4 elements (contiguous in memory when ldu == p: full 512-byte loads), and the
+  // NEXT slab is fetched into registers while the matrix cores work on the current one (round 3: 1.5 TB/s before).
+  constexpr int NPRE = ROT_PRE > 0 ? ROT_PRE : 1;
+  const int nel = 16 * p4;
+  double pre[NPRE];
+  auto load_slab = [&](int64_t r0s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+      const int idx = lane + (u << 6);
+      const int i = idx / p4, k = idx - i * p4;
+      const int64_t row = r0s + i;
+      pre[u] = (idx < nel && row < c.r1 && k < p) ? U[row * ldu + k] : 0.0;
+    }
+  };
+  if (ROT_PRE > 0 && c.r0 + 16 * wave < c.r1) load_slab(c.r0 + 16 * wave);
   for (int64_t r0 = c.r0 + 16 * wave; r0 < c.r1; r0 += 64) {
-    // stage 16 rows x p of U: row by row, lanes along the row (coalesced)
-    for (int i = 0; i < 16; ++i) {
-      const int64_t row = r0 + i;
-      for (int k = lane; k < p4; k += 64) Us[i * ustride + k] = (row < c.r1 && k < p) ? U[row * ldu + k] : 0.0;
+    if (ROT_PRE > 0) {
+#pragma unroll
+      for (int u = 0; u < NPRE; ++u) {
+        const int idx = lane + (u << 6);
+        if (idx < nel) {
+          const int i = idx / p4;
+          Us[i * ustride + (idx - i * p4)] = pre[u];
+        }
+      }
+    } else { // stage 16 rows x p of U: row by row, lanes along the row (coalesced)
+      for (int i = 0; i < 16; ++i) {
+        const int64_t row = r0 + i;
+        for (int k = lane; k < p4; k += 64) Us[i * ustride + k] = (row < c.r1 && k < p) ? U[row * ldu + k] : 0.0;
+      }
     }
     __builtin_amdgcn_s_waitcnt(0); // the wave reads back what its own lanes wrote (same wave: no barrier needed, only completion)
     __builtin_amdgcn_wave_barrier();
+    if (ROT_PRE > 0 && r0 + 64 < c.r1) load_slab(r0 + 64);
     v4d acc[ROT_TQ];
 #pragma unroll
     for (int t = 0; t < ROT_TQ; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
