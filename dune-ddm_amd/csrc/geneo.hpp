@@ -467,16 +467,17 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
     HIPCHECK(ctx, hipMemcpy(maskd, mk.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
     HIPCHECK(ctx, hipMemcpy(poud, pou_host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
   }
-  double *gA, *gC, *gmm[4], *svec[2], *Yd, *mud;
+  double *gA, *gC, *gmm[5], *svec[2], *Yd, *mud;
   DDMCHECK(W.alloc(&gA, (size_t)nsub * p * p));
   DDMCHECK(W.alloc(&gC, (size_t)nsub * p * p));
-  for (int k = 0; k < 4; ++k) DDMCHECK(W.alloc(&gmm[k], (size_t)nsub * m * m));
+  for (int k = 0; k < 5; ++k) DDMCHECK(W.alloc(&gmm[k], (size_t)nsub * m * m));
   for (int k = 0; k < 2; ++k) DDMCHECK(W.alloc(&svec[k], (size_t)nsub * m));
   const int q2 = 2 * m; // fused rotation: [X_new | P_new]
   DDMCHECK(W.alloc(&Yd, (size_t)nsub * p * q2));
   DDMCHECK(W.alloc(&mud, (size_t)nsub * m));
   std::vector<double> hA((size_t)nsub * p * p), hC((size_t)nsub * p * p), hY((size_t)nsub * p * q2), hmu((size_t)nsub * m);
-  std::vector<double> h_rr((size_t)nsub * m * m), h_rw((size_t)nsub * m * m), h_aa((size_t)nsub * m * m);
+  std::vector<double> h_rr((size_t)nsub * m * m), h_rw((size_t)nsub * m * m), h_aa((size_t)nsub * m * m), h_ww((size_t)nsub * m * m), h_pp((size_t)nsub * m * m);
+  std::vector<double> dscale((size_t)nsub * p, 1.0); // column scaling of S = [X | W | P] folded into the projected problem
   const unsigned gnm = (unsigned)((n * (int64_t)m + 255) / 256);
   const int64_t ld = p;
   // ---- initial block: random on the free DoFs, Rayleigh-Ritz on span X ----
@@ -513,19 +514,15 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
         const double *Bx[1] = {Wb};
         DDMCHECK(W.rotate(1, Ux, Ox, Bx, ld, m, gmm[3], m, ld, ld));
       }
-      DDMCHECK(apply_AC(m, Wb, ld, AWb, CWb, ld)); // both products of the unscaled W in one pass over it; scaled together below
+      DDMCHECK(apply_AC(m, Wb, ld, AWb, CWb, ld)); // both products of W in one pass over it
+      // A~-normalisation of the columns of W and P (zero columns stay zero): the blocks themselves are NOT rescaled (six passes over
+      // n x m blocks per iteration in round 2) -- the diagonal scaling D is applied where it is cheap: to the p x p Gram matrices
+      // (D G D) and to the rows of the Ritz coefficients (S D) Y = S (D Y), on the host
       DDMCHECK(W.gram(Wb, ld, m, AWb, ld, m, gmm[3]));
-      hipLaunchKernelGGL(k_geneo_invsqrt_diag, dim3((unsigned)((nsub * m + 255) / 256)), dim3(256), 0, ctx->stream, (int)nsub, m, gmm[3], svec[1]);
-      hipLaunchKernelGGL(k_geneo_colscale, dim3(gnm), dim3(256), 0, ctx->stream, n, m, W.sub_of_row, svec[1], Wb, ld);
-      hipLaunchKernelGGL(k_geneo_colscale, dim3(gnm), dim3(256), 0, ctx->stream, n, m, W.sub_of_row, svec[1], AWb, ld);
-      hipLaunchKernelGGL(k_geneo_colscale, dim3(gnm), dim3(256), 0, ctx->stream, n, m, W.sub_of_row, svec[1], CWb, ld);
-      // A~-normalise the columns of P (zero columns stay zero)
-      double *Pb = S[cur] + 2 * m, *APb = AS[cur] + 2 * m, *CPb = CS[cur] + 2 * m;
-      DDMCHECK(W.gram(Pb, ld, m, APb, ld, m, gmm[3]));
-      hipLaunchKernelGGL(k_geneo_invsqrt_diag, dim3((unsigned)((nsub * m + 255) / 256)), dim3(256), 0, ctx->stream, (int)nsub, m, gmm[3], svec[1]);
-      hipLaunchKernelGGL(k_geneo_colscale, dim3(gnm), dim3(256), 0, ctx->stream, n, m, W.sub_of_row, svec[1], Pb, ld);
-      hipLaunchKernelGGL(k_geneo_colscale, dim3(gnm), dim3(256), 0, ctx->stream, n, m, W.sub_of_row, svec[1], APb, ld);
-      hipLaunchKernelGGL(k_geneo_colscale, dim3(gnm), dim3(256), 0, ctx->stream, n, m, W.sub_of_row, svec[1], CPb, ld);
+      HIPCHECK(ctx, hipMemcpyAsync(h_ww.data(), gmm[3], sizeof(double) * h_ww.size(), hipMemcpyDeviceToHost, ctx->stream));
+      double *Pb = S[cur] + 2 * m, *APb = AS[cur] + 2 * m;
+      DDMCHECK(W.gram(Pb, ld, m, APb, ld, m, gmm[4]));
+      HIPCHECK(ctx, hipMemcpyAsync(h_pp.data(), gmm[4], sizeof(double) * h_pp.size(), hipMemcpyDeviceToHost, ctx->stream));
       have_residual = true;
     }
     DDMCHECK(W.gram(S[cur], ld, p, AS[cur], ld, p, gA));
@@ -561,15 +558,30 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
         th.emplace_back([&, t]() {
           std::vector<double> Y1((size_t)p * m);
           for (int64_t s = t; s < nsub; s += nth) {
-            const int r = dense::rayleigh_ritz(p, hA.data() + (size_t)s * p * p, hC.data() + (size_t)s * p * p, m, tau, hmu.data() + (size_t)s * m, Y1.data());
+            double *d = dscale.data() + (size_t)s * p;
+            for (int i = 0; i < p; ++i) d[i] = 1.0;
+            if (have_residual)
+              for (int j = 0; j < m; ++j) {
+                const double gw = h_ww[((size_t)s * m + j) * m + j], gp = h_pp[((size_t)s * m + j) * m + j];
+                d[m + j] = gw > 1e-300 ? 1.0 / std::sqrt(gw) : 0.0;
+                d[2 * m + j] = gp > 1e-300 ? 1.0 / std::sqrt(gp) : 0.0;
+              }
+            double *gAs = hA.data() + (size_t)s * p * p, *gCs = hC.data() + (size_t)s * p * p;
+            for (int i = 0; i < p; ++i)
+              for (int j = 0; j < p; ++j) {
+                gAs[(size_t)i * p + j] *= d[i] * d[j];
+                gCs[(size_t)i * p + j] *= d[i] * d[j];
+              }
+            const int r = dense::rayleigh_ritz(p, gAs, gCs, m, tau, hmu.data() + (size_t)s * m, Y1.data());
             ranks[(size_t)s] = r;
             rcs[(size_t)s] = r < m ? 1 : 0;
             if (r < m) continue;
             double *Y = hY.data() + (size_t)s * p * q2; // [Y | Y with the X rows zeroed]: X_new = S Y, P_new = [W P] Y_{W,P}
             for (int i = 0; i < p; ++i)
               for (int j = 0; j < m; ++j) {
-                Y[(size_t)i * q2 + j] = Y1[(size_t)i * m + j];
-                Y[(size_t)i * q2 + m + j] = i < m ? 0.0 : Y1[(size_t)i * m + j];
+                const double y = d[i] * Y1[(size_t)i * m + j];
+                Y[(size_t)i * q2 + j] = y;
+                Y[(size_t)i * q2 + m + j] = i < m ? 0.0 : y;
               }
           }
         });
