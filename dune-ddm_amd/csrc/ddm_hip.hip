@@ -1951,14 +1951,14 @@ static int ilu0_solve_multi_ld(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double
     F->mgraph = nullptr;
   }
   if (F->sn) {
-    if (nrhs > 48) return fail(ctx, DDM_EINVAL, "ddm_ilu0_solve_multi: at most 48 right-hand sides per call with the device direct solver");
-    if (!sn::reserve(*F->sn, nrhs)) return fail(ctx, DDM_EHIP, "sparse direct solver: allocation failed");
-    if (F->pm_nrhs < nrhs) {
+    const int w = std::min(nrhs, 48); // the panel kernels take up to 48 columns: wider blocks are solved in column panels
+    if (!sn::reserve(*F->sn, w)) return fail(ctx, DDM_EHIP, "sparse direct solver: allocation failed");
+    if (F->pm_nrhs < w) {
       (void)hipFree(F->pD);
       F->pD = nullptr;
       F->pm_nrhs = 0;
-      HIPCHECK(ctx, hipMalloc((void **)&F->pD, sizeof(double) * (size_t)F->n * (size_t)nrhs));
-      F->pm_nrhs = nrhs;
+      HIPCHECK(ctx, hipMalloc((void **)&F->pD, sizeof(double) * (size_t)F->n * (size_t)w));
+      F->pm_nrhs = w;
     }
   }
   if (F->perm && F->pm_nrhs < nrhs) {
@@ -1973,9 +1973,12 @@ static int ilu0_solve_multi_ld(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double
   hipGraph_t g = nullptr;
   HIPCHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
   if (F->sn) {
-    hipLaunchKernelGGL(k_perm_gather, dim3(grid_for(F->n * nrhs)), dim3(WG), 0, ctx->stream, F->n, nrhs, F->sn->d_perm, D, ldd, F->pD);
-    sn::solve(*F->sn, ctx->stream, nrhs, F->pD, nrhs);
-    hipLaunchKernelGGL(k_perm_scatter, dim3(grid_for(F->n * nrhs)), dim3(WG), 0, ctx->stream, F->n, nrhs, F->sn->d_perm, (const double *)F->pD, X, ldx);
+    for (int c0 = 0; c0 < nrhs; c0 += 48) {
+      const int w = std::min(48, nrhs - c0);
+      hipLaunchKernelGGL(k_perm_gather, dim3(grid_for(F->n * w)), dim3(WG), 0, ctx->stream, F->n, w, F->sn->d_perm, D + c0, ldd, F->pD);
+      sn::solve(*F->sn, ctx->stream, w, F->pD, w);
+      hipLaunchKernelGGL(k_perm_scatter, dim3(grid_for(F->n * w)), dim3(WG), 0, ctx->stream, F->n, w, F->sn->d_perm, (const double *)F->pD, X + c0, ldx);
+    }
   } else if (F->perm) { // sparse direct factor: solve in the fill-reducing order on packed work blocks
     hipLaunchKernelGGL(k_perm_gather, dim3(grid_for(F->n * nrhs)), dim3(WG), 0, ctx->stream, F->n, nrhs, F->perm, D, ldd, F->pD);
     enqueue_multi_levels_csr(ctx, F->Lc, false, nrhs, F->pD, nrhs, F->pX, nrhs);

@@ -64,6 +64,9 @@ __global__ void k_geneo_random(int64_t n, int m, int64_t ld, unsigned long long 
   X[i * ld + j] = ((double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5) * mask[i];
 }
 
+// widest block the eigensolver iterates (nev + extra): the dense kernels work in column panels beyond 48 (round 3; the threshold mode
+// of the reference doubles nev up to nev_max, spectra.hh:157-163), the limit is the memory of the six n x 3m blocks
+constexpr int GENEO_MAX_BLOCK = 132;
 struct GeneoWork {
   ddm_ctx *ctx = nullptr;
   int64_t n = 0;
@@ -84,36 +87,50 @@ struct GeneoWork {
     allocs.push_back(*ptr);
     return DDM_OK;
   }
-  // G[sub] = U^T V per subdomain (pu x pv row-major, nsub matrices)
+  // G[sub] = U^T V per subdomain (pu x pv row-major, nsub matrices).  Blocks wider than the register tiles of the kernel (128 x 80)
+  // are computed in column panels that land in their sub-block of the per-chunk partial matrices.
   int gram(const double *U, int64_t ldu, int pu, const double *V, int64_t ldv, int pv, double *G)
   {
-    if (pu > 144 || pv > 144) return fail(ctx, DDM_ENOTIMPL, "GenEO: block wider than 144 columns");
-    if (pu <= 128 && pv <= 80)
-      hipLaunchKernelGGL((k_gram_mfma<2, 5>), dim3(nchunk), dim3(256), 0, ctx->stream, chunks, U, ldu, pu, V, ldv, pv, partial);
-    else
-      hipLaunchKernelGGL((k_gram_mfma<3, 9>), dim3(nchunk), dim3(256), 0, ctx->stream, chunks, U, ldu, pu, V, ldv, pv, partial);
     const int64_t pp = (int64_t)pu * pv;
+    if (pu <= 128 && pv <= 80)
+      hipLaunchKernelGGL((k_gram_mfma<2, 5>), dim3(nchunk), dim3(256), 0, ctx->stream, chunks, U, ldu, pu, V, ldv, pv, partial, pp, pv, 0, 0);
+    else if (pu <= 144 && pv <= 144)
+      hipLaunchKernelGGL((k_gram_mfma<3, 9>), dim3(nchunk), dim3(256), 0, ctx->stream, chunks, U, ldu, pu, V, ldv, pv, partial, pp, pv, 0, 0);
+    else
+      for (int i0 = 0; i0 < pu; i0 += 128)
+        for (int j0 = 0; j0 < pv; j0 += 80)
+          hipLaunchKernelGGL((k_gram_mfma<2, 5>), dim3(nchunk), dim3(256), 0, ctx->stream, chunks, U + i0, ldu, std::min(128, pu - i0), V + j0, ldv, std::min(80, pv - j0),
+                             partial, pp, pv, i0, j0);
     hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((nsub * pp + 255) / 256)), dim3(256), 0, ctx->stream, nsub, sub_chunk_ptr, pp, partial, G);
     HIPCHECK(ctx, hipGetLastError());
     return DDM_OK;
   }
-  // Out_k[:, 0:q) = (Base_k -) U_k[:, 0:pk) Y[sub]  for k < narr
+  // Out_k[:, 0:q) = (Base_k -) U_k[:, 0:pk) Y[sub]  for k < narr.  Y: nsub matrices pk x q, row-major.  More than 48 output columns
+  // or more than 80 inner columns run as panels: 48 output columns per launch, the inner dimension in pieces of 72 whose products are
+  // added onto the output.
   int rotate(int narr, const double *const *U, double *const *Out, const double *const *Base, int64_t ldu, int pk, const double *Y, int q, int64_t ldo, int64_t ldb,
              int gap_from = 1 << 30, int gap = 0)
   {
-    if (q > 16 * ROT_TQ) return fail(ctx, DDM_ENOTIMPL, "GenEO: more than %d columns in a rotation", 16 * ROT_TQ);
-    RotArgs a;
-    for (int k = 0; k < 3; ++k) {
-      a.U[k] = k < narr ? U[k] : nullptr;
-      a.Out[k] = k < narr ? Out[k] : nullptr;
-      a.Base[k] = (k < narr && Base) ? Base[k] : nullptr;
+    const int KP = pk <= 80 ? pk : 72;
+    for (int j0 = 0; j0 < q; j0 += 16 * ROT_TQ) {
+      const int qq = std::min(16 * ROT_TQ, q - j0);
+      for (int k0 = 0; k0 < pk; k0 += KP) {
+        const int kk = std::min(KP, pk - k0);
+        RotArgs a;
+        for (int k = 0; k < 3; ++k) {
+          a.U[k] = k < narr ? U[k] + k0 : nullptr;
+          a.Out[k] = k < narr ? Out[k] : nullptr;
+          a.Base[k] = (k < narr && Base) ? Base[k] : nullptr;
+        }
+        const int mode = k0 == 0 ? (Base ? 1 : 0) : (Base ? 2 : 3);
+        const int p4 = (kk + 3) & ~3, q16 = ((qq + 15) >> 4) << 4;
+        const size_t lds = sizeof(double) * ((size_t)p4 * q16 + 4 * 16 * (size_t)(p4 + 1));
+        if (16 * p4 <= 20 * 64)
+          hipLaunchKernelGGL((k_rotate_mfma<20>), dim3(nchunk, narr), dim3(256), lds, ctx->stream, chunks, a, ldu, kk, Y, qq, ldo, ldb, gap_from, gap, q, pk, k0, j0, mode);
+        else
+          hipLaunchKernelGGL((k_rotate_mfma<0>), dim3(nchunk, narr), dim3(256), lds, ctx->stream, chunks, a, ldu, kk, Y, qq, ldo, ldb, gap_from, gap, q, pk, k0, j0, mode);
+      }
     }
-    const int p4 = (pk + 3) & ~3, q16 = ((q + 15) >> 4) << 4;
-    const size_t lds = sizeof(double) * ((size_t)p4 * q16 + 4 * 16 * (size_t)(p4 + 1));
-    if (16 * p4 <= 20 * 64)
-      hipLaunchKernelGGL((k_rotate_mfma<20>), dim3(nchunk, narr), dim3(256), lds, ctx->stream, chunks, a, ldu, pk, Y, q, ldo, ldb, gap_from, gap);
-    else
-      hipLaunchKernelGGL((k_rotate_mfma<0>), dim3(nchunk, narr), dim3(256), lds, ctx->stream, chunks, a, ldu, pk, Y, q, ldo, ldb, gap_from, gap);
     HIPCHECK(ctx, hipGetLastError());
     return DDM_OK;
   }
@@ -382,7 +399,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
   const int64_t n = A_neu->nrows;
   const int m = nev + std::max(P.extra, 1);
   const int p = 3 * m;
-  if (p > 144) return fail(ctx, DDM_ENOTIMPL, "GenEO: nev + extra = %d exceeds 48 vectors per subdomain", m);
+  if (m > GENEO_MAX_BLOCK) return fail(ctx, DDM_ENOTIMPL, "GenEO: nev + extra = %d exceeds %d vectors per subdomain", m, GENEO_MAX_BLOCK);
   for (int64_t s = 0; s < nsub; ++s)
     if (sub_ptr[s + 1] - sub_ptr[s] < 3 * (int64_t)m) return fail(ctx, DDM_EINVAL, "GenEO: subdomain %lld has fewer than 3 (nev + extra) = %d rows", (long long)s, 3 * m);
   const auto t_begin = std::chrono::steady_clock::now();

@@ -27,8 +27,11 @@ struct GChunk { // a run of rows inside ONE subdomain
 // TAW x TB accumulator tiles in registers (template bounds; the actual tile counts are wave-uniform run-time values).
 // HBM-bound: 8 (pu + pv) bytes per row for 2 pu pv flops.
 template <int TAW, int TB>
+// The pu x pv result is written as a sub-block at (out_i0, out_j0) of a per-chunk matrix with leading dimension out_ld (blocks wider
+// than the register tiles are computed in column panels: GeneoWork::gram).
 __global__ __launch_bounds__(256) void k_gram_mfma(const GChunk *__restrict__ chunks, const double *__restrict__ U, int64_t ldu, int pu,
-                                                  const double *__restrict__ V, int64_t ldv, int pv, double *__restrict__ partial)
+                                                  const double *__restrict__ V, int64_t ldv, int pv, double *__restrict__ partial, int64_t out_stride, int out_ld,
+                                                  int out_i0, int out_j0)
 {
   const GChunk c = chunks[blockIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256) void k_gram_mfma(const GChunk *__restrict__ ch
         for (int b = 0; b < TB; ++b)
           if (wave + 4 * a < ta_n && b < tb_n) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g][a], bv[g][b], acc[a][b], 0, 0, 0);
   }
-  double *out = partial + (int64_t)blockIdx.x * pu * pv;
+  double *out = partial + (int64_t)blockIdx.x * out_stride + (int64_t)out_i0 * out_ld + out_j0;
 #pragma unroll
   for (int a = 0; a < TAW; ++a)
 #pragma unroll
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256) void k_gram_mfma(const GChunk *__restrict__ ch
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = ((wave + 4 * a) << 4) + lr + 4 * q, j = (b << 4) + lc;
-        if (i < pu && j < pv) out[(int64_t)i * pv + j] = acc[a][b][q];
+        if (i < pu && j < pv) out[(int64_t)i * out_ld + j] = acc[a][b][q];
       }
     }
 }
@@ -107,8 +110,12 @@ constexpr int ROT_TQ = 3; // q <= 48
 // and P_new straight into the P slot, two slots further: no copy kernel behind it).
 template <int ROT_PRE> // registers per lane for the prefetched slab: 20 (p <= 80), or 0 = row-by-row staging without prefetch (any p <= 144)
 __global__ __launch_bounds__(256) void k_rotate_mfma(const GChunk *__restrict__ chunks, RotArgs args, int64_t ldu, int p, const double *__restrict__ Yall,
-                                                    int q, int64_t ldo, int64_t ldb, int gap_from, int gap)
+                                                    int q, int64_t ldo, int64_t ldb, int gap_from, int gap, int y_ld, int y_rows, int y_k0, int y_j0, int mode)
 {
+  // Panels (GeneoWork::rotate): this launch multiplies the p columns of U it is given by rows [y_k0, y_k0 + p), columns [y_j0, y_j0 + q)
+  // of the per-subdomain coefficient matrix (y_rows x y_ld, row-major) and produces the output columns y_j0 .. y_j0 + q - 1.
+  // mode 0: Out = U Y;  1: Out = Base - U Y (Base indexed by the plain column);  2 / 3: Out = Out -/+ U Y (further K panels: the
+  // addend is the output itself, at its mapped column)
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const GChunk c = chunks[blockIdx.x];
   const double *__restrict__ U = args.U[blockIdx.y];
@@ -121,10 +128,10 @@ __global__ __launch_bounds__(256) void k_rotate_mfma(const GChunk *__restrict__ 
   double *Ys = lds;                          // p4 x q16
   const int ustride = p4 + 1;                // odd stride: the 16 rows of an A operand fall into different banks
   double *Us = lds + (int64_t)p4 * q16 + (int64_t)wave * 16 * ustride;
-  const double *Y = Yall + (int64_t)c.sub * p * q;
+  const double *Y = Yall + (int64_t)c.sub * y_rows * y_ld;
   for (int t = threadIdx.x; t < p4 * q16; t += 256) {
     const int k = t / q16, j = t - k * q16;
-    Ys[t] = (k < p && j < q) ? Y[(int64_t)k * q + j] : 0.0;
+    Ys[t] = (k < p && j < q) ? Y[(int64_t)(y_k0 + k) * y_ld + y_j0 + j] : 0.0;
   }
   __syncthreads();
   const int tq_n = q16 >> 4;
@@ -178,7 +185,12 @@ __global__ __launch_bounds__(256) void k_rotate_mfma(const GChunk *__restrict__ 
       for (int v = 0; v < 4; ++v) {
         const int64_t row = r0 + lr + 4 * v;
         const int j = (t << 4) + lc;
-        if (row < c.r1 && j < q) Out[row * ldo + (j < gap_from ? j : j + gap)] = Base ? Base[row * ldb + j] - acc[t][v] : acc[t][v];
+        if (row < c.r1 && j < q) {
+          const int ja = y_j0 + j;
+          double *o = Out + row * ldo + (ja < gap_from ? ja : ja + gap);
+          const double a = acc[t][v];
+          *o = mode == 0 ? a : (mode == 1 ? Base[row * ldb + ja] - a : (mode == 2 ? *o - a : *o + a));
+        }
       }
     }
     __builtin_amdgcn_wave_barrier(); // all lanes are done with Us before the next slab overwrites it

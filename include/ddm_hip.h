@@ -279,7 +279,7 @@ typedef struct {
   double shift;            /* eigensolver.shift (1e-3) */
   double threshold;        /* eigensolver.threshold (-0.5 = off) */
   int32_t maxit;           /* block iterations (400) */
-  int32_t extra;           /* guard vectors iterated beyond nev (4) */
+  int32_t extra;           /* guard vectors iterated beyond nev (4); nev + extra <= 132 */
   int32_t seed;            /* start block */
   int32_t preconditioner;  /* 0 = sparse Cholesky of A + shift C if its flop count <= max_direct_flops, else ILU(0); 1 = ILU(0); 2 = Cholesky */
   double max_direct_flops; /* 2e13 multiply-adds: a few seconds of the device factorisation (the host engine is only taken below 1e11) */
@@ -326,7 +326,8 @@ int ddm_harmonic_extend(ddm_ctx *ctx, ddm_harmonic *H, int nrhs, double *X, int6
  * blocks split into subdomain row ranges sub_ptr[nsub+1]:
  *   gram  : G_host[s] = U[rows of s]^T V[rows of s]   (nsub matrices pu x pv, row-major; split-K over 2048-row chunks, summed in
  *           chunk order)                              -- Spectra's V^T B f / Gram products
- *   rotate: Out[rows of s, 0:q) = (Base[rows of s, 0:q) -) U[rows of s, 0:p) Y_host[s]   (Y: nsub matrices p x q, q <= 48)
+ *   rotate: Out[rows of s, 0:q) = (Base[rows of s, 0:q) -) U[rows of s, 0:p) Y_host[s]   (Y: nsub matrices p x q; more than 48 output
+ *           or 80 inner columns run as panels)
  *                                                     -- Spectra's compress_V (Arnoldi.h:310-329)
  * Synchronous. */
 int ddm_blockvec_gram(ddm_ctx *ctx, int64_t nsub, const int64_t *sub_ptr, const double *U, int64_t ldu, int pu, const double *V, int64_t ldv,

@@ -9,7 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("pu,pv", [(72, 72), (24, 24), (7, 19), (78, 26), (132, 132), (1, 3)])
+@pytest.mark.parametrize("pu,pv", [(72, 72), (24, 24), (7, 19), (78, 26), (132, 132), (1, 3), (204, 204), (300, 68), (130, 150)])   # the last three: column panels
 def test_gram_matches_fp64_reference(ddm, pu, pv):
     import torch
     ctx = ddm.torch_context(0)
@@ -29,7 +29,7 @@ def test_gram_matches_fp64_reference(ddm, pu, pv):
     ctx.close()
 
 
-@pytest.mark.parametrize("p,q", [(72, 48), (72, 24), (24, 24), (5, 3), (132, 44), (9, 17)])
+@pytest.mark.parametrize("p,q", [(72, 48), (72, 24), (24, 24), (5, 3), (132, 44), (9, 17), (204, 136), (90, 50), (300, 100)])   # the last three: output and inner panels
 def test_rotate_matches_fp64_reference(ddm, p, q):
     import torch
     ctx = ddm.torch_context(0)
