@@ -38,6 +38,7 @@ namespace sn {
 typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int TILE = 64;      // rows per panel / update tile
 constexpr int BWD_SMALL = 8;  // supernodes with at most this many row tiles do their backward reduction inside k_sn_bwd_diag
+constexpr int UPD_KC = 32;   // columns of the panels staged through LDS per trip of the update kernel
 constexpr int BWD_ROWS = 256; // rows per partial product of the others (one workgroup, four 64-row sub-tiles)
 
 struct Meta { // device pointers
@@ -108,53 +109,93 @@ __global__ __launch_bounds__(256) void k_sn_diag(Meta M, const int32_t *__restri
 {
   extern __shared__ __attribute__((aligned(16))) double a[];
   __shared__ double rowbuf[SN_MAX_COLS];
+  __shared__ double tmp[32 * 33];
   const int32_t s = lev_sn[blockIdx.x];
   const int32_t nc = M.first[s + 1] - M.first[s];
   const int64_t ld = nc + M.nrow[s];
   double *P = M.panels + M.pptr[s];
   const int ldl = nc | 1;
-  const int tid = threadIdx.x;
-  for (int idx = tid; idx < nc * nc; idx += 256) {
-    const int i = idx % nc, j = idx / nc;
-    a[i + j * ldl] = i >= j ? P[i + j * ld] : 0.0;
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  for (int j = ty; j < nc; j += 4)
+    for (int i = tx; i < nc; i += 64) a[i + j * ldl] = i >= j ? P[i + j * ld] : 0.0;
+  // Cholesky, right-looking, ONE barrier per column: the trailing update of step k works with the UNSCALED column k
+  // (a_ij -= a_ik a_jk / d_k), the column is scaled one step later, when nobody reads it any more
+  double rp_prev = 0.0, sq_prev = 0.0;
+  for (int k = 0; k < nc; ++k) {
+    __syncthreads();
+    if (k > 0) {
+      for (int i = k + tid; i < nc; i += 256) a[i + (k - 1) * ldl] *= rp_prev;
+      if (tid == 0) a[(k - 1) + (k - 1) * ldl] = sq_prev;
+    }
+    double d = a[k + k * ldl];
+    if (!(d > 0.0) || !(d < 1.7e308)) {
+      if (tid == 0) atomicCAS(err, 0u, (unsigned)s + 1u);
+      d = 1.0;
+    }
+    sq_prev = sqrt(d);
+    rp_prev = 1.0 / sq_prev;
+    const double invd = 1.0 / d;
+    for (int j = k + 1 + ty; j < nc; j += 4) {
+      const double ajk = a[j + k * ldl] * invd;
+      for (int i = j + tx; i < nc; i += 64) a[i + j * ldl] -= a[i + k * ldl] * ajk;
+    }
   }
   __syncthreads();
-  for (int k = 0; k < nc; ++k) {
-    if (tid == 0) {
-      double d = a[k + k * ldl];
-      if (!(d > 0.0) || !(d < 1.7e308)) {
-        atomicCAS(err, 0u, (unsigned)s + 1u);
-        d = 1.0;
+  if (tid == 0) a[(nc - 1) + (nc - 1) * ldl] = sq_prev;
+  __syncthreads();
+  // W = L^-1 in place, in 32 x 32 blocks.  (1) the diagonal blocks, all at once: row by row, row i of a block from row i of L (staged)
+  // and the rows of W above it
+  const int nb = (nc + 31) >> 5;
+  {
+    const int b = tid >> 5, j = tid & 31, b0 = b << 5; // thread = (block, column)
+    const int bn = b < nb ? min(32, nc - b0) : 0;
+    for (int i = 0; i < 32; ++i) {
+      if (i < bn && j <= i) rowbuf[b0 + j] = a[(b0 + i) + (b0 + j) * ldl];
+      __syncthreads();
+      if (i < bn && j <= i) {
+        double acc = (i == j) ? 1.0 : 0.0;
+        for (int k = j; k < i; ++k) acc -= rowbuf[b0 + k] * a[(b0 + k) + (b0 + j) * ldl];
+        a[(b0 + i) + (b0 + j) * ldl] = acc / rowbuf[b0 + i];
       }
-      a[k + k * ldl] = sqrt(d);
+      __syncthreads();
     }
-    __syncthreads();
-    const double piv = a[k + k * ldl];
-    for (int i = k + 1 + tid; i < nc; i += 256) a[i + k * ldl] /= piv;
-    __syncthreads();
-    const int m = nc - k - 1;
-    for (int idx = tid; idx < m * m; idx += 256) {
-      const int i = k + 1 + idx % m, j = k + 1 + idx / m;
-      if (i >= j) a[i + j * ldl] -= a[i + k * ldl] * a[j + k * ldl];
+  }
+  // (2) the blocks below the diagonal, column block by column block (the blocks of L to the right are still intact), row blocks
+  // downwards:  W_ib = -W_ii (sum_{k = b}^{i-1} L_ik W_kb)
+  {
+    const int r = tid & 31, cg = tid >> 5; // thread: row r of the 32 x 32 block, columns 4 cg .. 4 cg + 3
+    for (int b = 0; b + 1 < nb; ++b) {
+      const int b0 = b << 5;
+      for (int ib = b + 1; ib < nb; ++ib) {
+        const int i0 = ib << 5, in = min(32, nc - i0);
+        double t4[4] = {0.0, 0.0, 0.0, 0.0};
+        if (r < in)
+          for (int k = b0; k < i0; ++k) {
+            const double l = a[(i0 + r) + k * ldl];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) t4[c] += l * ((k - b0) >= 0 && k >= b0 + 4 * cg + c ? a[k + (b0 + 4 * cg + c) * ldl] : 0.0); // W_kb is lower triangular inside block b
+          }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tmp[r * 33 + 4 * cg + c] = t4[c];
+        __syncthreads();
+        double w4[4] = {0.0, 0.0, 0.0, 0.0};
+        if (r < in)
+          for (int k = 0; k <= r; ++k) {
+            const double wik = a[(i0 + r) + (i0 + k) * ldl]; // W_ii (lower)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) w4[c] -= wik * tmp[k * 33 + 4 * cg + c];
+          }
+        __syncthreads();
+        if (r < in) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) a[(i0 + r) + (b0 + 4 * cg + c) * ldl] = w4[c];
+        }
+        __syncthreads();
+      }
     }
-    __syncthreads();
   }
-  // W = L^-1 in place, row by row: row i of W from row i of L (staged) and the rows of W above
-  for (int i = 0; i < nc; ++i) {
-    if (tid <= i) rowbuf[tid] = a[i + tid * ldl];
-    __syncthreads();
-    if (tid <= i) {
-      const int j = tid;
-      double acc = (i == j) ? 1.0 : 0.0;
-      for (int k = j; k < i; ++k) acc -= rowbuf[k] * a[k + j * ldl];
-      a[i + j * ldl] = acc / rowbuf[i];
-    }
-    __syncthreads();
-  }
-  for (int idx = tid; idx < nc * nc; idx += 256) {
-    const int i = idx % nc, j = idx / nc;
-    if (i >= j) P[i + j * ld] = a[i + j * ldl];
-  }
+  for (int j = ty; j < nc; j += 4)
+    for (int i = j + tx; i < nc; i += 64) P[i + j * ld] = a[i + j * ldl];
 }
 
 // ---- panel: R_s <- R_s W_s^T  (64 rows per workgroup, 16 per wavefront, all ncol <= 128 columns in registers) ---------------
@@ -248,38 +289,68 @@ __global__ __launch_bounds__(256) void k_sn_update(Meta M, const int32_t *__rest
     const int32_t g = rowid[r];
     rpos[idx] = (g >= 0 && g >= slot_first[sl]) ? row_pos(M, slot_t[sl], g) : -1;
   }
+  // The product: K in chunks of UPD_KC columns staged through LDS (each panel element is read from global memory once per
+  // workgroup; round 3's first version had every wavefront fetch its operands itself: 24 TFLOP/s), the NEXT chunk in registers while
+  // the matrix cores work on the current one; wavefront w owns the 32 x 32 quadrant (w >> 1, w & 1): 2 x 2 MFMA tiles, two A and
+  // two B operand reads per four MFMAs.
+  __shared__ double As[UPD_KC * TILE], Bs[UPD_KC * TILE]; // [k][row]
   const int lane = tid & 63, wave = tid >> 6, lc = lane & 15, lr = lane >> 4;
-  v4d acc[4];
+  const int wi = wave >> 1, wj = wave & 1;
+  const bool diag = ti == tj;
+  v4d acc[2][2];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
-  const int arow = ti * TILE + wave * 16 + lc;
-  const bool aok = arow < nr;
-  for (int k0 = 0; k0 < nc; k0 += 4) {
-    const int k = k0 + lr;
-    const bool kok = k < nc;
-    const double av = (aok && kok) ? P[nc + arow + (int64_t)k * ld] : 0.0;
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int brow = tj * TILE + (t << 4) + lc;
-      const double bv = (brow < nr && kok) ? P[nc + brow + (int64_t)k * ld] : 0.0;
-      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+    for (int b = 0; b < 2; ++b) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
+  constexpr int NLD = UPD_KC * TILE / 256; // elements per thread and operand per chunk
+  const int lrow = tid & 63, lk = tid >> 6; // loader mapping: 64 consecutive rows of one column per wavefront
+  double pa[NLD], pb[NLD];
+  auto load_chunk = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int k = k0 + lk + 4 * u;
+      const int ra = ti * TILE + lrow, rb = tj * TILE + lrow;
+      pa[u] = (k < nc && ra < nr) ? P[nc + ra + (int64_t)k * ld] : 0.0;
+      pb[u] = (!diag && k < nc && rb < nr) ? P[nc + rb + (int64_t)k * ld] : 0.0;
+    }
+  };
+  load_chunk(0);
+  for (int k0 = 0; k0 < nc; k0 += UPD_KC) {
+    __syncthreads(); // the previous chunk has been consumed (and, first trip, rpos is complete)
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      As[(lk + 4 * u) * TILE + lrow] = pa[u];
+      if (!diag) Bs[(lk + 4 * u) * TILE + lrow] = pb[u];
+    }
+    __syncthreads();
+    if (k0 + UPD_KC < nc) load_chunk(k0 + UPD_KC);
+    const double *Bp = diag ? As : Bs;
+#pragma unroll
+    for (int kk = 0; kk < UPD_KC; kk += 4) {
+      const double a0 = As[(kk + lr) * TILE + 32 * wi + lc], a1 = As[(kk + lr) * TILE + 32 * wi + 16 + lc];
+      const double b0 = Bp[(kk + lr) * TILE + 32 * wj + lc], b1 = Bp[(kk + lr) * TILE + 32 * wj + 16 + lc];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
     }
   }
-  __syncthreads();
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int c = (t << 4) + lc;
+  for (int b = 0; b < 2; ++b) {
+    const int c = 32 * wj + 16 * b + lc;
     const int sl = slot_of_col[c];
     if (sl < 0) continue;
     const int32_t gc = colid[c];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = wave * 16 + lr + 4 * q;
-      const int32_t gr = rowid[r];
-      if (gr < gc) continue; // (also gr == -1) lower triangle only
-      const int32_t rp = rpos[sl * TILE + r];
-      unsafeAtomicAdd(M.panels + slot_base[sl] + rp + (int64_t)(gc - slot_first[sl]) * slot_ld[sl], -acc[t][q]);
-    }
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 32 * wi + 16 * a + lr + 4 * q;
+        const int32_t gr = rowid[r];
+        if (gr < gc) continue; // (also gr == -1) lower triangle only
+        const int32_t rp = rpos[sl * TILE + r];
+        unsafeAtomicAdd(M.panels + slot_base[sl] + rp + (int64_t)(gc - slot_first[sl]) * slot_ld[sl], -acc[a][b][q]);
+      }
   }
 }
 
