@@ -136,18 +136,23 @@ def main():
 
     # ---- roofline of the dominant kernel: the local solve (two triangular sweeps over the factor) -------------------------------
     zf, n = tl.schwarz.factor_nnz(), tl.rl.n
-    alg_bytes = 12.0 * zf + 40.0 * n
+    engine = tl.schwarz.engine()
+    # CSR factors: value + column index of every entry once; supernodal panels (device engine): every panel entry once per sweep, no indices
+    alg_bytes = (16.0 * zf if engine == "supernodal" else 12.0 * zf) + 40.0 * n
     avg_ms = local_ms / max(local_cnt, 1)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     traffic, traffic_source = None, None
     try:   # HBM bytes of ONE local solve (all its level launches) from the committed rocprofv3 --pmc passes of this command: NOT measured in this run
         src = f"profiles/r03_pmc_traffic_{args.problem}.json"
         pmc = json.load(open(os.path.join(ROOT, src)))
-        if pmc.get("cells") == (C if args.problem == "dg" else None) and pmc.get("refine") == (None if args.problem == "dg" else args.refine) and cfg["local"] == pmc.get("local_solver"):
+        if pmc.get("cells") == (C if args.problem == "dg" else None) and pmc.get("refine") == (None if args.problem == "dg" else args.refine) and cfg["local"] == pmc.get("local_solver") and pmc.get("engine", "levels") == engine:
             traffic, traffic_source = pmc["local_solve_hbm_bytes_corrected"] / world, src
     except Exception:
         traffic = None
-    roofline = {"bound": "hbm", "kernel": "local solve: " + ("sparse direct factor, level-scheduled CSR kernels with supernodal blocks (k_trsv_csr_level)" if cfg["local"] != "ilu0" else "ILU(0) triangular solve"),
+    roofline = {"bound": "hbm", "kernel": "local solve: " + ("ILU(0) triangular solve" if cfg["local"] == "ilu0" else
+                                                 "device supernodal factor, one launch per tree level and sweep (sn::k_sn_fwd1, k_sn_bwd1_partial, k_sn_bwd1_diag)" if engine == "supernodal" else
+                                                 "sparse direct factor, level-scheduled CSR kernels with supernodal blocks (k_trsv_csr_level)"),
+                "engine": engine,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms, "launches_timed": int(local_cnt)}
 

@@ -511,10 +511,11 @@ class SchwarzPreconditioner:
     def num_levels(self):
         return (int(self.ctx.lib.ddm_schwarz_num_levels(self.h, 0)), int(self.ctx.lib.ddm_schwarz_num_levels(self.h, 1)))
 
-    ENGINES = {8: "pipe", 4: "xcd2", 0: "levels"}
+    ENGINES = {8: "pipe", 4: "xcd2", 0: "levels", 16: "supernodal"}
 
     def engine(self):
-        """triangular-solve engine of the local solver: 'pipe', 'xcd2' (also when pipe declined the matrix) or 'levels'"""
+        """triangular-solve engine of the local solver: 'pipe', 'xcd2' (also when pipe declined the matrix), 'levels', or 'supernodal'
+        (sparse direct factor of the device engine: dense panels, csrc/sn_chol.hpp)"""
         return self.ENGINES[int(self.ctx.lib.ddm_schwarz_engine(self.h))]
 
     def factor_nnz(self):

@@ -1327,7 +1327,7 @@ static int sn_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, con
     flops += (lu ? 2.0 : 1.0) * S.flops;
     entries += (lu ? 2 : 1) * S.entries; // (L U: the U^T blocks; slightly over-counted by the diagonal blocks)
   }
-  double min_flops = setup_use ? 1e10 : 5e11; // (see direct_create_impl)
+  double min_flops = setup_use ? 1e10 : 2e10; // (see direct_create_impl)
   if (const char *e = std::getenv("DDM_DIRECT_DEVICE_MIN_FLOPS")) min_flops = std::atof(e);
   if (!force && flops < min_flops) return 1;
   if (max_flops > 0.0 && flops > max_flops)
@@ -1367,7 +1367,9 @@ static int sn_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, con
   int rc = DDM_OK;
   if (hipHostMalloc((void **)&F->err, 128, hipHostMallocMapped) != hipSuccess) rc = fail(ctx, DDM_EHIP, "sparse direct solver: allocation failed");
   else std::memset(F->err, 0, 128);
-  if (!rc && hipMalloc((void **)&F->pd, sizeof(double) * (size_t)std::max<int64_t>(n, 1)) != hipSuccess) rc = fail(ctx, DDM_EHIP, "sparse direct solver: allocation failed");
+  if (!rc && (hipMalloc((void **)&F->pd, sizeof(double) * (size_t)std::max<int64_t>(n, 1)) != hipSuccess ||
+              hipMalloc((void **)&F->px, sizeof(double) * (size_t)std::max<int64_t>(n, 1)) != hipSuccess))
+    rc = fail(ctx, DDM_EHIP, "sparse direct solver: allocation failed");
   if (rc) {
     ddm_ilu0_destroy(F);
     return rc;
@@ -1427,9 +1429,10 @@ extern "C" int ddm_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks
   return direct_create_impl(ctx, A, nblocks, block_ptr, general, max_flops, false, out);
 }
 // setup_use: the factor serves a handful of block solves during a setup phase (GenEO preconditioner, harmonic extensions) -- the
-// device engine pays from ~1e10 multiply-adds; as the local solver of a Krylov loop (thousands of single solves) the host engine's
-// CSR level solves are the faster ones (measured on configs[4]: 1.3 against 4.3 ms per solve), so the device engine is only taken
-// when the host factorisation would run for about a minute (5e11).
+// device engine pays from ~1e10 multiply-adds.  As the local solver of a Krylov loop the host engine's CSR level solves are the
+// faster single-vector solves (measured on configs[4]: 1.31 against 1.75 ms), but its factorisation costs ~1 s per 1e10
+// multiply-adds against ~0.05 s on the device: from 2e10 the device engine wins the time to solution of any solve shorter than
+// several thousand iterations, so that is the default there (DDM_DIRECT_DEVICE_MIN_FLOPS / DDM_DIRECT_ENGINE override).
 static int direct_create_impl(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, int general, double max_flops, bool setup_use, ddm_ilu0 **out)
 {
   if (!ctx || !A || !out || nblocks < 1 || !block_ptr) return fail(ctx, DDM_EINVAL, "ddm_direct_create: bad arguments");
@@ -1535,6 +1538,7 @@ extern "C" int64_t ddm_ilu0_num_levels(const ddm_ilu0 *F, int upper) { return up
 extern "C" int ddm_ilu0_engine(const ddm_ilu0 *F)
 {
   if (!F) return -1;
+  if (F->sn) return 16; // device supernodal factor (sn_chol.hpp)
   return (F->mode == 8 && F->pipe_state < 0) ? 4 : F->mode;
 }
 extern "C" int ddm_ilu0_get_factors_host(ddm_ctx *ctx, const ddm_ilu0 *F, double *lu_host)
@@ -1857,7 +1861,7 @@ static int ilu0_solve_epilogue(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, doubl
   bool epilogue_done = false;
   if (F->sn) { // supernodal device factor: gather into the permuted work vector, solve in place on the panels, scatter
     hipLaunchKernelGGL(k_perm_gather, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, 1, F->sn->d_perm, d_user, (int64_t)1, F->pd);
-    sn::solve(*F->sn, ctx->stream, 1, F->pd, 1);
+    sn::solve(*F->sn, ctx->stream, 1, F->pd, 1, F->px);
     hipLaunchKernelGGL(k_perm_scatter, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, 1, F->sn->d_perm, (const double *)F->pd, x_user, (int64_t)1);
   } else {
   if (F->perm) { // sparse direct factor: solve in the fill-reducing order

@@ -902,6 +902,173 @@ __global__ __launch_bounds__(256) void k_sn_bwd_diag(Meta M, const int32_t *__re
   }
 }
 
+// ---- ONE right-hand side (the Schwarz apply inside a Krylov loop) -----------------------------------------------------------------
+// GEMV-shaped variants of the four solve kernels: 512 threads, every thread's slice of loads in flight at once, the k range (or the
+// rows) split over thread groups and summed in a fixed order; forward: ONE launch per level -- every workgroup of a supernode
+// recomputes y_s = W_s b_s itself (at most 128^2 / 2 multiply-adds), item 0 stores it to Y (a separate vector: the others still read
+// b_s), items 1.. apply their 64 rows of the update.
+// NCMAX = 128 (4 x 128 threads) or 64 (levels whose widest supernode has at most 64 columns -- the many small supernodes at the bottom
+// of the tree: half the threads per workgroup, twice the workgroups per CU)
+__device__ __forceinline__ double s1_wave_sum(double v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+template <bool LU, int NCMAX>
+__global__ __launch_bounds__(4 * NCMAX) void k_sn_fwd1(Meta M, const int32_t *__restrict__ lev_sn, const int32_t *__restrict__ pre, int cnt, double *__restrict__ B,
+                                                  double *__restrict__ Y)
+{
+  constexpr int YS = NCMAX / 4; // k slice of the four thread groups that compute y
+  __shared__ double bs[NCMAX], ys[NCMAX], part[4 * NCMAX];
+  int lo = 0, hi = cnt; // item -> (supernode, local item): largest i with pre[i] + i <= item (1 + T_i items per supernode)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (pre[mid] + mid <= (int)blockIdx.x) lo = mid;
+    else hi = mid;
+  }
+  const int32_t s = lev_sn[lo];
+  const int item = (int)blockIdx.x - pre[lo] - lo;
+  const int32_t f = M.first[s], nc = M.first[s + 1] - f, nr = M.nrow[s];
+  const int64_t ld = nc + nr;
+  const double *P = M.panels + M.pptr[s];
+  const int tid = threadIdx.x;
+  if (tid < nc) bs[tid] = B[f + (LU ? M.piv[f + tid] : tid)];
+  __syncthreads();
+  {
+    const int i = tid & (NCMAX - 1), sl = tid / NCMAX; // row i of W, k slice [YS sl, YS sl + YS)
+    double acc = 0.0;
+    if (i < nc) {
+      const int k1 = min(YS * sl + YS, LU ? i : i + 1);
+      for (int kb = YS * sl; kb < k1; kb += 8) {
+        double w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = kb + u < k1 ? P[i + (int64_t)(kb + u) * ld] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += w[u] * bs[min(kb + u, nc - 1)];
+      }
+    }
+    part[sl * NCMAX + i] = acc;
+  }
+  __syncthreads();
+  if (tid < nc) ys[tid] = (LU ? bs[tid] : 0.0) + ((part[tid] + part[NCMAX + tid]) + (part[2 * NCMAX + tid] + part[3 * NCMAX + tid]));
+  __syncthreads();
+  if (item == 0) {
+    if (tid < nc) Y[f + tid] = ys[tid];
+    return;
+  }
+  const int r0 = (item - 1) * TILE, rl = tid & 63, sl = tid >> 6; // row rl of the tile, k slice [16 sl, 16 sl + 16)
+  double acc = 0.0;
+  if (r0 + rl < nr) {
+    double w[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) w[u] = 16 * sl + u < nc ? P[nc + r0 + rl + (int64_t)(16 * sl + u) * ld] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += w[u] * ys[min(16 * sl + u, nc - 1)];
+  }
+  part[sl * TILE + rl] = acc;
+  __syncthreads();
+  if (tid < TILE && r0 + tid < nr) {
+    double sum = 0.0;
+#pragma unroll
+    for (int q = 0; q < NCMAX / 16; ++q) sum += part[q * TILE + tid];
+    unsafeAtomicAdd(B + (M.rows + M.rptr[s])[r0 + tid], -sum);
+  }
+}
+// out[k] += sum over 64 rows of a tile of block[r][k] x[rows[r]]: thread = (row rl, k slice of 16); blk: first row of the tile in the
+// nrow x ncol block (leading dimension bld); results of the 64 rows are summed over the wavefront
+__device__ __forceinline__ void s1_tile_tdot(const double *__restrict__ blk, int64_t bld, int32_t nc, int rn, int rl, int sl, double xr, double (&acc)[16])
+{
+  double w[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) w[u] = (rl < rn && 16 * sl + u < nc) ? blk[rl + (int64_t)(16 * sl + u) * bld] : 0.0;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) acc[u] += w[u] * xr;
+}
+template <bool LU, int NCMAX>
+__global__ __launch_bounds__(4 * NCMAX) void k_sn_bwd1_partial(Meta M, const int32_t *__restrict__ big_sn, const int32_t *__restrict__ pre, int cnt, const double *__restrict__ X,
+                                                          double *__restrict__ partial)
+{
+  const int it = find_item(pre, cnt, (int32_t)blockIdx.x);
+  const int32_t s = big_sn[it];
+  const int item = (int)blockIdx.x - pre[it];
+  const int32_t nc = M.first[s + 1] - M.first[s], nr = M.nrow[s];
+  const double *blk = LU ? M.upanels + M.uptr[s] : M.panels + M.pptr[s] + nc;
+  const int64_t bld = LU ? (int64_t)nr : (int64_t)nc + nr;
+  const int32_t *R = M.rows + M.rptr[s];
+  const int tid = threadIdx.x, rl = tid & 63, sl = tid >> 6;
+  double acc[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) acc[u] = 0.0;
+  for (int sub = 0; sub < BWD_ROWS / TILE; ++sub) {
+    const int r0 = item * BWD_ROWS + sub * TILE, rn = min(TILE, nr - r0);
+    if (rn <= 0) break;
+    s1_tile_tdot(blk + r0, bld, nc, rn, rl, sl, rl < rn ? X[R[r0 + rl]] : 0.0, acc);
+  }
+  double *out = partial + (int64_t)blockIdx.x * SN_MAX_COLS;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const double v = s1_wave_sum(acc[u]);
+    if (rl == 0 && 16 * sl + u < nc) out[16 * sl + u] = v;
+  }
+}
+template <bool LU, int NCMAX>
+__global__ __launch_bounds__(4 * NCMAX) void k_sn_bwd1_diag(Meta M, const int32_t *__restrict__ lev_sn, const int32_t *__restrict__ big_index, const int32_t *__restrict__ pre_big,
+                                                       const double *__restrict__ partial, const double *__restrict__ Y, double *__restrict__ B)
+{
+  constexpr int XS = NCMAX / 4;
+  __shared__ double t[NCMAX], part[4 * NCMAX];
+  const int32_t s = lev_sn[blockIdx.x];
+  const int32_t f = M.first[s], nc = M.first[s + 1] - f, nr = M.nrow[s];
+  const int64_t ld = nc + nr;
+  const double *P = M.panels + M.pptr[s];
+  const int32_t *R = M.rows + M.rptr[s];
+  const int tid = threadIdx.x, rl = tid & 63, sl = tid >> 6;
+  const int bi = big_index[blockIdx.x];
+  if (bi >= 0) {
+    if (tid < nc) {
+      double acc = Y[f + tid];
+      const double *pp = partial + (int64_t)pre_big[bi] * SN_MAX_COLS + tid;
+      const int npart = (nr + BWD_ROWS - 1) / BWD_ROWS;
+      for (int q = 0; q < npart; ++q) acc -= pp[(int64_t)q * SN_MAX_COLS];
+      t[tid] = acc;
+    }
+  } else {
+    const double *blk = LU ? M.upanels + M.uptr[s] : P + nc;
+    const int64_t bld = LU ? (int64_t)nr : ld;
+    double acc[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc[u] = 0.0;
+    for (int r0 = 0; r0 < nr; r0 += TILE) {
+      const int rn = min(TILE, nr - r0);
+      s1_tile_tdot(blk + r0, bld, nc, rn, rl, sl, rl < rn ? B[R[r0 + rl]] : 0.0, acc);
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const double v = s1_wave_sum(acc[u]);
+      if (rl == 0 && 16 * sl + u < nc) t[16 * sl + u] = Y[f + 16 * sl + u] - v;
+    }
+  }
+  __syncthreads();
+  { // x = W^T t (Cholesky: x_i = sum_{k >= i} W[k][i] t_k) resp. U^-1 t (x_i = sum_{k >= i} U^-1[i][k] t_k): thread = (i, k slice of 32)
+    const int i = tid & (NCMAX - 1), q = tid / NCMAX;
+    double acc = 0.0;
+    if (i < nc) {
+      const int k0 = max(XS * q, i), k1 = min(XS * q + XS, nc);
+      for (int kb = k0; kb < k1; kb += 8) {
+        double w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = kb + u < k1 ? (LU ? P[i + (int64_t)(kb + u) * ld] : P[kb + u + (int64_t)i * ld]) : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += w[u] * t[min(kb + u, nc - 1)];
+      }
+    }
+    part[q * NCMAX + i] = acc;
+  }
+  __syncthreads();
+  if (tid < nc) B[f + tid] = (part[tid] + part[NCMAX + tid]) + (part[2 * NCMAX + tid] + part[3 * NCMAX + tid]);
+}
+
 // ---- host driver -------------------------------------------------------------------------------------------------------------------
 struct Factor {
   int64_t n = 0, entries = 0;
@@ -1127,8 +1294,33 @@ static inline bool reserve(Factor &F, int m)
 }
 
 template <bool LU>
-static inline void solve_t(const Factor &F, hipStream_t st, int m, double *B, int64_t ldb)
+static inline void solve_t(const Factor &F, hipStream_t st, int m, double *B, int64_t ldb, double *Yvec)
 {
+  if (m == 1 && ldb == 1 && Yvec) { // the single-vector kernels: three launches per level
+    for (int32_t l = 0; l < F.nlev; ++l) {
+      const int32_t cnt = F.lev_ptr[(size_t)l + 1] - F.lev_ptr[(size_t)l];
+      if (cnt == 0) continue;
+      const int32_t *lsn = F.d_lev_sn + F.lev_ptr[(size_t)l], *preT = F.d_preT + F.lev_ptr[(size_t)l] + l;
+      const unsigned grid = (unsigned)(F.h_tilesT[(size_t)l] + cnt);
+      if (F.lev_maxnc[(size_t)l] <= 64) hipLaunchKernelGGL((k_sn_fwd1<LU, 64>), dim3(grid), dim3(256), 0, st, F.M, lsn, preT, cnt, B, Yvec);
+      else hipLaunchKernelGGL((k_sn_fwd1<LU, 128>), dim3(grid), dim3(512), 0, st, F.M, lsn, preT, cnt, B, Yvec);
+    }
+    for (int32_t l = F.nlev - 1; l >= 0; --l) {
+      const int32_t cnt = F.lev_ptr[(size_t)l + 1] - F.lev_ptr[(size_t)l];
+      if (cnt == 0) continue;
+      const int32_t *lsn = F.d_lev_sn + F.lev_ptr[(size_t)l];
+      const int32_t nbig = F.lev_big_ptr[(size_t)l + 1] - F.lev_big_ptr[(size_t)l];
+      const int32_t *preB = F.d_preB + F.lev_big_ptr[(size_t)l] + l, *bsn = F.d_big_sn + F.lev_big_ptr[(size_t)l], *bidx = F.d_big_index + F.lev_ptr[(size_t)l];
+      const bool small = F.lev_maxnc[(size_t)l] <= 64;
+      if (nbig > 0) {
+        if (small) hipLaunchKernelGGL((k_sn_bwd1_partial<LU, 64>), dim3((unsigned)F.h_tilesB[(size_t)l]), dim3(256), 0, st, F.M, bsn, preB, nbig, (const double *)B, F.d_partial);
+        else hipLaunchKernelGGL((k_sn_bwd1_partial<LU, 128>), dim3((unsigned)F.h_tilesB[(size_t)l]), dim3(512), 0, st, F.M, bsn, preB, nbig, (const double *)B, F.d_partial);
+      }
+      if (small) hipLaunchKernelGGL((k_sn_bwd1_diag<LU, 64>), dim3((unsigned)cnt), dim3(256), 0, st, F.M, lsn, bidx, preB, (const double *)F.d_partial, (const double *)Yvec, B);
+      else hipLaunchKernelGGL((k_sn_bwd1_diag<LU, 128>), dim3((unsigned)cnt), dim3(512), 0, st, F.M, lsn, bidx, preB, (const double *)F.d_partial, (const double *)Yvec, B);
+    }
+    return;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)k_sn_fwd_diag<LU>, hipFuncAttributeMaxDynamicSharedMemorySize, SN_MAX_COLS * 48 * 8);
@@ -1161,10 +1353,11 @@ static inline void solve_t(const Factor &F, hipStream_t st, int m, double *B, in
 }
 
 // in-place solve (L L^T resp. P^T L U) X = B on the permuted row-major work block (n x m, leading dimension ldb); enqueues only
-static inline void solve(const Factor &F, hipStream_t st, int m, double *B, int64_t ldb)
+// Yvec: a second n-vector for the single-vector kernels (m == 1), or nullptr = the block kernels
+static inline void solve(const Factor &F, hipStream_t st, int m, double *B, int64_t ldb, double *Yvec = nullptr)
 {
-  if (F.lu) solve_t<true>(F, st, m, B, ldb);
-  else solve_t<false>(F, st, m, B, ldb);
+  if (F.lu) solve_t<true>(F, st, m, B, ldb, Yvec);
+  else solve_t<false>(F, st, m, B, ldb, Yvec);
 }
 
 } // namespace sn

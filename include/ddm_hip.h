@@ -148,9 +148,10 @@ int ddm_chol_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64
  * definite (the DG convection-diffusion operator; `type = umfpack`); DDM_ENUMERIC on a vanishing pivot.  general == 0 = ddm_chol_create. */
 int ddm_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, int general, double max_flops, ddm_ilu0 **out);
 /* Engines of ddm_chol_create / ddm_direct_create, environment DDM_DIRECT_ENGINE = device | host.  Default: the device engine when the
- * factorisation needs at least DDM_DIRECT_DEVICE_MIN_FLOPS multiply-adds -- 5e11 for ddm_direct_create / the Schwarz local solver
- * (about a minute of host factorisation; below that the host engine's CSR level solves are the faster single-vector solves), 1e10
- * for the factors the library builds for a handful of block solves (GenEO preconditioner, harmonic extensions):
+ * factorisation needs at least DDM_DIRECT_DEVICE_MIN_FLOPS multiply-adds -- 2e10 for ddm_direct_create / the Schwarz local solver
+ * (the host engine's CSR level solves are the faster single-vector solves, 1.31 against 1.75 ms on configs[4], but its factorisation
+ * takes ~1 s per 1e10 multiply-adds: above 2e10 the device engine wins the time to solution), 1e10 for the factors the library
+ * builds for a handful of block solves (GenEO preconditioner, harmonic extensions):
  *   device  SUPERNODAL Cholesky (general = 0) or L U (general = 1) with numeric factorisation AND solves on the GPU (csrc/sn_chol.hpp):
  *           nested-dissection supernodes of at most 128 columns, dense panels, FP64-MFMA updates, level by level of the supernodal
  *           elimination tree; the host only orders and analyses.  L U: threshold partial pivoting (0.1, UMFPACK's default) INSIDE the

@@ -16,6 +16,8 @@ nsolves = bench["local_solves_in_run"]
 
 def is_solve_kernel(name):
     n = name.replace("void ", "")
+    if bench["roofline"].get("engine") == "supernodal":   # device engine: the single-vector kernels of sn_chol.hpp + the two permutations around them
+        return n.startswith("sn::k_sn_fwd1") or n.startswith("sn::k_sn_bwd1_") or n.startswith("ddm::k_perm_gather") or n.startswith("ddm::k_perm_scatter")
     return (n.startswith("ddm::k_trsv_") and "multi" not in n) or n.startswith("ddm::k_pipe_permute") or n.startswith("ddm::k_w_permute")
 
 
@@ -42,7 +44,7 @@ if f:
             stats[row["Name"].split("(")[0].replace("void ", "")] = {"calls": int(row["Calls"]), "total_ms": float(row["TotalDurationNs"]) / 1e6, "average_us": float(row["AverageNs"]) / 1e3}
 doc = {"note": "rocprofv3 --pmc passes (separate runs, --kernel-trace only) of `python3 bench_convdiff.py --problem %s --steps 10 --warmup 3 --cpu-iters 0 --no-solve "
                "--profile-counts`; FETCH_SIZE / WRITE_SIZE in KiB as reported; gfx950: read bytes = 2 x FETCH_SIZE" % problem,
-       "problem": problem, "cells": bench["config"].get("cells"), "refine": bench["config"].get("refine"), "local_solver": bench["config"].get("local_solver"),
+       "problem": problem, "cells": bench["config"].get("cells"), "refine": bench["config"].get("refine"), "local_solver": bench["config"].get("local_solver"), "engine": bench["roofline"].get("engine", "levels"),
        "local_solves_in_run": nsolves, "solve_kernels": {k: dict(v, **stats.get(k, {})) for k, v in per_kernel.items()},
        "local_solve_hbm_bytes_corrected": (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0 / nsolves,
        "local_solve_kernel_ms": sum(v["total_ms"] for v in stats.values()) / nsolves if stats else None,
