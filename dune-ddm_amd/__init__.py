@@ -137,6 +137,7 @@ SYMBOLS = {
     "ddm_harmonic_destroy": (None, [_P]),
     "ddm_harmonic_extend": (_I32, [_P, _P, _I32, _P, _I64]),
     "ddm_blockvec_gram": (_I32, [_P, _I64, _P, _P, _I64, _I32, _P, _I64, _I32, _P]),
+    "ddm_blockvec_gram2_sym": (_I32, [_P, _I64, _P, _P, _I64, _P, _P, _I64, _I32, _P, _P]),
     "ddm_blockvec_rotate": (_I32, [_P, _I64, _P, _P, _I64, _I32, _P, _I32, _P, _I64, _P, _I64]),
     "ddm_dense_sym_eig_host": (_I32, [_I32, _P, _P]),
     "ddm_dense_rayleigh_ritz_host": (_I32, [_I32, _P, _P, _I32, _D, _P, _P]),
@@ -668,6 +669,17 @@ def blockvec_gram(ctx: Context, sub_ptr, U, V):
     out = np.empty((len(bp) - 1, U.shape[1], V.shape[1]), dtype=np.float64)
     ctx.check(ctx.lib.ddm_blockvec_gram(ctx.h, len(bp) - 1, _hp(bp), _ptr(U), U.stride(0), U.shape[1], _ptr(V), V.stride(0), V.shape[1], _hp(out)))
     return out
+
+
+def blockvec_gram2_sym(ctx: Context, sub_ptr, U, V1, V2):
+    """per-subdomain U^T V1, U^T V2 for symmetric products (upper tiles computed, mirrored) -> two ndarrays (nsub, p, p)"""
+    bp = _np(sub_ptr, np.int64)
+    p = U.shape[1]
+    assert V1.shape == U.shape == V2.shape and V1.stride(0) == V2.stride(0) and U.shape[0] == bp[-1]
+    g1 = np.empty((len(bp) - 1, p, p), dtype=np.float64)
+    g2 = np.empty_like(g1)
+    ctx.check(ctx.lib.ddm_blockvec_gram2_sym(ctx.h, len(bp) - 1, _hp(bp), _ptr(U), U.stride(0), _ptr(V1), _ptr(V2), V1.stride(0), p, _hp(g1), _hp(g2)))
+    return g1, g2
 
 
 def blockvec_rotate(ctx: Context, sub_ptr, U, Y, out, base=None):

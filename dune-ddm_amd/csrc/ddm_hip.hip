@@ -18,6 +18,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -75,7 +77,11 @@ static int fail(ddm_ctx *ctx, int code, const char *fmt, ...)
   va_start(ap, fmt);
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
-  if (ctx) ctx->err = buf;
+  if (ctx) { // (setup phases run independent host work on helper threads that may fail at the same time)
+    static std::mutex err_mutex;
+    std::lock_guard<std::mutex> lock(err_mutex);
+    ctx->err = buf;
+  }
   return code;
 }
 #define HIPCHECK(ctx, call)                                                                                   \
@@ -382,18 +388,60 @@ extern "C" int ddm_timing_reset(ddm_ctx *ctx)
 }
 
 // ---- CSR ---------------------------------------------------------------------------------------
+// Host arrays of matrix size (10^8..10^9 entries): a std::vector whose resize() leaves the new elements UNINITIALISED -- the value
+// initialisation of std::vector is a single-threaded pass over fresh pages (0.5 s per 3 GB), the threads that fill the array then
+// touch the pages themselves.
+template <class T>
+struct noinit_alloc : std::allocator<T> {
+  template <class U>
+  struct rebind {
+    using other = noinit_alloc<U>;
+  };
+  template <class U, class... Args>
+  void construct(U *p, Args &&...args)
+  {
+    if constexpr (sizeof...(Args) == 0) ::new ((void *)p) U;
+    else ::new ((void *)p) U(std::forward<Args>(args)...);
+  }
+};
+template <class T>
+using hvec = std::vector<T, noinit_alloc<T>>;
+// dst = src with `threads` memcpy workers (fresh pages: the copy is page-fault bound on one thread)
+template <class T>
+static void hvec_copy(hvec<T> &dst, const T *src, size_t n)
+{
+  dst.resize(n);
+  const size_t nth = std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), std::max<size_t>(1, n >> 22));
+  if (nth <= 1) {
+    if (n) std::memcpy(dst.data(), src, sizeof(T) * n);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < nth; ++t)
+    th.emplace_back([&, t]() {
+      const size_t a = n * t / nth, b = n * (t + 1) / nth;
+      std::memcpy(dst.data() + a, src + a, sizeof(T) * (b - a));
+    });
+  for (auto &t : th) t.join();
+}
+
 struct ddm_csr {
   int64_t nrows = 0, ncols = 0, nnz = 0;
-  std::vector<int64_t> h_rp; // host copies are kept for the ILU(0) factorisation / analysis
-  std::vector<int32_t> h_ci;
-  std::vector<double> h_va;
+  hvec<int64_t> h_rp; // host copies are kept for the ILU(0) factorisation / analysis
+  hvec<int32_t> h_ci;
+  hvec<double> h_va;
   int64_t *rp = nullptr;
   int32_t *ci = nullptr;
   double *va = nullptr;
   int32_t *blk_row = nullptr;
   int nblk = 0;
+  bool borrowed_pattern = false; // rp / ci / blk_row belong to another ddm_csr (values-only companion on the same pattern)
+  std::thread uploader;          // device copies still in flight (csr_adopt): csr_wait_upload joins it
+  int upload_rc = 0;
+  std::string upload_err;
 };
 
+static std::vector<int32_t> csr_row_blocks(int64_t nrows, const int64_t *rowptr);
 extern "C" int ddm_csr_create(ddm_ctx *ctx, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *col,
                               const double *val, ddm_csr **out)
 {
@@ -408,22 +456,10 @@ extern "C" int ddm_csr_create(ddm_ctx *ctx, int64_t nrows, int64_t ncols, const 
   A->nrows = nrows;
   A->ncols = ncols;
   A->nnz = nnz;
-  A->h_rp.assign(rowptr, rowptr + nrows + 1);
-  A->h_ci.assign(col, col + nnz);
-  A->h_va.assign(val, val + nnz);
-  // row-block schedule of the CSR-stream kernel: <= SPMV_NNZ non-zeros and <= WG rows per block,
-  // a row longer than SPMV_NNZ gets a block of its own
-  std::vector<int32_t> blk;
-  blk.push_back(0);
-  int64_t r = 0;
-  while (r < nrows) {
-    int64_t r1 = r;
-    const int64_t z0 = rowptr[r];
-    while (r1 < nrows && r1 - r < WG && rowptr[r1 + 1] - z0 <= SPMV_NNZ) ++r1;
-    if (r1 == r) r1 = r + 1; // long row
-    blk.push_back((int32_t)r1);
-    r = r1;
-  }
+  hvec_copy(A->h_rp, rowptr, (size_t)nrows + 1);
+  hvec_copy(A->h_ci, col, (size_t)nnz);
+  hvec_copy(A->h_va, val, (size_t)nnz);
+  const std::vector<int32_t> blk = csr_row_blocks(nrows, rowptr);
   A->nblk = (int)blk.size() - 1;
   int rc = upload(ctx, rowptr, nrows + 1, &A->rp);
   if (!rc) rc = upload(ctx, col, nnz, &A->ci);
@@ -439,11 +475,78 @@ extern "C" int ddm_csr_create(ddm_ctx *ctx, int64_t nrows, int64_t ncols, const 
 extern "C" void ddm_csr_destroy(ddm_csr *A)
 {
   if (!A) return;
-  (void)hipFree(A->rp);
-  (void)hipFree(A->ci);
+  if (A->uploader.joinable()) A->uploader.join();
+  if (!A->borrowed_pattern) {
+    (void)hipFree(A->rp);
+    (void)hipFree(A->ci);
+    (void)hipFree(A->blk_row);
+  }
   (void)hipFree(A->va);
-  (void)hipFree(A->blk_row);
   delete A;
+}
+// row-block schedule of the CSR-stream kernel: <= SPMV_NNZ non-zeros and <= WG rows per block, a row longer than SPMV_NNZ gets a
+// block of its own
+static std::vector<int32_t> csr_row_blocks(int64_t nrows, const int64_t *rowptr)
+{
+  std::vector<int32_t> blk;
+  blk.push_back(0);
+  int64_t r = 0;
+  while (r < nrows) {
+    int64_t r1 = r;
+    const int64_t z0 = rowptr[r];
+    while (r1 < nrows && r1 - r < WG && rowptr[r1 + 1] - z0 <= SPMV_NNZ) ++r1;
+    if (r1 == r) r1 = r + 1; // long row
+    blk.push_back((int32_t)r1);
+    r = r1;
+  }
+  return blk;
+}
+// Library-internal constructors for matrices the library assembled itself (GenEO pencil): the host arrays are MOVED in (no copy, no
+// validation pass), and the device copies are made by a helper thread while the caller goes on with host work on the host arrays
+// (factorisation, analysis).  Everything that touches the device arrays calls csr_wait_upload first.
+static int csr_wait_upload(ddm_ctx *ctx, const ddm_csr *A)
+{
+  ddm_csr *M = const_cast<ddm_csr *>(A);
+  if (M->uploader.joinable()) M->uploader.join();
+  if (M->upload_rc) return fail(ctx, M->upload_rc, "%s", M->upload_err.c_str());
+  return DDM_OK;
+}
+static ddm_csr *csr_adopt(ddm_ctx *ctx, int64_t n, hvec<int64_t> &&rp, hvec<int32_t> &&ci, hvec<double> &&va, hvec<double> &&companion_values, ddm_csr **companion)
+{
+  ddm_csr *A = new ddm_csr, *C = new ddm_csr;
+  A->nrows = A->ncols = C->nrows = C->ncols = n;
+  A->nnz = C->nnz = rp[(size_t)n];
+  A->h_rp = std::move(rp);
+  A->h_ci = std::move(ci);
+  A->h_va = std::move(va);
+  C->borrowed_pattern = true;
+  *companion = C;
+  const int device = ctx->device;
+  auto cv = std::make_shared<hvec<double>>(std::move(companion_values));
+  A->uploader = std::thread([A, C, cv, device]() {
+    auto up = [&](const void *src, size_t bytes, void **dst) {
+      if (A->upload_rc) return;
+      hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 8));
+      if (e == hipSuccess && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+      if (e != hipSuccess) {
+        A->upload_rc = DDM_EHIP;
+        A->upload_err = std::string("matrix upload failed: ") + hipGetErrorString(e);
+      }
+    };
+    (void)hipSetDevice(device);
+    const std::vector<int32_t> blk = csr_row_blocks(A->nrows, A->h_rp.data());
+    A->nblk = (int)blk.size() - 1;
+    up(A->h_rp.data(), sizeof(int64_t) * A->h_rp.size(), (void **)&A->rp);
+    up(A->h_ci.data(), sizeof(int32_t) * A->h_ci.size(), (void **)&A->ci);
+    up(A->h_va.data(), sizeof(double) * A->h_va.size(), (void **)&A->va);
+    up(blk.data(), sizeof(int32_t) * blk.size(), (void **)&A->blk_row);
+    up(cv->data(), sizeof(double) * cv->size(), (void **)&C->va);
+    C->rp = A->rp;
+    C->ci = A->ci;
+    C->blk_row = A->blk_row;
+    C->nblk = A->nblk;
+  });
+  return A;
 }
 extern "C" int64_t ddm_csr_rows(const ddm_csr *A) { return A->nrows; }
 extern "C" int64_t ddm_csr_nnz(const ddm_csr *A) { return A->nnz; }
@@ -618,7 +721,7 @@ struct ddm_ilu0 {
   double direct_flops = 0.0;
   sn::Factor *sn = nullptr;       // supernodal factor computed ON THE DEVICE (sn_chol.hpp); solves run on its panels, in place in pd / pD
   int64_t nvirt = 0; // virtual unknowns of the supernodal transformation: the permuted work vectors hold n + nvirt entries
-  std::vector<double> h_lu; // factor values in the pattern of A
+  hvec<double> h_lu; // factor values in the pattern of A
   TriSchedule L, U;
   TriCsr Lc, Uc;   // direct factors use these instead of L / U (global levels: multi-RHS solves, one launch per level)
   TriCsr Lb, Ub;   // the same factors ordered by (block, level): single right-hand side, one workgroup per block
@@ -639,7 +742,7 @@ static constexpr int SMALL_LEVEL_ROWS = 2048;
 static constexpr int SMALL_LEVELS_PER_LAUNCH = 256;
 
 // Builds the level schedule of the lower (upper=false) or upper factor.
-static int build_schedule(ddm_ctx *ctx, const ddm_csr *A, const std::vector<double> &lu, const std::vector<int64_t> &diag,
+static int build_schedule(ddm_ctx *ctx, const ddm_csr *A, const hvec<double> &lu, const std::vector<int64_t> &diag,
                           bool upper, TriSchedule &S)
 {
   const int64_t n = A->nrows;
@@ -746,7 +849,7 @@ struct Supernodes {
 };
 // T^-1 of the unit lower / M^-1 of the upper (pivots on the diagonal) diagonal block of every supernode; row-oriented substitution
 // (row i of the inverse is a combination of the finished rows: contiguous updates), supernodes in parallel on the host threads
-static void invert_supernodes(const std::vector<double> &lu, const std::vector<int64_t> &diag, Supernodes &SN)
+static void invert_supernodes(const hvec<double> &lu, const std::vector<int64_t> &diag, Supernodes &SN)
 {
   const size_t ns = SN.j0.size();
   SN.Linv.assign(ns, {});
@@ -831,7 +934,7 @@ static Supernodes detect_supernodes(const ddm_csr *A, const std::vector<int64_t>
 }
 
 // block_ptr != nullptr: rows ordered by (block, level), levels numbered per block (blk_lev_ptr), for k_trsv_csr_blocks
-static int build_csr_schedule(ddm_ctx *ctx, const ddm_csr *A, const std::vector<double> &lu, const std::vector<int64_t> &diag, bool upper, TriCsr &S,
+static int build_csr_schedule(ddm_ctx *ctx, const ddm_csr *A, const hvec<double> &lu, const std::vector<int64_t> &diag, bool upper, TriCsr &S,
                               const Supernodes &SN, int64_t nblocks = 0, const int64_t *block_ptr = nullptr)
 {
   const int64_t n = A->nrows;
@@ -1113,7 +1216,7 @@ static int ilu0_create_impl(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, con
   ddm_ilu0 *F = new ddm_ilu0;
   F->n = A->nrows;
   F->nnz = A->nnz;
-  F->h_lu = A->h_va;
+  hvec_copy(F->h_lu, A->h_va.data(), A->h_va.size());
   std::vector<int64_t> diag(A->nrows);
   std::vector<int> rcs(nblocks, 0);
   {
@@ -1147,9 +1250,10 @@ static int ilu0_create_impl(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, con
 // ---- sparse direct local solver (host Cholesky, device triangular solves) ----------------------------------------
 struct CholResult {
   std::vector<int32_t> perm; // perm[new] = old (rank-local indices; blocks stay contiguous)
-  std::vector<int64_t> rp, diag;
-  std::vector<int32_t> ci;
-  std::vector<double> lu;
+  hvec<int64_t> rp;
+  std::vector<int64_t> diag;
+  hvec<int32_t> ci;
+  hvec<double> lu;
   double flops = 0.0;
   int64_t nnzL = 0;
   std::string error;
@@ -1332,6 +1436,7 @@ static int sn_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, con
   if (!force && flops < min_flops) return 1;
   if (max_flops > 0.0 && flops > max_flops)
     return fail(ctx, DDM_ENOTIMPL, "sparse direct solver: the factorisation needs %.3g flops (limit %.3g)", flops, max_flops);
+  DDMCHECK(csr_wait_upload(ctx, A)); // (matrices the library assembled itself are uploaded by a helper thread: csr_adopt)
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)entries * 8.0 > 0.85 * (double)free_b)
     return fail(ctx, DDM_ENOTIMPL, "sparse direct solver: the factor needs %.1f GB, %.1f GB of device memory are free", entries * 8e-9, free_b * 1e-9);
@@ -1556,7 +1661,7 @@ static int build_xcd_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
   const ddm_csr *A = F->A;
   const int64_t *rp = A->h_rp.data();
   const int32_t *ci = A->h_ci.data();
-  const std::vector<double> &lu = F->h_lu;
+  const hvec<double> &lu = F->h_lu;
   const std::vector<int64_t> &diag = F->h_diag;
   const int nb = (int)F->h_block_ptr.size() - 1;
   std::vector<GroupDesc> groups(nb);
@@ -1922,9 +2027,17 @@ static void enqueue_multi_levels(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const doub
       const LevelDesc &L = S.desc[l];
       if (L.m == 0) continue;
       const bool wide = L.w >= 96 && nrhs <= WG;
-      const int64_t threads = (int64_t)L.m * nrhs;
+      const bool quad = !wide && nrhs % 4 == 0 && ldd % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)D & 31) == 0 && ((uintptr_t)X & 31) == 0;
+      const int64_t threads = (int64_t)L.m * (quad ? nrhs / 4 : nrhs);
       const unsigned grid = wide ? (unsigned)L.m : (unsigned)((threads + WG - 1) / WG);
-      if (pass) {
+      if (quad) {
+        if (pass)
+          hipLaunchKernelGGL(k_trsv_level_multi4<true>, dim3(grid), dim3(WG), 0, ctx->stream, L.m, L.w, nrhs / 4, S.rows + L.row_off, S.cols + L.ent_off, S.vals + L.ent_off,
+                             S.dinv + L.row_off, D, ldd, X, ldx);
+        else
+          hipLaunchKernelGGL(k_trsv_level_multi4<false>, dim3(grid), dim3(WG), 0, ctx->stream, L.m, L.w, nrhs / 4, S.rows + L.row_off, S.cols + L.ent_off, S.vals + L.ent_off,
+                             (const double *)nullptr, D, ldd, X, ldx);
+      } else if (pass) {
         if (wide)
           hipLaunchKernelGGL(k_trsv_level_multi_wide<true>, dim3(grid), dim3(WG), 0, ctx->stream, L.m, L.w, nrhs, S.rows + L.row_off, S.cols + L.ent_off,
                              S.vals + L.ent_off, S.dinv + L.row_off, D, ldd, X, ldx);

@@ -92,7 +92,10 @@ struct GeneoWork {
   int gram(const double *U, int64_t ldu, int pu, const double *V, int64_t ldv, int pv, double *G)
   {
     const int64_t pp = (int64_t)pu * pv;
-    if (pu <= 128 && pv <= 80)
+    if (pu <= 32 && pv <= 32) {
+      if (U == V && ldu == ldv && pu == pv) hipLaunchKernelGGL((k_gram_small<true>), dim3(nchunk), dim3(256), 0, ctx->stream, chunks, U, ldu, pu, V, ldv, pv, partial, pp, pv);
+      else hipLaunchKernelGGL((k_gram_small<false>), dim3(nchunk), dim3(256), 0, ctx->stream, chunks, U, ldu, pu, V, ldv, pv, partial, pp, pv);
+    } else if (pu <= 128 && pv <= 80)
       hipLaunchKernelGGL((k_gram_mfma<2, 5>), dim3(nchunk), dim3(256), 0, ctx->stream, chunks, U, ldu, pu, V, ldv, pv, partial, pp, pv, 0, 0);
     else if (pu <= 144 && pv <= 144)
       hipLaunchKernelGGL((k_gram_mfma<3, 9>), dim3(nchunk), dim3(256), 0, ctx->stream, chunks, U, ldu, pu, V, ldv, pv, partial, pp, pv, 0, 0);
@@ -101,9 +104,30 @@ struct GeneoWork {
         for (int j0 = 0; j0 < pv; j0 += 80)
           hipLaunchKernelGGL((k_gram_mfma<2, 5>), dim3(nchunk), dim3(256), 0, ctx->stream, chunks, U + i0, ldu, std::min(128, pu - i0), V + j0, ldv, std::min(80, pv - j0),
                              partial, pp, pv, i0, j0);
-    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((nsub * pp + 255) / 256)), dim3(256), 0, ctx->stream, nsub, sub_chunk_ptr, pp, partial, G);
+    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((nsub * pp + 255) / 256)), dim3(256), 0, ctx->stream, nsub, sub_chunk_ptr, pp, partial, pp, G);
     HIPCHECK(ctx, hipGetLastError());
     return DDM_OK;
+  }
+  // G1[sub] = U^T V1, G2[sub] = U^T V2 (p x p each) for products that are symmetric by construction (V1 = A~ U, V2 = C~ U): one pass over
+  // U, upper tiles only -- the entries BELOW the diagonal tiles of G1 / G2 are not defined, the caller mirrors the upper triangle
+  // (gram2_mirror_host).  The partial buffer must hold 2 p p doubles per chunk.  p > 80: two general products.
+  bool gram2_sym(const double *U, int64_t ldu, const double *V1, const double *V2, int64_t ldv, int p, double *G1, double *G2)
+  {
+    const int64_t pp = (int64_t)p * p;
+    if (p > 80) {
+      (void)gram(U, ldu, p, V1, ldv, p, G1);
+      (void)gram(U, ldu, p, V2, ldv, p, G2);
+      return false;
+    }
+    hipLaunchKernelGGL(k_gram2_sym, dim3(nchunk), dim3(256), 0, ctx->stream, chunks, U, ldu, V1, V2, ldv, p, partial);
+    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((nsub * pp + 255) / 256)), dim3(256), 0, ctx->stream, nsub, sub_chunk_ptr, pp, (const double *)partial, 2 * pp, G1);
+    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((nsub * pp + 255) / 256)), dim3(256), 0, ctx->stream, nsub, sub_chunk_ptr, pp, (const double *)(partial + pp), 2 * pp, G2);
+    return true;
+  }
+  static void gram2_mirror_host(int p, double *G)
+  {
+    for (int i = 1; i < p; ++i)
+      for (int j = 0; j < i; ++j) G[(size_t)i * p + j] = G[(size_t)j * p + i];
   }
   // Out_k[:, 0:q) = (Base_k -) U_k[:, 0:pk) Y[sub]  for k < narr.  Y: nsub matrices pk x q, row-major.  More than 48 output columns
   // or more than 80 inner columns run as panels: 48 output columns per launch, the inner dimension in pieces of 72 whose products are
@@ -137,11 +161,12 @@ struct GeneoWork {
 };
 
 // A~ = A + sigma C~ and C~ = D B D without Dirichlet rows / columns, on the union pattern, as host CSR
-static void build_pencil_host(const ddm_csr *A, const ddm_csr *B, const double *pou, const uint8_t *dir, double sigma, std::vector<int64_t> &rpT,
-                              std::vector<int32_t> &ciT, std::vector<double> &vaT, std::vector<double> &vaC)
+static void build_pencil_host(const ddm_csr *A, const ddm_csr *B, const double *pou, const uint8_t *dir, double sigma, hvec<int64_t> &rpT,
+                              hvec<int32_t> &ciT, hvec<double> &vaT, hvec<double> &vaC)
 {
   const int64_t n = A->nrows;
-  rpT.assign((size_t)n + 1, 0);
+  rpT.resize((size_t)n + 1);
+  rpT[0] = 0;
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
   const int nth = (int)std::min<int64_t>(hw, std::max<int64_t>(1, n / 65536));
   std::vector<std::thread> th;
@@ -405,9 +430,9 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
   const auto t_begin = std::chrono::steady_clock::now();
   auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
   // ---- pencil ----
-  std::vector<int64_t> rpT;
-  std::vector<int32_t> ciT;
-  std::vector<double> vaT, vaC;
+  hvec<int64_t> rpT;
+  hvec<int32_t> ciT;
+  hvec<double> vaT, vaC;
   build_pencil_host(A_neu, B_neu, pou_pencil_host ? pou_pencil_host : pou_host, dirichlet_host, P.shift, rpT, ciT, vaT, vaC);
   const double t_pencil = since(t_begin);
   struct Owned {
@@ -416,13 +441,13 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
     ~Owned()
     {
       ddm_ilu0_destroy(T);
-      ddm_csr_destroy(At);
+      ddm_csr_destroy(At); // (joins the upload thread that also fills C)
       ddm_csr_destroy(C);
     }
   } own;
-  DDMCHECK(ddm_csr_create(ctx, n, n, rpT.data(), ciT.data(), vaT.data(), &own.At));
-  DDMCHECK(ddm_csr_create(ctx, n, n, rpT.data(), ciT.data(), vaC.data(), &own.C));
-  { std::vector<double>().swap(vaT); std::vector<double>().swap(vaC); }
+  // the host arrays move into At; its device copy and the values of C~ (same pattern, device only) are uploaded by a helper thread
+  // while this one factorises / analyses on the host
+  own.At = csr_adopt(ctx, n, std::move(rpT), std::move(ciT), std::move(vaT), std::move(vaC), &own.C);
   const double t_upload = since(t_begin);
   // A~ X and C~ X of the same block in one pass (the two matrices share their pattern: build_pencil_host)
   auto apply_AC = [&](int mm, const double *X, int64_t ldx, double *YA, double *YC, int64_t ldy) -> int {
@@ -431,19 +456,48 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
     return (*op_C)(mm, X, ldx, YC, ldy);
   };
   // ---- preconditioner ----
+  // "auto": the ILU(0) factorisation starts on a helper thread while this one orders and analyses for the sparse direct factor
+  // (at the headline size the analysis ends in "too expensive" after 0.9 s and the ILU(0) setup takes 2.3 s); whichever is not
+  // needed is dropped
   int direct = 0;
+  ddm_ilu0 *T_ilu = nullptr;
+  int rc_ilu = DDM_OK;
+  std::string err_ilu;
+  std::thread ilu_thread;
+  auto start_ilu = [&]() {
+    ilu_thread = std::thread([&]() {
+      (void)hipSetDevice(ctx->device);
+      rc_ilu = ilu0_create_impl(ctx, own.At, nsub, sub_ptr, /*multi_rhs_only=*/true, &T_ilu);
+      if (rc_ilu) err_ilu = ddm_last_error(ctx);
+    });
+  };
+  if (P.preconditioner != 2) start_ilu();
+  int rc_direct = DDM_OK;
+  std::string why_not;
   if (P.preconditioner != 1) {
-    const int rc = direct_create_impl(ctx, own.At, nsub, sub_ptr, 0, P.preconditioner == 2 ? 0.0 : P.max_direct_flops, /*setup_use=*/true, &own.T);
-    if (rc == DDM_OK) direct = 1;
-    else if (P.preconditioner == 2 || (rc != DDM_ENOTIMPL && rc != DDM_ENUMERIC)) return rc;
-    else if (P.verbose) std::fprintf(stderr, "[ddm geneo] sparse Cholesky not used (%s): ILU(0) preconditioner\n", ddm_last_error(ctx));
+    rc_direct = direct_create_impl(ctx, own.At, nsub, sub_ptr, 0, P.preconditioner == 2 ? 0.0 : P.max_direct_flops, /*setup_use=*/true, &own.T);
+    if (rc_direct == DDM_OK) direct = 1;
+    else why_not = ddm_last_error(ctx);
   }
   const double t_direct = since(t_begin);
-  if (!direct) DDMCHECK(ilu0_create_impl(ctx, own.At, nsub, sub_ptr, /*multi_rhs_only=*/true, &own.T));
+  if (ilu_thread.joinable()) ilu_thread.join();
+  if (direct) {
+    ddm_ilu0_destroy(T_ilu); // (speculative work, not needed)
+  } else {
+    if (P.preconditioner != 1 && (P.preconditioner == 2 || (rc_direct != DDM_ENOTIMPL && rc_direct != DDM_ENUMERIC))) {
+      ddm_ilu0_destroy(T_ilu);
+      return fail(ctx, rc_direct, "%s", why_not.c_str());
+    }
+    if (P.preconditioner != 1 && P.verbose) std::fprintf(stderr, "[ddm geneo] sparse Cholesky not used (%s): ILU(0) preconditioner\n", why_not.c_str());
+    if (rc_ilu) return fail(ctx, rc_ilu, "%s", err_ilu.c_str());
+    own.T = T_ilu;
+  }
+  const double t_prec = since(t_begin);
+  DDMCHECK(csr_wait_upload(ctx, own.At));
   const double t_setup = since(t_begin);
   if (P.verbose)
-    std::fprintf(stderr, "[ddm geneo] setup: pencil %.2f s, two CSR uploads %.2f s, sparse direct attempt %.2f s (%s), ILU(0) %.2f s\n", t_pencil, t_upload - t_pencil,
-                 t_direct - t_upload, direct ? "used" : "declined", t_setup - t_direct);
+    std::fprintf(stderr, "[ddm geneo] setup: pencil %.2f s, sparse direct attempt %.2f s (%s), rest of the ILU(0) setup (helper thread) %.2f s, rest of the matrix upload (helper thread) %.2f s\n",
+                 t_pencil, t_direct - t_upload, direct ? "used" : "declined", t_prec - t_direct, t_setup - t_prec);
   // ---- work space ----
   GeneoWork W;
   W.ctx = ctx;
@@ -462,7 +516,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
   DDMCHECK(W.alloc(&W.chunks, chunks.size()));
   DDMCHECK(W.alloc(&W.sub_chunk_ptr, scp.size()));
   DDMCHECK(W.alloc(&W.sub_of_row, (size_t)n));
-  DDMCHECK(W.alloc(&W.partial, (size_t)W.nchunk * p * p));
+  DDMCHECK(W.alloc(&W.partial, (size_t)W.nchunk * p * p * 2)); // (two products per chunk: gram2_sym)
   HIPCHECK(ctx, hipMemcpy(W.chunks, chunks.data(), sizeof(GChunk) * chunks.size(), hipMemcpyHostToDevice));
   HIPCHECK(ctx, hipMemcpy(W.sub_chunk_ptr, scp.data(), sizeof(int32_t) * scp.size(), hipMemcpyHostToDevice));
   HIPCHECK(ctx, hipMemcpy(W.sub_of_row, sor.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
@@ -493,7 +547,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
   DDMCHECK(W.alloc(&Yd, (size_t)nsub * p * q2));
   DDMCHECK(W.alloc(&mud, (size_t)nsub * m));
   std::vector<double> hA((size_t)nsub * p * p), hC((size_t)nsub * p * p), hY((size_t)nsub * p * q2), hmu((size_t)nsub * m);
-  std::vector<double> h_rr((size_t)nsub * m * m), h_rw((size_t)nsub * m * m), h_aa((size_t)nsub * m * m), h_ww((size_t)nsub * m * m), h_pp((size_t)nsub * m * m);
+  std::vector<double> h_rr((size_t)nsub * m * m), h_rw((size_t)nsub * m * m), h_aa((size_t)nsub * m * m);
   std::vector<double> dscale((size_t)nsub * p, 1.0); // column scaling of S = [X | W | P] folded into the projected problem
   const unsigned gnm = (unsigned)((n * (int64_t)m + 255) / 256);
   const int64_t ld = p;
@@ -509,13 +563,12 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
   const auto t_iter = std::chrono::steady_clock::now();
   for (it = 0; it <= P.maxit; ++it) {
     if (it > 0) {
-      // R = C X - mu A~ X ; column norms ; W = T (R / ||R||)
+      // R = C X - mu A~ X ; column norms ; W = T R
       hipLaunchKernelGGL(k_geneo_residual, dim3(gnm), dim3(256), 0, ctx->stream, n, m, W.sub_of_row, mud, AS[cur], ld, CS[cur], ld, R, (int64_t)m);
       if (con) DDMCHECK(harmonic_apply_transposed(ctx, con, m, R, m)); // residual of the constrained problem: P^T r
       DDMCHECK(W.gram(R, m, m, R, m, m, gmm[0]));
       HIPCHECK(ctx, hipMemcpyAsync(h_rr.data(), gmm[0], sizeof(double) * h_rr.size(), hipMemcpyDeviceToHost, ctx->stream));
-      hipLaunchKernelGGL(k_geneo_invsqrt_diag, dim3((unsigned)((nsub * m + 255) / 256)), dim3(256), 0, ctx->stream, (int)nsub, m, gmm[0], svec[0]);
-      hipLaunchKernelGGL(k_geneo_colscale, dim3(gnm), dim3(256), 0, ctx->stream, n, m, W.sub_of_row, svec[0], R, (int64_t)m);
+      // (W = T r with the residual columns as they are: their scaling is folded into the projected problem below, like W's and P's)
       double *Wb = S[cur] + m, *AWb = AS[cur] + m, *CWb = CS[cur] + m;
       DDMCHECK(ilu0_solve_multi_ld(ctx, own.T, m, R, m, Wb, ld));
       DDMCHECK(W.gram(R, m, m, Wb, ld, m, gmm[1]));   // r^T T r per column (diagonal)
@@ -534,31 +587,44 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
       DDMCHECK(apply_AC(m, Wb, ld, AWb, CWb, ld)); // both products of W in one pass over it
       // A~-normalisation of the columns of W and P (zero columns stay zero): the blocks themselves are NOT rescaled (six passes over
       // n x m blocks per iteration in round 2) -- the diagonal scaling D is applied where it is cheap: to the p x p Gram matrices
-      // (D G D) and to the rows of the Ritz coefficients (S D) Y = S (D Y), on the host
-      DDMCHECK(W.gram(Wb, ld, m, AWb, ld, m, gmm[3]));
-      HIPCHECK(ctx, hipMemcpyAsync(h_ww.data(), gmm[3], sizeof(double) * h_ww.size(), hipMemcpyDeviceToHost, ctx->stream));
-      double *Pb = S[cur] + 2 * m, *APb = AS[cur] + 2 * m;
-      DDMCHECK(W.gram(Pb, ld, m, APb, ld, m, gmm[4]));
-      HIPCHECK(ctx, hipMemcpyAsync(h_pp.data(), gmm[4], sizeof(double) * h_pp.size(), hipMemcpyDeviceToHost, ctx->stream));
+      // (D G D) and to the rows of the Ritz coefficients (S D) Y = S (D Y), on the host; the norms W^T A~ W, P^T A~ P are the diagonal
+      // of the unscaled S^T A~ S that is computed below anyway (two separate m x m products until round 3)
       have_residual = true;
     }
-    DDMCHECK(W.gram(S[cur], ld, p, AS[cur], ld, p, gA));
-    DDMCHECK(W.gram(S[cur], ld, p, CS[cur], ld, p, gC));
+    const bool upper_only = W.gram2_sym(S[cur], ld, AS[cur], CS[cur], ld, p, gA, gC);
+    HIPCHECK(ctx, hipGetLastError());
     HIPCHECK(ctx, hipMemcpyAsync(hA.data(), gA, sizeof(double) * hA.size(), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHECK(ctx, hipMemcpyAsync(hC.data(), gC, sizeof(double) * hC.size(), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (upper_only)
+      for (int64_t s = 0; s < nsub; ++s) {
+        GeneoWork::gram2_mirror_host(p, hA.data() + (size_t)s * p * p);
+        GeneoWork::gram2_mirror_host(p, hC.data() + (size_t)s * p * p);
+      }
     if (have_residual) { // residuals of the block that entered this iteration (its Ritz values are still in hmu)
       worst = 0.0;
-      for (int64_t s = 0; s < nsub; ++s)
+      int64_t nconv_cols = 0;
+      int lead_min = nev; // converged columns in front of the first unconverged one, minimum over the subdomains
+      for (int64_t s = 0; s < nsub; ++s) {
+        int lead = 0;
+        bool leading = true;
         for (int j = 0; j < nev; ++j) {
           const size_t dj = ((size_t)s * m + j) * m + j;
           const double rn = std::sqrt(std::max(h_rr[dj], 0.0)), mu = std::fabs(hmu[(size_t)s * m + j]);
-          // T was applied to rhat = r / ||r||:  r^T T r = ||r||^2 rhat^T T rhat
-          const double res = direct ? rn * std::sqrt(std::fabs(h_rw[dj])) / std::max(mu, 1e-300)
+          const double res = direct ? std::sqrt(std::fabs(h_rw[dj])) / std::max(mu, 1e-300) // sqrt(r^T T r) / mu
                                     : rn / std::max(mu * std::sqrt(std::max(h_aa[dj], 0.0)), 1e-300);
           worst = std::max(worst, res);
+          if (res < P.tolerance) {
+            ++nconv_cols;
+            if (leading) ++lead;
+          } else
+            leading = false;
         }
-      if (P.verbose) std::fprintf(stderr, "[ddm geneo] it %3d  worst residual %.3e  rank >= %d  lambda_min(sub 0) %.6g\n", it, worst, rank_min, 1.0 / hmu[0] - P.shift);
+        lead_min = std::min(lead_min, lead);
+      }
+      if (P.verbose)
+        std::fprintf(stderr, "[ddm geneo] it %3d  worst residual %.3e  rank >= %d  lambda_min(sub 0) %.6g  converged columns %lld of %lld, leading (min over subdomains) %d\n", it, worst,
+                     rank_min, 1.0 / hmu[0] - P.shift, (long long)nconv_cols, (long long)(nsub * nev), lead_min);
       if (worst < P.tolerance) {
         converged = 1;
         break;
@@ -579,7 +645,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
             for (int i = 0; i < p; ++i) d[i] = 1.0;
             if (have_residual)
               for (int j = 0; j < m; ++j) {
-                const double gw = h_ww[((size_t)s * m + j) * m + j], gp = h_pp[((size_t)s * m + j) * m + j];
+                const double gw = hA[(size_t)s * p * p + (size_t)(m + j) * p + (m + j)], gp = hA[(size_t)s * p * p + (size_t)(2 * m + j) * p + (2 * m + j)];
                 d[m + j] = gw > 1e-300 ? 1.0 / std::sqrt(gw) : 0.0;
                 d[2 * m + j] = gp > 1e-300 ? 1.0 / std::sqrt(gp) : 0.0;
               }
@@ -838,6 +904,25 @@ extern "C" int ddm_blockvec_gram(ddm_ctx *ctx, int64_t nsub, const int64_t *sub_
   DDMCHECK(W.alloc(&G, (size_t)nsub * pu * pv));
   DDMCHECK(W.gram(U, ldu, pu, V, ldv, pv, G));
   return ddm_memcpy_d2h(ctx, G_host, G, (int64_t)sizeof(double) * nsub * pu * pv);
+}
+extern "C" int ddm_blockvec_gram2_sym(ddm_ctx *ctx, int64_t nsub, const int64_t *sub_ptr, const double *U, int64_t ldu, const double *V1, const double *V2, int64_t ldv, int p,
+                                      double *G1_host, double *G2_host)
+{
+  if (!ctx || !sub_ptr || !U || !V1 || !V2 || !G1_host || !G2_host || nsub < 1 || p < 1 || ldu < p || ldv < p) return fail(ctx, DDM_EINVAL, "ddm_blockvec_gram2_sym: bad arguments");
+  GeneoWork W;
+  DDMCHECK(blockvec_setup(ctx, W, nsub, sub_ptr, 2 * p * p));
+  double *G = nullptr;
+  DDMCHECK(W.alloc(&G, (size_t)nsub * p * p * 2));
+  const bool upper_only = W.gram2_sym(U, ldu, V1, V2, ldv, p, G, G + (size_t)nsub * p * p);
+  HIPCHECK(ctx, hipGetLastError());
+  DDMCHECK(ddm_memcpy_d2h(ctx, G1_host, G, (int64_t)sizeof(double) * nsub * p * p));
+  DDMCHECK(ddm_memcpy_d2h(ctx, G2_host, G + (size_t)nsub * p * p, (int64_t)sizeof(double) * nsub * p * p));
+  if (upper_only)
+    for (int64_t s = 0; s < nsub; ++s) {
+      GeneoWork::gram2_mirror_host(p, G1_host + (size_t)s * p * p);
+      GeneoWork::gram2_mirror_host(p, G2_host + (size_t)s * p * p);
+    }
+  return DDM_OK;
 }
 extern "C" int ddm_blockvec_rotate(ddm_ctx *ctx, int64_t nsub, const int64_t *sub_ptr, const double *U, int64_t ldu, int p, const double *Y_host, int q,
                                    const double *Base, int64_t ldb, double *Out, int64_t ldo)

@@ -34,7 +34,10 @@ __global__ __launch_bounds__(256) void k_gram_mfma(const GChunk *__restrict__ ch
                                                   int out_i0, int out_j0)
 {
   const GChunk c = chunks[blockIdx.x];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // tile rows are dealt to the wavefronts in turn, and with 5 tile rows (p = 72) the first one gets two: the FP64 MFMA (64 cycles per
+  // 16x16x4 on a SIMD) makes that wavefront the critical one, so the deal starts at a different wavefront in every workgroup --
+  // the workgroups that share a CU then load its four SIMDs evenly (4.5 -> 3.3 ms for the 72 x 72 products at 216^3)
+  const int lane = threadIdx.x & 63, wave = ((threadIdx.x >> 6) + blockIdx.x) & 3;
   const int ta_n = (pu + 15) >> 4, tb_n = (pv + 15) >> 4;
   const int lc = lane & 15, lr = lane >> 4;
   v4d acc[TAW][TB];
@@ -82,16 +85,187 @@ __global__ __launch_bounds__(256) void k_gram_mfma(const GChunk *__restrict__ ch
     }
 }
 
-// G[sub] = sum of the chunk partials of the subdomain, in chunk order (deterministic); one thread per entry
-__global__ void k_gram_reduce(int nsub, const int32_t *__restrict__ sub_chunk_ptr, int64_t pp, const double *__restrict__ partial, double *__restrict__ G)
+// Gram products of NARROW blocks (pu, pv <= 32: the m x m inner products of the block eigensolver at nev = 20).  The general kernel
+// above deals tile rows to the wavefronts, which leaves two of four idle here and 12 loads in flight per wavefront; this one
+// splits the ROWS of the chunk over the four wavefronts (32 rows = 8 slabs per wavefront and trip, 16..32 loads in flight), every
+// wavefront accumulates all (at most 2 x 2) tiles, and the four partial results meet in LDS in wavefront order (deterministic).
+// SAME: U and V are the same block (column norms, R^T R): the A operand doubles as the B operand, nothing is loaded twice.
+template <bool SAME>
+__global__ __launch_bounds__(256) void k_gram_small(const GChunk *__restrict__ chunks, const double *__restrict__ U, int64_t ldu, int pu,
+                                                   const double *__restrict__ V, int64_t ldv, int pv, double *__restrict__ partial, int64_t out_stride, int out_ld)
+{
+  __shared__ double red[4][4][256];
+  const GChunk c = chunks[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lc = lane & 15, lr = lane >> 4;
+  const bool a1 = pu > 16, b1 = pv > 16;
+  v4d acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = v4d{0.0, 0.0, 0.0, 0.0};
+  constexpr int GU = 8;
+  for (int64_t r = c.r0 + (int64_t)wave * 4 * GU; r < c.r1; r += 16 * GU) {
+    double av[GU][2], bv[GU][2];
+#pragma unroll
+    for (int g = 0; g < GU; ++g) {
+      const int64_t row = r + 4 * g + lr;
+      const bool rok = row < c.r1;
+      av[g][0] = (rok && lc < pu) ? U[row * ldu + lc] : 0.0;
+      av[g][1] = (rok && a1 && 16 + lc < pu) ? U[row * ldu + 16 + lc] : 0.0;
+      if (!SAME) {
+        bv[g][0] = (rok && lc < pv) ? V[row * ldv + lc] : 0.0;
+        bv[g][1] = (rok && b1 && 16 + lc < pv) ? V[row * ldv + 16 + lc] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < GU; ++g)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          if ((a == 0 || a1) && (b == 0 || b1)) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g][a], SAME ? av[g][b] : bv[g][b], acc[a][b], 0, 0, 0);
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) red[wave][2 * a + b][4 * lane + q] = acc[a][b][q];
+  __syncthreads();
+  double *out = partial + (int64_t)blockIdx.x * out_stride;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { // thread = entry (4 lane + q) of tile t, summed over the wavefronts in order
+    const int e = threadIdx.x, l = e >> 2, q = e & 3;
+    const int i = ((t >> 1) << 4) + (l >> 4) + 4 * q, j = ((t & 1) << 4) + (l & 15);
+    if (i < pu && j < pv) out[(int64_t)i * out_ld + j] = ((red[0][t][e] + red[1][t][e]) + red[2][t][e]) + red[3][t][e];
+  }
+}
+
+// The two SYMMETRIC p x p products of the Rayleigh-Ritz step in one pass:  G1 = U^T V1,  G2 = U^T V2  with V1 = A~ U, V2 = C~ U
+// (p <= 80: five 16-column tiles).  U is read once for both, and only the tiles on and above the diagonal are computed (15 of 25:
+// the FP64 MFMA costs 64 cycles per 16x16x4 on a SIMD, which made the separate full products MFMA-bound on their critical wavefront,
+// 2 x 4.3 ms at 216^3 for 2 x 12.5 GB); the host mirrors the upper triangle.  The 15 tiles are dealt to the four wavefronts in
+// groups that share operands -- {00 01 02 03}, {11 12 13 14}, {22 23 24 04}, {33 34 44} -- and the group a wavefront takes rotates
+// with the workgroup index, so that the workgroups of a CU load its four SIMDs evenly.  Operands of the next 8 rows are in flight
+// while the matrix cores work on the current 8 (two register buffers).  Entries of tiles below the diagonal are NOT written.
+template <int G>
+struct Gram2Group;
+template <>
+struct Gram2Group<0> {
+  static constexpr int NA = 1, NB = 4, NT = 4;
+  static constexpr int AL[2] = {0, 0}, BL[4] = {0, 1, 2, 3}, TA[4] = {0, 0, 0, 0}, TB[4] = {0, 1, 2, 3};
+};
+template <>
+struct Gram2Group<1> {
+  static constexpr int NA = 1, NB = 4, NT = 4;
+  static constexpr int AL[2] = {1, 1}, BL[4] = {1, 2, 3, 4}, TA[4] = {0, 0, 0, 0}, TB[4] = {0, 1, 2, 3};
+};
+template <>
+struct Gram2Group<2> {
+  static constexpr int NA = 2, NB = 3, NT = 4;
+  static constexpr int AL[2] = {2, 0}, BL[4] = {2, 3, 4, 4}, TA[4] = {0, 0, 0, 1}, TB[4] = {0, 1, 2, 2};
+};
+template <>
+struct Gram2Group<3> {
+  static constexpr int NA = 2, NB = 2, NT = 3;
+  static constexpr int AL[2] = {3, 4}, BL[4] = {3, 4, 4, 4}, TA[4] = {0, 0, 1, 1}, TB[4] = {0, 1, 1, 1};
+};
+template <int G>
+__device__ __forceinline__ void gram2_sym_group(const GChunk c, const double *__restrict__ U, int64_t ldu, const double *__restrict__ V1, const double *__restrict__ V2,
+                                                int64_t ldv, int p, double *__restrict__ out1, double *__restrict__ out2)
+{
+  using GG = Gram2Group<G>;
+  constexpr int GU = 2; // 4-row slabs per buffer
+  const int lane = threadIdx.x & 63, lc = lane & 15, lr = lane >> 4;
+  const int tn = (p + 15) >> 4;
+  v4d acc1[GG::NT], acc2[GG::NT];
+#pragma unroll
+  for (int t = 0; t < GG::NT; ++t) acc1[t] = acc2[t] = v4d{0.0, 0.0, 0.0, 0.0};
+  double a0[GU][GG::NA], b0[GU][GG::NB], c0[GU][GG::NB], a1[GU][GG::NA], b1[GU][GG::NB], c1[GU][GG::NB];
+  auto load = [&](double(&a)[GU][GG::NA], double(&b)[GU][GG::NB], double(&cc)[GU][GG::NB], int64_t r) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < GU; ++g) {
+      const int64_t row = r + 4 * g + lr;
+      const bool rok = row < c.r1;
+#pragma unroll
+      for (int i = 0; i < GG::NA; ++i) {
+        const int col = (GG::AL[i] << 4) + lc;
+        a[g][i] = (rok && col < p) ? U[row * ldu + col] : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < GG::NB; ++i) {
+        const int col = (GG::BL[i] << 4) + lc;
+        const bool ok = rok && col < p;
+        b[g][i] = ok ? V1[row * ldv + col] : 0.0;
+        cc[g][i] = ok ? V2[row * ldv + col] : 0.0;
+      }
+    }
+  };
+  auto compute = [&](const double(&a)[GU][GG::NA], const double(&b)[GU][GG::NB], const double(&cc)[GU][GG::NB]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < GU; ++g)
+#pragma unroll
+      for (int t = 0; t < GG::NT; ++t)
+        if (GG::AL[GG::TA[t]] < tn && GG::BL[GG::TB[t]] < tn) {
+          acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g][GG::TA[t]], b[g][GG::TB[t]], acc1[t], 0, 0, 0);
+          acc2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g][GG::TA[t]], cc[g][GG::TB[t]], acc2[t], 0, 0, 0);
+        }
+  };
+  constexpr int RS = 4 * GU;
+  load(a0, b0, c0, c.r0);
+  for (int64_t r = c.r0; r < c.r1; r += 2 * RS) {
+    load(a1, b1, c1, r + RS); // (rows beyond the chunk load zeros)
+    compute(a0, b0, c0);
+    load(a0, b0, c0, r + 2 * RS);
+    compute(a1, b1, c1);
+  }
+#pragma unroll
+  for (int t = 0; t < GG::NT; ++t) {
+    const int ta = GG::AL[GG::TA[t]], tb = GG::BL[GG::TB[t]];
+    if (ta >= tn || tb >= tn) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = (ta << 4) + lr + 4 * q, j = (tb << 4) + lc;
+      if (i < p && j < p) {
+        out1[(int64_t)i * p + j] = acc1[t][q];
+        out2[(int64_t)i * p + j] = acc2[t][q];
+      }
+    }
+  }
+}
+// partial: per chunk two p x p matrices (stride 2 p p)
+__global__ __launch_bounds__(256) void k_gram2_sym(const GChunk *__restrict__ chunks, const double *__restrict__ U, int64_t ldu, const double *__restrict__ V1,
+                                                  const double *__restrict__ V2, int64_t ldv, int p, double *__restrict__ partial)
+{
+  const GChunk c = chunks[blockIdx.x];
+  const int64_t pp = (int64_t)p * p;
+  double *out1 = partial + (int64_t)blockIdx.x * 2 * pp, *out2 = out1 + pp;
+  switch (((threadIdx.x >> 6) + blockIdx.x) & 3) { // wave-uniform
+  case 0: gram2_sym_group<0>(c, U, ldu, V1, V2, ldv, p, out1, out2); break;
+  case 1: gram2_sym_group<1>(c, U, ldu, V1, V2, ldv, p, out1, out2); break;
+  case 2: gram2_sym_group<2>(c, U, ldu, V1, V2, ldv, p, out1, out2); break;
+  default: gram2_sym_group<3>(c, U, ldu, V1, V2, ldv, p, out1, out2); break;
+  }
+}
+
+// G[sub] = sum of the chunk partials of the subdomain in a fixed order (deterministic): one thread per entry, eight independent running
+// sums over the chunks (a single one is a chain of ~660 dependent loads at 216^3: 0.27 ms per call whatever the size of the product)
+// (stride: distance of the chunks' partial matrices, pp unless two products share the buffer)
+__global__ void k_gram_reduce(int nsub, const int32_t *__restrict__ sub_chunk_ptr, int64_t pp, const double *__restrict__ partial, int64_t stride, double *__restrict__ G)
 {
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (t >= (int64_t)nsub * pp) return;
   const int s = (int)(t / pp);
   const int64_t e = t - (int64_t)s * pp;
-  double acc = 0.0;
-  for (int c = sub_chunk_ptr[s]; c < sub_chunk_ptr[s + 1]; ++c) acc += partial[(int64_t)c * pp + e];
-  G[t] = acc;
+  double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  int c = sub_chunk_ptr[s];
+  const int c1 = sub_chunk_ptr[s + 1];
+  for (; c + 8 <= c1; c += 8)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += partial[(int64_t)(c + u) * stride + e];
+  for (; c < c1; ++c) a[0] += partial[(int64_t)c * stride + e];
+  G[t] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -136,28 +310,31 @@ __global__ __launch_bounds__(256) void k_rotate_mfma(const GChunk *__restrict__ 
   __syncthreads();
   const int tq_n = q16 >> 4;
   // The 16 x p4 slab of U is read as ONE flat run of 16 p4 elements (contiguous in memory when ldu == p: full 512-byte loads), and the
-  // NEXT slab is fetched into registers while the matrix cores work on the current one (round 3: 1.5 TB/s before).
+  // slabs of the next TWO trips are on their way into registers while the matrix cores work on the current one: the workgroup's
+  // LDS (Y + four staging slabs) allows two workgroups per CU, i.e. two wavefronts per SIMD, and the 54 MFMAs of a slab (1.4 us) are
+  // shorter than an HBM round trip under load -- with one slab in flight (round 3, first version) the wavefronts waited for data
+  // (3.2 TB/s for the fused rotation at 216^3, 1.5 TB/s before any prefetch).
   constexpr int NPRE = ROT_PRE > 0 ? ROT_PRE : 1;
+  constexpr int DEPTH = 2;
   const int nel = 16 * p4;
-  double pre[NPRE];
-  auto load_slab = [&](int64_t r0s) __attribute__((always_inline)) {
+  double pre[DEPTH][NPRE];
+  auto load_slab = [&](double(&dst)[NPRE], int64_t r0s) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < NPRE; ++u) {
       const int idx = lane + (u << 6);
       const int i = idx / p4, k = idx - i * p4;
       const int64_t row = r0s + i;
-      pre[u] = (idx < nel && row < c.r1 && k < p) ? U[row * ldu + k] : 0.0;
+      dst[u] = (idx < nel && row < c.r1 && k < p) ? U[row * ldu + k] : 0.0;
     }
   };
-  if (ROT_PRE > 0 && c.r0 + 16 * wave < c.r1) load_slab(c.r0 + 16 * wave);
-  for (int64_t r0 = c.r0 + 16 * wave; r0 < c.r1; r0 += 64) {
+  auto process = [&](const double(&src)[NPRE], int64_t r0) __attribute__((always_inline)) {
     if (ROT_PRE > 0) {
 #pragma unroll
       for (int u = 0; u < NPRE; ++u) {
         const int idx = lane + (u << 6);
         if (idx < nel) {
           const int i = idx / p4;
-          Us[i * ustride + (idx - i * p4)] = pre[u];
+          Us[i * ustride + (idx - i * p4)] = src[u];
         }
       }
     } else { // stage 16 rows x p of U: row by row, lanes along the row (coalesced)
@@ -166,9 +343,10 @@ __global__ __launch_bounds__(256) void k_rotate_mfma(const GChunk *__restrict__ 
         for (int k = lane; k < p4; k += 64) Us[i * ustride + k] = (row < c.r1 && k < p) ? U[row * ldu + k] : 0.0;
       }
     }
-    __builtin_amdgcn_s_waitcnt(0); // the wave reads back what its own lanes wrote (same wave: no barrier needed, only completion)
+    // the wave reads back what its own lanes wrote: LDS operations of a wave complete in order, the wait covers the LDS counter only
+    // (the prefetched slabs stay in flight) and the barrier keeps the compiler from moving the reads up
+    __builtin_amdgcn_s_waitcnt(ROT_PRE > 0 ? 0xC07F : 0);
     __builtin_amdgcn_wave_barrier();
-    if (ROT_PRE > 0 && r0 + 64 < c.r1) load_slab(r0 + 64);
     v4d acc[ROT_TQ];
 #pragma unroll
     for (int t = 0; t < ROT_TQ; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
@@ -194,6 +372,23 @@ __global__ __launch_bounds__(256) void k_rotate_mfma(const GChunk *__restrict__ 
       }
     }
     __builtin_amdgcn_wave_barrier(); // all lanes are done with Us before the next slab overwrites it
+  };
+  const int64_t rw = c.r0 + 16 * wave;
+  if (ROT_PRE > 0) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) load_slab(pre[d], rw + 64 * d); // (rows beyond the chunk load zeros)
+    for (int64_t r0 = rw; r0 < c.r1; r0 += 64 * DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        const int64_t rd = r0 + 64 * d;
+        if (rd < c.r1) { // wave-uniform
+          process(pre[d], rd);
+          load_slab(pre[d], rd + 64 * DEPTH);
+        }
+      }
+    }
+  } else {
+    for (int64_t r0 = rw; r0 < c.r1; r0 += 64) process(pre[0], r0);
   }
 }
 

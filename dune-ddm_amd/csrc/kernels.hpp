@@ -190,6 +190,39 @@ __global__ __launch_bounds__(WG) void k_trsv_level_multi(int m, int w, int nrhs,
   const double s = trsv_row_sum_multi<int64_t>(UPPER ? x[o] : d[(int64_t)rows[r] * ldd + j], w, m, r, ldx, j, cols, vals, x);
   x[o] = UPPER ? s * dinv[r] : s;
 }
+// nrhs % 4 == 0 and 32-byte aligned rows: one thread per (row, group of 4 right-hand sides) -- a quarter of the index / value /
+// gather instructions and wavefronts per level (the 24-column solves of the block eigensolver move 27 GB of gathered x rows per
+// triangle through the caches at 216^3: the large levels are throughput-bound).  Same sums in the same order as the scalar kernel.
+template <bool UPPER>
+__global__ __launch_bounds__(WG) void k_trsv_level_multi4(int m, int w, int nq /* nrhs / 4 */, const int32_t *__restrict__ rows,
+                                                           const int32_t *__restrict__ cols, const double *__restrict__ vals,
+                                                           const double *__restrict__ dinv, const double *__restrict__ d, int64_t ldd, double *x, int64_t ldx)
+{
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x;
+  const int r = (int)(t / nq);
+  if (r >= m) return;
+  const int j = 4 * (int)(t - (int64_t)r * nq);
+  const int64_t o = (int64_t)rows[r] * ldx + j;
+  d4 s = UPPER ? *reinterpret_cast<const d4 *>(x + o) : *reinterpret_cast<const d4 *>(d + (int64_t)rows[r] * ldd + j);
+  for (int k0 = 0; k0 < w; k0 += TRSV_UNROLL) {
+    int32_t c[TRSV_UNROLL];
+    double v[TRSV_UNROLL];
+    d4 xv[TRSV_UNROLL];
+#pragma unroll
+    for (int u = 0; u < TRSV_UNROLL; ++u) {
+      const bool ok = k0 + u < w;
+      c[u] = ok ? cols[(int64_t)(k0 + u) * m + r] : -1;
+      v[u] = ok ? vals[(int64_t)(k0 + u) * m + r] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < TRSV_UNROLL; ++u) xv[u] = c[u] >= 0 ? *reinterpret_cast<const d4 *>(x + (int64_t)c[u] * ldx + j) : d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < TRSV_UNROLL; ++u) s -= v[u] * xv[u];
+  }
+  if (UPPER) s *= dinv[r];
+  *reinterpret_cast<d4 *>(x + o) = s;
+}
 // The same for levels of WIDE rows (factors of the sparse direct solver: separator rows have thousands of entries and a
 // level often holds a single row): one workgroup per row, the 256 threads split the row's entries into 256 / nrhs slices
 // per right-hand side, slice sums meet in LDS and are added in slice order (deterministic).

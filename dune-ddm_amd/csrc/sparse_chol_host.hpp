@@ -464,7 +464,8 @@ inline bool factorize_lu(const PermutedLowerLU &P, BlockFactor &F, std::vector<d
   return true;
 }
 // rows of an L U block factor in the ILU(0) storage convention: L(i, j) below the diagonal, 1 / U(i, i) on it, U(i, j) above
-inline void append_rows_lu(const BlockFactor &F, const std::vector<double> &Ux, int64_t r0, std::vector<int64_t> &rp, std::vector<int32_t> &ci, std::vector<double> &lu,
+template <class VRP, class VCI, class VLU>
+inline void append_rows_lu(const BlockFactor &F, const std::vector<double> &Ux, int64_t r0, VRP &rp, VCI &ci, VLU &lu,
                            std::vector<int64_t> &diag)
 {
   const int32_t n = F.n;
@@ -502,7 +503,8 @@ inline void append_rows_lu(const BlockFactor &F, const std::vector<double> &Ux, 
 // Appends the rows of this block's factor to a CSR in the storage convention of the ILU(0) engines (global permuted
 // row numbers = r0 + new local index): strictly lower part l_ij / l_jj (unit lower factor), diagonal 1 / l_ii^2
 // (inverse pivot), strictly upper part l_ii * l_ji (= D L^T).  Columns ascending in every row.
-inline void append_rows(const BlockFactor &F, int64_t r0, std::vector<int64_t> &rp, std::vector<int32_t> &ci, std::vector<double> &lu, std::vector<int64_t> &diag)
+template <class VRP, class VCI, class VLU>
+inline void append_rows(const BlockFactor &F, int64_t r0, VRP &rp, VCI &ci, VLU &lu, std::vector<int64_t> &diag)
 {
   const int32_t n = F.n;
   std::vector<int64_t> lcnt(n + 1, 0); // strictly lower entries per row (transpose of the CSC factor)

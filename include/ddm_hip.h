@@ -333,6 +333,11 @@ int ddm_harmonic_extend(ddm_ctx *ctx, ddm_harmonic *H, int nrhs, double *X, int6
  * Synchronous. */
 int ddm_blockvec_gram(ddm_ctx *ctx, int64_t nsub, const int64_t *sub_ptr, const double *U, int64_t ldu, int pu, const double *V, int64_t ldv,
                       int pv, double *G_host);
+/* gram2_sym: G1_host[s] = U^T V1, G2_host[s] = U^T V2 (p x p) for products that are SYMMETRIC by construction (V1 = A~ U, V2 = C~ U:
+ * the two projected matrices of the Rayleigh-Ritz step) -- one pass over U, upper tiles only, the lower triangle is the mirrored
+ * upper one. */
+int ddm_blockvec_gram2_sym(ddm_ctx *ctx, int64_t nsub, const int64_t *sub_ptr, const double *U, int64_t ldu, const double *V1, const double *V2, int64_t ldv, int p,
+                           double *G1_host, double *G2_host);
 int ddm_blockvec_rotate(ddm_ctx *ctx, int64_t nsub, const int64_t *sub_ptr, const double *U, int64_t ldu, int p, const double *Y_host, int q,
                         const double *Base, int64_t ldb, double *Out, int64_t ldo);
 /* host logic of the Rayleigh-Ritz step, exposed for the CPU tests: symmetric eigen-decomposition (V: matrix in, eigenvectors as

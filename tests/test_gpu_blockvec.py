@@ -58,3 +58,39 @@ def test_rotate_matches_fp64_reference(ddm, p, q):
         assert np.all(np.abs(b[rows, :q] - ref) <= 1e-13 * (np.abs(Bh[rows, :q]) + np.abs(Uh[rows]) @ np.abs(Y[s])))
     assert np.array_equal(b[:, q:], Bh[:, q:])
     ctx.close()
+
+
+@pytest.mark.parametrize("p", [72, 48, 80, 33, 5, 96])   # 96: beyond five tiles, two general products
+def test_gram2_sym_matches_fp64_reference(ddm, p):
+    """the fused pair of symmetric products of the Rayleigh-Ritz step (k_gram2_sym): U^T (M1 U), U^T (M2 U) with symmetric M1, M2 applied
+    row-wise per subdomain (here: symmetric tridiagonal-in-rows stand-ins built on the host), against the FP64 host products; the result
+    must be exactly symmetric (mirrored upper triangle)"""
+    import torch
+    ctx = ddm.torch_context(0)
+    rng = np.random.default_rng(100 + p)
+    sizes = [4099, 17, 2048, 1, 6150]
+    bp = np.concatenate([[0], np.cumsum(sizes)])
+    n = int(bp[-1])
+    Uh = rng.standard_normal((n, p + 3))
+    V1h = np.empty((n, p + 3))
+    V2h = np.empty((n, p + 3))
+    for s in range(len(sizes)):           # V = M U with M symmetric per subdomain => U^T V symmetric up to rounding
+        r = slice(bp[s], bp[s + 1])
+        d1, d2 = rng.uniform(1, 2, sizes[s]), rng.uniform(0, 1, sizes[s])
+        V1h[r] = d1[:, None] * Uh[r]
+        V2h[r] = d2[:, None] * Uh[r]
+        if sizes[s] > 1:
+            e = rng.standard_normal(sizes[s] - 1)
+            V1h[r][1:] += e[:, None] * Uh[r][:-1]
+            V1h[r][:-1] += e[:, None] * Uh[r][1:]
+    U, V1, V2 = (torch.as_tensor(x).cuda() for x in (Uh, V1h, V2h))
+    g1, g2 = ddm.blockvec_gram2_sym(ctx, bp, U[:, :p], V1[:, :p], V2[:, :p])     # strided views (ld = p + 3)
+    for s in range(len(sizes)):
+        r = slice(bp[s], bp[s + 1])
+        for g, Vh in ((g1, V1h), (g2, V2h)):
+            ref = Uh[r, :p].T @ Vh[r, :p]
+            bound = np.abs(Uh[r, :p]).T @ np.abs(Vh[r, :p])
+            assert np.all(np.abs(g[s] - ref) <= 2e-13 * bound + 1e-300), (s, np.abs(g[s] - ref).max())
+            if p <= 80:
+                assert np.array_equal(g[s], g[s].T)
+    ctx.close()
