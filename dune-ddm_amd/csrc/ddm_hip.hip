@@ -648,6 +648,7 @@ struct TriSchedule { // one triangular factor, level by level in sliced ELL
   int32_t *cols = nullptr;            // sliced ELL columns
   double *vals = nullptr;             // sliced ELL values
   double *dinv = nullptr;             // upper only: inverse pivots in level order
+  float *vals_f32 = nullptr, *dinv_f32 = nullptr; // single-precision copies for the preconditioner sweeps (made on first use)
   LevelDesc *d_desc = nullptr;        // device copy (for the small-level kernel)
   struct Launch {                     // execution plan
     int first, count;                 // levels [first, first+count)
@@ -731,6 +732,9 @@ struct ddm_ilu0 {
   double *mg_X = nullptr;
   int mg_nrhs = 0;
   int64_t mg_ldd = 0, mg_ldx = 0;
+  bool mg_f32 = false;   // the cached graph runs the single-precision sweeps
+  float *xf = nullptr;   // their n x nrhs work block
+  int xf_nrhs = 0;
   // HIP graph cache of the whole solve for one (d, x) pointer pair
   hipGraphExec_t graph = nullptr;
   const double *g_d = nullptr;
@@ -1150,6 +1154,8 @@ static void free_schedule(TriSchedule &S)
   (void)hipFree(S.cols);
   (void)hipFree(S.vals);
   (void)hipFree(S.dinv);
+  (void)hipFree(S.vals_f32);
+  (void)hipFree(S.dinv_f32);
   (void)hipFree(S.d_desc);
 }
 
@@ -1395,6 +1401,24 @@ static int sn_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, con
   std::vector<sn::BlockSym> BS((size_t)nblocks);
   std::vector<int> bad((size_t)nblocks, 0);
   std::vector<double> quick((size_t)nblocks, 0.0);
+  if (max_flops > 0.0 && nblocks > 1) {
+    // the largest block first, alone: when its first separator already says "a factor of four beyond the limit" the other blocks are
+    // not looked at (the callers run other host work beside this analysis: one busy thread instead of one per block)
+    int64_t bl = 0;
+    for (int64_t b = 1; b < nblocks; ++b)
+      if (block_ptr[b + 1] - block_ptr[b] > block_ptr[bl + 1] - block_ptr[bl]) bl = b;
+    const int64_t r0 = block_ptr[bl], r1 = block_ptr[bl + 1];
+    bool inside = true;
+    for (int64_t i = r0; i < r1 && inside; ++i)
+      for (int64_t k = rp[i]; k < rp[i + 1]; ++k)
+        if (ci[k] < r0 || ci[k] >= r1) inside = false;
+    if (inside) {
+      const double q = (lu ? 2.0 : 1.0) * sn::estimate_flops(chol::block_graph(rp, ci, r0, r1));
+      if (q * (double)nblocks > 4.0 * max_flops)
+        return fail(ctx, DDM_ENOTIMPL, "sparse direct solver: the factorisation needs about %.1g flops (estimate from the first separator of the largest block; limit %.3g)",
+                    q * (double)nblocks, max_flops);
+    }
+  }
   {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const int nthreads = (int)std::min<int64_t>(nblocks, hw);
@@ -1588,6 +1612,7 @@ extern "C" void ddm_ilu0_destroy(ddm_ilu0 *F)
   if (!F) return;
   if (F->graph) (void)hipGraphExecDestroy(F->graph);
   if (F->mgraph) (void)hipGraphExecDestroy(F->mgraph);
+  (void)hipFree(F->xf);
   if (F->err) (void)hipHostFree(F->err);
   delete F->sn;
   (void)hipFree(F->perm);
@@ -2055,13 +2080,56 @@ static void enqueue_multi_levels(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const doub
     }
   }
 }
-static int ilu0_solve_multi_ld(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double *D, int64_t ldd, double *X, int64_t ldx)
+// single-precision preconditioner sweeps of an ILU(0) factor (kernels.hpp: k_trsv_level_multi4_f32); D, X double
+static void enqueue_multi_levels_f32(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double *D, int64_t ldd, double *X, int64_t ldx)
+{
+  for (int pass = 0; pass < 2; ++pass) {
+    const TriSchedule &S = pass ? F->U : F->L;
+    for (int64_t l = 0; l < S.nlev; ++l) {
+      const LevelDesc &L = S.desc[l];
+      if (L.m == 0) continue;
+      const unsigned grid = (unsigned)(((int64_t)L.m * (nrhs / 4) + WG - 1) / WG);
+      if (pass)
+        hipLaunchKernelGGL(k_trsv_level_multi4_f32<true>, dim3(grid), dim3(WG), 0, ctx->stream, L.m, L.w, nrhs / 4, S.rows + L.row_off, S.cols + L.ent_off, S.vals_f32 + L.ent_off,
+                           S.dinv_f32 + L.row_off, D, ldd, F->xf, (int64_t)nrhs, X, ldx);
+      else
+        hipLaunchKernelGGL(k_trsv_level_multi4_f32<false>, dim3(grid), dim3(WG), 0, ctx->stream, L.m, L.w, nrhs / 4, S.rows + L.row_off, S.cols + L.ent_off, S.vals_f32 + L.ent_off,
+                           (const float *)nullptr, D, ldd, F->xf, (int64_t)nrhs, X, ldx);
+    }
+  }
+}
+static int ilu0_solve_multi_ld(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double *D, int64_t ldd, double *X, int64_t ldx, bool f32 = false)
 {
   if (!F || !D || !X || D == X || nrhs < 1 || ldd < nrhs || ldx < nrhs) return fail(ctx, DDM_EINVAL, "ddm_ilu0_solve_multi: bad arguments");
   if (F->n == 0) return DDM_OK;
-  if (F->mgraph && F->mg_D == D && F->mg_X == X && F->mg_nrhs == nrhs && F->mg_ldd == ldd && F->mg_ldx == ldx) {
+  // single precision only for plain ILU(0) factors on aligned blocks of a multiple of 4 columns without wide levels
+  f32 = f32 && !F->sn && !F->perm && nrhs % 4 == 0 && ldd % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)D & 31) == 0 && ((uintptr_t)X & 31) == 0;
+  if (f32)
+    for (const TriSchedule *S : {&F->L, &F->U})
+      for (const LevelDesc &L : S->desc) f32 = f32 && L.w < 96;
+  if (F->mgraph && F->mg_D == D && F->mg_X == X && F->mg_nrhs == nrhs && F->mg_ldd == ldd && F->mg_ldx == ldx && F->mg_f32 == f32) {
     HIPCHECK(ctx, hipGraphLaunch(F->mgraph, ctx->stream));
     return DDM_OK;
+  }
+  if (f32) {
+    for (TriSchedule *S : {&F->L, &F->U}) {
+      if (!S->vals_f32 && S->ell_entries > 0) {
+        HIPCHECK(ctx, hipMalloc((void **)&S->vals_f32, sizeof(float) * (size_t)S->ell_entries));
+        hipLaunchKernelGGL(k_to_float, dim3((unsigned)((S->ell_entries + 255) / 256)), dim3(256), 0, ctx->stream, S->ell_entries, (const double *)S->vals, S->vals_f32);
+      }
+      if (S == &F->U && !S->dinv_f32) {
+        HIPCHECK(ctx, hipMalloc((void **)&S->dinv_f32, sizeof(float) * (size_t)std::max<int64_t>(F->n, 1)));
+        hipLaunchKernelGGL(k_to_float, dim3((unsigned)((F->n + 255) / 256)), dim3(256), 0, ctx->stream, F->n, (const double *)S->dinv, S->dinv_f32);
+      }
+    }
+    if (F->xf_nrhs < nrhs) {
+      (void)hipFree(F->xf);
+      F->xf = nullptr;
+      F->xf_nrhs = 0;
+      HIPCHECK(ctx, hipMalloc((void **)&F->xf, sizeof(float) * (size_t)F->n * (size_t)nrhs));
+      F->xf_nrhs = nrhs;
+    }
+    HIPCHECK(ctx, hipGetLastError());
   }
   if (F->mgraph) {
     (void)hipGraphExecDestroy(F->mgraph);
@@ -2101,6 +2169,8 @@ static int ilu0_solve_multi_ld(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double
     enqueue_multi_levels_csr(ctx, F->Lc, false, nrhs, F->pD, nrhs, F->pX, nrhs);
     enqueue_multi_levels_csr(ctx, F->Uc, true, nrhs, F->pD, nrhs, F->pX, nrhs);
     hipLaunchKernelGGL(k_perm_scatter, dim3(grid_for(F->n * nrhs)), dim3(WG), 0, ctx->stream, F->n, nrhs, F->perm, (const double *)F->pX, X, ldx);
+  } else if (f32) {
+    enqueue_multi_levels_f32(ctx, F, nrhs, D, ldd, X, ldx);
   } else {
     enqueue_multi_levels(ctx, F, nrhs, D, ldd, X, ldx);
   }
@@ -2117,6 +2187,7 @@ static int ilu0_solve_multi_ld(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double
   F->mg_nrhs = nrhs;
   F->mg_ldd = ldd;
   F->mg_ldx = ldx;
+  F->mg_f32 = f32;
   HIPCHECK(ctx, hipGraphLaunch(F->mgraph, ctx->stream));
   return DDM_OK;
 }

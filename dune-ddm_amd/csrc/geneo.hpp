@@ -492,6 +492,9 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
     if (rc_ilu) return fail(ctx, rc_ilu, "%s", err_ilu.c_str());
     own.T = T_ilu;
   }
+  // ILU(0) as the preconditioner of the block iteration: single-precision sweeps (the iteration only needs a fixed search direction
+  // W = T r; eigenpairs and residuals are computed in double).  DDM_GENEO_ILU_F64=1 keeps the sweeps in double.
+  const bool prec_f32 = !direct && !std::getenv("DDM_GENEO_ILU_F64");
   const double t_prec = since(t_begin);
   DDMCHECK(csr_wait_upload(ctx, own.At));
   const double t_setup = since(t_begin);
@@ -570,7 +573,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
       HIPCHECK(ctx, hipMemcpyAsync(h_rr.data(), gmm[0], sizeof(double) * h_rr.size(), hipMemcpyDeviceToHost, ctx->stream));
       // (W = T r with the residual columns as they are: their scaling is folded into the projected problem below, like W's and P's)
       double *Wb = S[cur] + m, *AWb = AS[cur] + m, *CWb = CS[cur] + m;
-      DDMCHECK(ilu0_solve_multi_ld(ctx, own.T, m, R, m, Wb, ld));
+      DDMCHECK(ilu0_solve_multi_ld(ctx, own.T, m, R, m, Wb, ld, prec_f32));
       DDMCHECK(W.gram(R, m, m, Wb, ld, m, gmm[1]));   // r^T T r per column (diagonal)
       HIPCHECK(ctx, hipMemcpyAsync(h_rw.data(), gmm[1], sizeof(double) * h_rw.size(), hipMemcpyDeviceToHost, ctx->stream));
       if (con) DDMCHECK(harmonic_apply(ctx, con, m, Wb, ld, true));    // W = P T P^T r stays in the subspace

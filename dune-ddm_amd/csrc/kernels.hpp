@@ -223,6 +223,54 @@ __global__ __launch_bounds__(WG) void k_trsv_level_multi4(int m, int w, int nq /
   if (UPPER) s *= dinv[r];
   *reinterpret_cast<d4 *>(x + o) = s;
 }
+// SINGLE-PRECISION sweeps for uses where the triangular solve is a PRECONDITIONER inside an iteration that only needs a fixed, good
+// search direction (the block eigensolver of the GenEO setup: W = T r): factor entries and the work block in float -- half the bytes of
+// the gathered x rows, which is what the 24-column level solves are bound by -- right-hand side read and result written in double.
+// One thread per (row, 4 right-hand sides); xf: n x nrhs floats (ld = nrhs).
+__global__ void k_to_float(int64_t n, const double *__restrict__ src, float *__restrict__ dst)
+{
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t < n) dst[t] = (float)src[t];
+}
+template <bool UPPER>
+__global__ __launch_bounds__(WG) void k_trsv_level_multi4_f32(int m, int w, int nq /* nrhs / 4 */, const int32_t *__restrict__ rows, const int32_t *__restrict__ cols,
+                                                               const float *__restrict__ vals, const float *__restrict__ dinv, const double *__restrict__ d, int64_t ldd,
+                                                               float *xf, int64_t ldf, double *__restrict__ xout, int64_t ldx)
+{
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x;
+  const int r = (int)(t / nq);
+  if (r >= m) return;
+  const int j = 4 * (int)(t - (int64_t)r * nq);
+  const int64_t row = rows[r], o = row * ldf + j;
+  f4 s;
+  if (UPPER) s = *reinterpret_cast<const f4 *>(xf + o);
+  else {
+    const d4 dv = *reinterpret_cast<const d4 *>(d + row * ldd + j);
+    s = f4{(float)dv[0], (float)dv[1], (float)dv[2], (float)dv[3]};
+  }
+  for (int k0 = 0; k0 < w; k0 += TRSV_UNROLL) {
+    int32_t c[TRSV_UNROLL];
+    float v[TRSV_UNROLL];
+    f4 xv[TRSV_UNROLL];
+#pragma unroll
+    for (int u = 0; u < TRSV_UNROLL; ++u) {
+      const bool ok = k0 + u < w;
+      c[u] = ok ? cols[(int64_t)(k0 + u) * m + r] : -1;
+      v[u] = ok ? vals[(int64_t)(k0 + u) * m + r] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < TRSV_UNROLL; ++u) xv[u] = c[u] >= 0 ? *reinterpret_cast<const f4 *>(xf + (int64_t)c[u] * ldf + j) : f4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int u = 0; u < TRSV_UNROLL; ++u) s -= v[u] * xv[u];
+  }
+  if (UPPER) {
+    s *= dinv[r];
+    *reinterpret_cast<d4 *>(xout + row * ldx + j) = d4{(double)s[0], (double)s[1], (double)s[2], (double)s[3]};
+  }
+  *reinterpret_cast<f4 *>(xf + o) = s;
+}
 // The same for levels of WIDE rows (factors of the sparse direct solver: separator rows have thousands of entries and a
 // level often holds a single row): one workgroup per row, the 256 threads split the row's entries into 256 / nrhs slices
 // per right-hand side, slice sums meet in LDS and are added in slice order (deterministic).
