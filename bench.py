@@ -163,6 +163,7 @@ def main():
         tl = TwoLevelSchwarz(dec, rank, world, local_rank, comm, schwarz_type="standard", mode="additive", coarse=coarse, subdomain_solver=args.local_solver)
     tl.ctx.sync()
     t_dev = time.perf_counter() - t1 - (geneo_check["seconds"] if geneo_check else 0.0)
+    log(rank, "device setup phases (s): " + ", ".join(f"{k} {v:.2f}" for k, v in tl.setup_times.items()))
     log(rank, f"device setup (upload, ILU(0), level schedule, coarse space '{coarse}', R A R^T): {t_dev:.1f} s; "
               f"ILU levels L/U = {tl.schwarz_levels()}")
 

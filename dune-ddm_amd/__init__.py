@@ -78,6 +78,7 @@ SYMBOLS = {
     "ddm_csr_usmv": (_I32, [_P, _P, _D, _P, _P]),
     "ddm_csr_mm": (_I32, [_P, _P, _I32, _P, _P]),
     "ddm_ilu0_solve_multi": (_I32, [_P, _P, _I32, _P, _P]),
+    "ddm_ilu0_solve_multi_f32": (_I32, [_P, _P, _I32, _P, _P]),
     "ddm_ilu0_create": (_I32, [_P, _P, _I64, _P, _PP]),
     "ddm_ilu0_destroy": (None, [_P]),
     "ddm_ilu0_solve": (_I32, [_P, _P, _P, _P]),
@@ -384,10 +385,11 @@ class Ilu0:
     def solve(self, d, x):
         self.ctx.check(self.ctx.lib.ddm_ilu0_solve(self.ctx.h, self.h, _ptr(d), _ptr(x)))
 
-    def solve_multi(self, D, X):
-        """X = (LU)^-1 D for row-major (n, nrhs) device tensors"""
+    def solve_multi(self, D, X, single_precision=False):
+        """X = (LU)^-1 D for row-major (n, nrhs) device tensors; single_precision: float sweeps (preconditioner grade)"""
         assert D.shape == X.shape and D.is_contiguous() and X.is_contiguous()
-        self.ctx.check(self.ctx.lib.ddm_ilu0_solve_multi(self.ctx.h, self.h, int(D.shape[1]), _ptr(D), _ptr(X)))
+        fn = self.ctx.lib.ddm_ilu0_solve_multi_f32 if single_precision else self.ctx.lib.ddm_ilu0_solve_multi
+        self.ctx.check(fn(self.ctx.h, self.h, int(D.shape[1]), _ptr(D), _ptr(X)))
 
     def num_levels(self, upper=False):
         return int(self.ctx.lib.ddm_ilu0_num_levels(self.h, int(upper)))

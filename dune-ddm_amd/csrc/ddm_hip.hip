@@ -793,11 +793,21 @@ static int build_schedule(ddm_ctx *ctx, const ddm_csr *A, const hvec<double> &lu
     ent += m * (int64_t)w;
   }
   S.ell_entries = ent;
-  std::vector<int32_t> cols((size_t)std::max<int64_t>(ent, 1));
-  std::vector<double> vals((size_t)std::max<int64_t>(ent, 1));
-  std::vector<double> dinv;
+  hvec<int32_t> cols((size_t)std::max<int64_t>(ent, 1));
+  hvec<double> vals((size_t)std::max<int64_t>(ent, 1));
+  hvec<double> dinv;
   if (upper) dinv.resize(n);
-  for (int64_t l = 0; l < nlev; ++l) {
+  // the sliced-ELL fill (strided writes, 1.8 GB per triangle at 216^3) on several threads: levels are independent, each thread takes a
+  // run of consecutive levels with about the same number of entries (the two triangles are built at the same time: half the cores each)
+  const int nfill = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::max(1u, std::thread::hardware_concurrency() / 2), nlev, ent / (1 << 20) + 1}));
+  std::vector<int64_t> cut((size_t)nfill + 1, nlev);
+  cut[0] = 0;
+  for (int t = 1, l = 0; t < nfill; ++t) {
+    while (l < nlev && S.desc[l].ent_off < ent * t / nfill) ++l;
+    cut[(size_t)t] = l;
+  }
+  auto fill = [&](int64_t l0, int64_t l1) {
+  for (int64_t l = l0; l < l1; ++l) {
     const LevelDesc &D = S.desc[l];
     for (int64_t r = 0; r < D.m; ++r) {
       const int64_t i = rows[D.row_off + r];
@@ -814,6 +824,13 @@ static int build_schedule(ddm_ctx *ctx, const ddm_csr *A, const hvec<double> &lu
       }
       if (upper) dinv[D.row_off + r] = lu[diag[i]];
     }
+  }
+  };
+  if (nfill <= 1) fill(0, nlev);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nfill; ++t) th.emplace_back(fill, cut[(size_t)t], cut[(size_t)t + 1]);
+    for (auto &t : th) t.join();
   }
   // launch plan: runs of small levels share one single-workgroup launch
   int l = 0;
@@ -1219,6 +1236,8 @@ static int ilu0_create_impl(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, con
   if (!ctx || !A || !out || nblocks < 1 || !block_ptr) return fail(ctx, DDM_EINVAL, "ddm_ilu0_create: bad arguments");
   if (A->nrows != A->ncols) return fail(ctx, DDM_EINVAL, "ILU(0) needs a square matrix");
   if (block_ptr[0] != 0 || block_ptr[nblocks] != A->nrows) return fail(ctx, DDM_EINVAL, "block_ptr does not cover the matrix");
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); };
   ddm_ilu0 *F = new ddm_ilu0;
   F->n = A->nrows;
   F->nnz = A->nnz;
@@ -1244,11 +1263,15 @@ static int ilu0_create_impl(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, con
       if (rc == -3) return fail(ctx, DDM_EINVAL, "ILU(0): rows must have sorted column indices");
       return fail(ctx, DDM_ENUMERIC, "ILU(0): missing or zero pivot in block %lld", (long long)b);
     }
+  const double t_factor = since();
   const int rc = ilu0_build_engines(ctx, F, A, diag, nblocks, block_ptr, multi_rhs_only);
   if (rc) {
     ddm_ilu0_destroy(F);
     return rc;
   }
+  if (std::getenv("DDM_PIPE_VERBOSE"))
+    std::fprintf(stderr, "[ddm] ILU(0) setup: %lld rows, factorisation (host, one thread per block) %.2f s, level schedules%s %.2f s\n", (long long)F->n, t_factor,
+                 multi_rhs_only ? "" : " + single-launch engine", since() - t_factor);
   *out = F;
   return DDM_OK;
 }
@@ -2192,6 +2215,10 @@ static int ilu0_solve_multi_ld(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double
   return DDM_OK;
 }
 extern "C" int ddm_ilu0_solve_multi(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double *D, double *X) { return ilu0_solve_multi_ld(ctx, F, nrhs, D, nrhs, X, nrhs); }
+// the same solve with SINGLE-PRECISION sweeps (factor entries and work block in float, D read and X written in double): preconditioner
+// grade -- what the GenEO block iteration applies.  Falls back to the double sweeps when nrhs is not a multiple of 4 or F is a sparse
+// direct factor.
+extern "C" int ddm_ilu0_solve_multi_f32(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double *D, double *X) { return ilu0_solve_multi_ld(ctx, F, nrhs, D, nrhs, X, nrhs, true); }
 
 // ---- halo --------------------------------------------------------------------------------------
 struct ddm_halo {

@@ -128,7 +128,17 @@ class TwoLevelSchwarz:
                 assert comm is not None
                 self.ctx.set_comm(rank, nranks, comm.alltoall, comm.allreduce)
                 self.exchange = "callback"
+        import time
+        self.setup_times = {}                                          # seconds per phase of the device setup (diagnostics: bench.py logs them)
+        _t = [time.perf_counter()]
+
+        def lap(name):
+            now = time.perf_counter()
+            self.setup_times[name] = self.setup_times.get(name, 0.0) + now - _t[0]
+            _t[0] = now
+        self._lap = lap
         rl = self.rl = RankLocal(dec, rank, nranks)
+        lap("rank-local numbering")
         ctx = self.ctx
         if comm is not None and comm.backend != "nccl":
             # gloo rehearsal: several ranks share one GPU.  The single-launch triangular solves need all
@@ -136,6 +146,7 @@ class TwoLevelSchwarz:
             os.environ["DDM_TRSV_MODE"] = "levels"
         self.A = CsrMatrix(ctx, rl.A)
         self.A_dir = CsrMatrix(ctx, rl.A_dir)
+        lap("matrix upload (A, A_dir)")
         self.h_novlp = Halo(ctx, 1, Halo.ADD, rl.plan_novlp_add)
         self.h_copy = Halo(ctx, 2, Halo.COPY, rl.plan_ovlp_copy)
         self.h_add = Halo(ctx, 3, Halo.ADD, rl.plan_ovlp_add)
@@ -146,6 +157,7 @@ class TwoLevelSchwarz:
         self.schwarz = SchwarzPreconditioner(ctx, self.A_dir, rl.block_ptr, rl.n_o, rl.ext_map,
                                              rl.pou if use_pou_in_schwarz else None, schwarz_type, self.h_copy, self.h_add,
                                              subdomain_solver=subdomain_solver)   # [schwarz.subdomain_solver] type (schwarz.hh:85-92)
+        lap("halo plans, operator, local solver (factorisation, schedules)")
         self.galerkin = None
         self.a0 = None
         if coarse is not None and coarse != "none":
@@ -187,11 +199,16 @@ class TwoLevelSchwarz:
             basis[:k_all[s], rl.off[s]:rl.off[s] + dec.subs[s].n] = basis_by_sub[s]
             coarse_index[li, :k_all[s]] = offset[s] + np.arange(k_all[s])
         self.k_all, self.coarse_offset, self.K = k_all, offset, K
+        import time
+        t0 = time.perf_counter()
         A0 = self._build_coarse_matrix(basis, k_all, offset, K)
+        t1 = time.perf_counter()
         self.a0 = A0
         a0inv = np.linalg.inv(A0)
         self.galerkin = GalerkinPreconditioner(self.ctx, rl.n, rl.n_o, rl.ext_map, rl.block_ptr, basis, coarse_index.reshape(-1),
                                                a0inv, self.h_copy, self.h_add)
+        self.setup_times["coarse matrix R A R^T"] = t1 - t0
+        self.setup_times["coarse inverse, basis upload"] = time.perf_counter() - t1
 
     def _allgather_small(self, local: dict, P):
         if self.comm is None:

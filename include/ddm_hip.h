@@ -108,6 +108,10 @@ int ddm_ilu0_solve(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x);
 /* X = (LU)^-1 D for row-major n x nrhs block vectors (cf. the reference's multi-RHS triangular
  * solve eigensolvers/umfpack.hh:131-197); D and X must not alias */
 int ddm_ilu0_solve_multi(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double *D, double *X);
+/* the same with SINGLE-PRECISION sweeps (factor entries and the work block in float; D is read and X written in double): preconditioner
+ * grade, relative error ~1e-6 x the growth of the triangular solves -- what the GenEO block iteration applies as W = T r (its eigenpairs
+ * and residuals are computed in double).  nrhs % 4 != 0 or a sparse direct factor: the double sweeps. */
+int ddm_ilu0_solve_multi_f32(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double *D, double *X);
 int64_t ddm_ilu0_num_levels(const ddm_ilu0 *F, int upper);
 /* status of the persistent (single-launch) triangular solve: 0 ok, 1 = a wave timed out waiting for a
  * dependency level (results invalid).  Synchronous.  DDM_TRSV_MODE=levels selects one launch per level. */

@@ -17,6 +17,38 @@ def _sin_largest_angle(U, V):
     return float(np.linalg.norm(Qu - Qv @ (Qv.T @ Qu), 2))
 
 
+@pytest.mark.parametrize("m", [24, 8, 6])
+def test_multi_rhs_single_precision_sweeps(ddm, m):
+    """ddm_ilu0_solve_multi_f32 (the GenEO block iteration's preconditioner application: float factor entries and work block, double
+    in / out) against the double solve on 4 independent blocks: relative error of single precision times the growth of the two
+    sweeps (here < 2e-5 of the column's largest entry); m = 6 is not a multiple of 4 and must give the double result bit for bit;
+    repeated calls (graph replay) give identical results."""
+    import torch
+    from dune_ddm_amd import synth
+    import scipy.sparse as sp
+    ctx = ddm.torch_context(0)
+    M1 = synth.StructuredPoisson((14, 12, 11), (1, 1, 1)).subdomain(0).A
+    M = sp.block_diag([M1] * 4, format="csr")
+    n1 = M1.shape[0]
+    A = ddm.CsrMatrix(ctx, M)
+    F = ddm.Ilu0(ctx, A, block_ptr=[0, n1, 2 * n1, 3 * n1, 4 * n1])
+    rng = np.random.default_rng(5)
+    D = torch.as_tensor(rng.standard_normal((4 * n1, m))).cuda()
+    X64, X32, X32b = torch.empty_like(D), torch.empty_like(D), torch.empty_like(D)
+    F.solve_multi(D, X64)
+    F.solve_multi(D, X32, single_precision=True)
+    F.solve_multi(D, X32, single_precision=True)          # replay of the captured graph
+    F.solve_multi(D, X32b, single_precision=True)         # other output block: new capture
+    ctx.sync()
+    assert torch.equal(X32, X32b)
+    if m % 4:
+        assert torch.equal(X32, X64)
+    else:
+        err = (X32 - X64).abs().max(dim=0).values / X64.abs().max(dim=0).values
+        assert not torch.equal(X32, X64) and float(err.max()) < 2e-5, err
+    ctx.close()
+
+
 @pytest.mark.parametrize("m", [7, 8, 24])
 def test_multi_rhs_kernels(ddm, m):
     """ddm_csr_mm and ddm_ilu0_solve_multi == column-by-column single-vector kernels (bit-exact: same order); m = 8, 24 take the
