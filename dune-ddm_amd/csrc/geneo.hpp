@@ -93,8 +93,19 @@ struct GeneoWork {
   {
     const int64_t pp = (int64_t)pu * pv;
     if (pu <= 32 && pv <= 32) {
-      if (U == V && ldu == ldv && pu == pv) hipLaunchKernelGGL((k_gram_small<true>), dim3(nchunk), dim3(256), 0, ctx->stream, chunks, U, ldu, pu, V, ldv, pv, partial, pp, pv);
-      else hipLaunchKernelGGL((k_gram_small<false>), dim3(nchunk), dim3(256), 0, ctx->stream, chunks, U, ldu, pu, V, ldv, pv, partial, pp, pv);
+      const bool same = U == V && ldu == ldv && pu == pv;
+#define DDM_GRAM_SMALL(SAME, A1, B1) hipLaunchKernelGGL((k_gram_small<SAME, A1, B1>), dim3(nchunk), dim3(256), 0, ctx->stream, chunks, U, ldu, pu, V, ldv, pv, partial, pp, pv)
+      if (same) {
+        if (pu > 16) DDM_GRAM_SMALL(true, true, true);
+        else DDM_GRAM_SMALL(true, false, false);
+      } else if (pu > 16) {
+        if (pv > 16) DDM_GRAM_SMALL(false, true, true);
+        else DDM_GRAM_SMALL(false, true, false);
+      } else {
+        if (pv > 16) DDM_GRAM_SMALL(false, false, true);
+        else DDM_GRAM_SMALL(false, false, false);
+      }
+#undef DDM_GRAM_SMALL
     } else if (pu <= 128 && pv <= 80)
       hipLaunchKernelGGL((k_gram_mfma<2, 5>), dim3(nchunk), dim3(256), 0, ctx->stream, chunks, U, ldu, pu, V, ldv, pv, partial, pp, pv, 0, 0);
     else if (pu <= 144 && pv <= 144)
@@ -119,7 +130,13 @@ struct GeneoWork {
       (void)gram(U, ldu, p, V2, ldv, p, G2);
       return false;
     }
-    hipLaunchKernelGGL(k_gram2_sym, dim3(nchunk), dim3(256), 0, ctx->stream, chunks, U, ldu, V1, V2, ldv, p, partial);
+    switch ((p + 15) >> 4) {
+    case 1: hipLaunchKernelGGL(k_gram2_sym<1>, dim3(nchunk), dim3(256), 0, ctx->stream, chunks, U, ldu, V1, V2, ldv, p, partial); break;
+    case 2: hipLaunchKernelGGL(k_gram2_sym<2>, dim3(nchunk), dim3(256), 0, ctx->stream, chunks, U, ldu, V1, V2, ldv, p, partial); break;
+    case 3: hipLaunchKernelGGL(k_gram2_sym<3>, dim3(nchunk), dim3(256), 0, ctx->stream, chunks, U, ldu, V1, V2, ldv, p, partial); break;
+    case 4: hipLaunchKernelGGL(k_gram2_sym<4>, dim3(nchunk), dim3(256), 0, ctx->stream, chunks, U, ldu, V1, V2, ldv, p, partial); break;
+    default: hipLaunchKernelGGL(k_gram2_sym<5>, dim3(nchunk), dim3(256), 0, ctx->stream, chunks, U, ldu, V1, V2, ldv, p, partial); break;
+    }
     hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((nsub * pp + 255) / 256)), dim3(256), 0, ctx->stream, nsub, sub_chunk_ptr, pp, (const double *)partial, 2 * pp, G1);
     hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((nsub * pp + 255) / 256)), dim3(256), 0, ctx->stream, nsub, sub_chunk_ptr, pp, (const double *)(partial + pp), 2 * pp, G2);
     return true;
@@ -149,10 +166,18 @@ struct GeneoWork {
         const int mode = k0 == 0 ? (Base ? 1 : 0) : (Base ? 2 : 3);
         const int p4 = (kk + 3) & ~3, q16 = ((qq + 15) >> 4) << 4;
         const size_t lds = sizeof(double) * ((size_t)p4 * q16 + 4 * 16 * (size_t)(p4 + 1));
-        if (16 * p4 <= 20 * 64)
-          hipLaunchKernelGGL((k_rotate_mfma<20>), dim3(nchunk, narr), dim3(256), lds, ctx->stream, chunks, a, ldu, kk, Y, qq, ldo, ldb, gap_from, gap, q, pk, k0, j0, mode);
-        else
-          hipLaunchKernelGGL((k_rotate_mfma<0>), dim3(nchunk, narr), dim3(256), lds, ctx->stream, chunks, a, ldu, kk, Y, qq, ldo, ldb, gap_from, gap, q, pk, k0, j0, mode);
+#define DDM_ROTATE(PRE, TQ) hipLaunchKernelGGL((k_rotate_mfma<PRE, TQ>), dim3(nchunk, narr), dim3(256), lds, ctx->stream, chunks, a, ldu, kk, Y, qq, ldo, ldb, gap_from, gap, q, pk, k0, j0, mode)
+        const int tq = q16 >> 4;
+        if (16 * p4 <= 20 * 64) {
+          if (tq == 1) DDM_ROTATE(20, 1);
+          else if (tq == 2) DDM_ROTATE(20, 2);
+          else DDM_ROTATE(20, 3);
+        } else {
+          if (tq == 1) DDM_ROTATE(0, 1);
+          else if (tq == 2) DDM_ROTATE(0, 2);
+          else DDM_ROTATE(0, 3);
+        }
+#undef DDM_ROTATE
       }
     }
     HIPCHECK(ctx, hipGetLastError());

@@ -14,6 +14,13 @@ namespace ddm {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// Guarded operand loads select their ADDRESS, not their result: an element outside the block is read from this page of zeros.  A load
+// inside a conditional compiles to a branch around it (and a basic block per load); a select on the loaded VALUE puts a VALU
+// instruction behind every load, which the compiler then waits for right there -- both break the software pipelines below.
+// (NOT const: a constant-address-space object would make the selected pointer generic and the loads flat_load, which complete out of
+// order and force full waits)
+__device__ double ddm_zero_page[16];
+
 struct GChunk { // a run of rows inside ONE subdomain
   int64_t r0, r1;
   int32_t sub, pad;
@@ -90,15 +97,15 @@ __global__ __launch_bounds__(256) void k_gram_mfma(const GChunk *__restrict__ ch
 // splits the ROWS of the chunk over the four wavefronts (32 rows = 8 slabs per wavefront and trip, 16..32 loads in flight), every
 // wavefront accumulates all (at most 2 x 2) tiles, and the four partial results meet in LDS in wavefront order (deterministic).
 // SAME: U and V are the same block (column norms, R^T R): the A operand doubles as the B operand, nothing is loaded twice.
-template <bool SAME>
+template <bool SAME, bool A1, bool B1> // A1 / B1: a second 16-column tile of U / V (pu > 16, pv > 16), compile-time: the accumulators keep their registers
 __global__ __launch_bounds__(256) void k_gram_small(const GChunk *__restrict__ chunks, const double *__restrict__ U, int64_t ldu, int pu,
                                                    const double *__restrict__ V, int64_t ldv, int pv, double *__restrict__ partial, int64_t out_stride, int out_ld)
 {
   __shared__ double red[4][4][256];
   const GChunk c = chunks[blockIdx.x];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lc = lane & 15, lr = lane >> 4;
-  const bool a1 = pu > 16, b1 = pv > 16;
+  constexpr bool a1 = A1, b1 = B1;
   v4d acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -111,11 +118,11 @@ __global__ __launch_bounds__(256) void k_gram_small(const GChunk *__restrict__ c
     for (int g = 0; g < GU; ++g) {
       const int64_t row = r + 4 * g + lr;
       const bool rok = row < c.r1;
-      av[g][0] = (rok && lc < pu) ? U[row * ldu + lc] : 0.0;
-      av[g][1] = (rok && a1 && 16 + lc < pu) ? U[row * ldu + 16 + lc] : 0.0;
+      av[g][0] = *((rok && lc < pu) ? U + row * ldu + lc : ddm_zero_page);
+      av[g][1] = a1 ? *((rok && 16 + lc < pu) ? U + row * ldu + 16 + lc : ddm_zero_page) : 0.0;
       if (!SAME) {
-        bv[g][0] = (rok && lc < pv) ? V[row * ldv + lc] : 0.0;
-        bv[g][1] = (rok && b1 && 16 + lc < pv) ? V[row * ldv + 16 + lc] : 0.0;
+        bv[g][0] = *((rok && lc < pv) ? V + row * ldv + lc : ddm_zero_page);
+        bv[g][1] = b1 ? *((rok && 16 + lc < pv) ? V + row * ldv + 16 + lc : ddm_zero_page) : 0.0;
       }
     }
 #pragma unroll
@@ -171,14 +178,14 @@ struct Gram2Group<3> {
   static constexpr int NA = 2, NB = 2, NT = 3;
   static constexpr int AL[2] = {3, 4}, BL[4] = {3, 4, 4, 4}, TA[4] = {0, 0, 1, 1}, TB[4] = {0, 1, 1, 1};
 };
-template <int G>
+template <int G, int TN> // TN = tiles per side = ceil(p / 16), compile-time
 __device__ __forceinline__ void gram2_sym_group(const GChunk c, const double *__restrict__ U, int64_t ldu, const double *__restrict__ V1, const double *__restrict__ V2,
                                                 int64_t ldv, int p, double *__restrict__ out1, double *__restrict__ out2)
 {
   using GG = Gram2Group<G>;
   constexpr int GU = 2; // 4-row slabs per buffer
   const int lane = threadIdx.x & 63, lc = lane & 15, lr = lane >> 4;
-  const int tn = (p + 15) >> 4;
+  constexpr int tn = TN;
   v4d acc1[GG::NT], acc2[GG::NT];
 #pragma unroll
   for (int t = 0; t < GG::NT; ++t) acc1[t] = acc2[t] = v4d{0.0, 0.0, 0.0, 0.0};
@@ -191,14 +198,14 @@ __device__ __forceinline__ void gram2_sym_group(const GChunk c, const double *__
 #pragma unroll
       for (int i = 0; i < GG::NA; ++i) {
         const int col = (GG::AL[i] << 4) + lc;
-        a[g][i] = (rok && col < p) ? U[row * ldu + col] : 0.0;
+        a[g][i] = *((rok && col < p) ? U + row * ldu + col : ddm_zero_page);
       }
 #pragma unroll
       for (int i = 0; i < GG::NB; ++i) {
         const int col = (GG::BL[i] << 4) + lc;
         const bool ok = rok && col < p;
-        b[g][i] = ok ? V1[row * ldv + col] : 0.0;
-        cc[g][i] = ok ? V2[row * ldv + col] : 0.0;
+        b[g][i] = *(ok ? V1 + row * ldv + col : ddm_zero_page);
+        cc[g][i] = *(ok ? V2 + row * ldv + col : ddm_zero_page);
       }
     }
   };
@@ -235,17 +242,18 @@ __device__ __forceinline__ void gram2_sym_group(const GChunk c, const double *__
   }
 }
 // partial: per chunk two p x p matrices (stride 2 p p)
+template <int TN>
 __global__ __launch_bounds__(256) void k_gram2_sym(const GChunk *__restrict__ chunks, const double *__restrict__ U, int64_t ldu, const double *__restrict__ V1,
                                                   const double *__restrict__ V2, int64_t ldv, int p, double *__restrict__ partial)
 {
   const GChunk c = chunks[blockIdx.x];
   const int64_t pp = (int64_t)p * p;
   double *out1 = partial + (int64_t)blockIdx.x * 2 * pp, *out2 = out1 + pp;
-  switch (((threadIdx.x >> 6) + blockIdx.x) & 3) { // wave-uniform
-  case 0: gram2_sym_group<0>(c, U, ldu, V1, V2, ldv, p, out1, out2); break;
-  case 1: gram2_sym_group<1>(c, U, ldu, V1, V2, ldv, p, out1, out2); break;
-  case 2: gram2_sym_group<2>(c, U, ldu, V1, V2, ldv, p, out1, out2); break;
-  default: gram2_sym_group<3>(c, U, ldu, V1, V2, ldv, p, out1, out2); break;
+  switch (__builtin_amdgcn_readfirstlane(((threadIdx.x >> 6) + blockIdx.x) & 3)) { // wave-uniform
+  case 0: gram2_sym_group<0, TN>(c, U, ldu, V1, V2, ldv, p, out1, out2); break;
+  case 1: gram2_sym_group<1, TN>(c, U, ldu, V1, V2, ldv, p, out1, out2); break;
+  case 2: gram2_sym_group<2, TN>(c, U, ldu, V1, V2, ldv, p, out1, out2); break;
+  default: gram2_sym_group<3, TN>(c, U, ldu, V1, V2, ldv, p, out1, out2); break;
   }
 }
 
@@ -282,7 +290,9 @@ struct RotArgs {
 constexpr int ROT_TQ = 3; // q <= 48
 // Output columns j >= gap_from are written `gap` columns further right (the fused Rayleigh-Ritz rotation writes X_new to the X slot
 // and P_new straight into the P slot, two slots further: no copy kernel behind it).
-template <int ROT_PRE> // registers per lane for the prefetched slab: 20 (p <= 80), or 0 = row-by-row staging without prefetch (any p <= 144)
+// TQ = 16-column output tiles of this launch (ceil(q / 16) <= ROT_TQ), compile-time: with a run-time tile count the compiler keeps ONE
+// accumulator in the matrix-core registers and moves the others in and out around every MFMA
+template <int ROT_PRE, int TQ> // ROT_PRE: registers per lane for a prefetched slab: 20 (p <= 80), or 0 = row-by-row staging without prefetch (any p <= 144)
 __global__ __launch_bounds__(256) void k_rotate_mfma(const GChunk *__restrict__ chunks, RotArgs args, int64_t ldu, int p, const double *__restrict__ Yall,
                                                     int q, int64_t ldo, int64_t ldb, int gap_from, int gap, int y_ld, int y_rows, int y_k0, int y_j0, int mode)
 {
@@ -298,7 +308,7 @@ __global__ __launch_bounds__(256) void k_rotate_mfma(const GChunk *__restrict__ 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lc = lane & 15, lr = lane >> 4;
   const int p4 = (p + 3) & ~3;              // k extent padded to the MFMA step
-  const int q16 = ((q + 15) >> 4) << 4;     // columns of Y padded to whole tiles
+  constexpr int q16 = 16 * TQ;              // columns of Y padded to whole tiles
   double *Ys = lds;                          // p4 x q16
   const int ustride = p4 + 1;                // odd stride: the 16 rows of an A operand fall into different banks
   double *Us = lds + (int64_t)p4 * q16 + (int64_t)wave * 16 * ustride;
@@ -308,7 +318,6 @@ __global__ __launch_bounds__(256) void k_rotate_mfma(const GChunk *__restrict__ 
     Ys[t] = (k < p && j < q) ? Y[(int64_t)(y_k0 + k) * y_ld + y_j0 + j] : 0.0;
   }
   __syncthreads();
-  const int tq_n = q16 >> 4;
   // The 16 x p4 slab of U is read as ONE flat run of 16 p4 elements (contiguous in memory when ldu == p: full 512-byte loads), and the
   // slabs of the next TWO trips are on their way into registers while the matrix cores work on the current one: the workgroup's
   // LDS (Y + four staging slabs) allows two workgroups per CU, i.e. two wavefronts per SIMD, and the 54 MFMAs of a slab (1.4 us) are
@@ -324,7 +333,7 @@ __global__ __launch_bounds__(256) void k_rotate_mfma(const GChunk *__restrict__ 
       const int idx = lane + (u << 6);
       const int i = idx / p4, k = idx - i * p4;
       const int64_t row = r0s + i;
-      dst[u] = (idx < nel && row < c.r1 && k < p) ? U[row * ldu + k] : 0.0;
+      dst[u] = *((idx < nel && row < c.r1 && k < p) ? U + row * ldu + k : ddm_zero_page);
     }
   };
   auto process = [&](const double(&src)[NPRE], int64_t r0) __attribute__((always_inline)) {
@@ -347,18 +356,20 @@ __global__ __launch_bounds__(256) void k_rotate_mfma(const GChunk *__restrict__ 
     // (the prefetched slabs stay in flight) and the barrier keeps the compiler from moving the reads up
     __builtin_amdgcn_s_waitcnt(ROT_PRE > 0 ? 0xC07F : 0);
     __builtin_amdgcn_wave_barrier();
-    v4d acc[ROT_TQ];
+    v4d acc[TQ];
 #pragma unroll
-    for (int t = 0; t < ROT_TQ; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+    for (int t = 0; t < TQ; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+    const double *ua = Us + lc * ustride + lr, *yb = Ys + lr * q16 + lc;
     for (int k0 = 0; k0 < p4; k0 += 4) {
-      const double a = Us[lc * ustride + k0 + lr];
+      const double a = ua[k0];
+      double b[TQ];
 #pragma unroll
-      for (int t = 0; t < ROT_TQ; ++t)
-        if (t < tq_n) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Ys[(k0 + lr) * q16 + (t << 4) + lc], acc[t], 0, 0, 0);
+      for (int t = 0; t < TQ; ++t) b[t] = yb[k0 * q16 + (t << 4)];
+#pragma unroll
+      for (int t = 0; t < TQ; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[t], acc[t], 0, 0, 0);
     }
 #pragma unroll
-    for (int t = 0; t < ROT_TQ; ++t) {
-      if (t >= tq_n) continue;
+    for (int t = 0; t < TQ; ++t) {
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         const int64_t row = r0 + lr + 4 * v;
