@@ -2681,8 +2681,11 @@ extern "C" int ddm_galerkin_products(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t
   int64_t *d_cidx = nullptr;
   if (!rc) rc = upload(ctx, scp.data(), 2, &d_scp);
   for (int64_t j = 0; j < nright && !rc; ++j) {
-    rc = ddm_csr_mv(ctx, A_dir, right + j * n, y);
-    if (rc) break;
+    // y[row0:row1) = (A_dir right_j)[row0:row1): only the rows the products below read (a whole-matrix product per vector and call
+    // was 1 s of the headline setup: 1 280 passes over 3.5 GB); same row sums in the same order as ddm_csr_mv
+    if (row1 > row0)
+      hipLaunchKernelGGL(k_spmm_rowmajor, dim3((unsigned)((row1 - row0 + WG - 1) / WG)), dim3(WG), 0, ctx->stream, row1 - row0, 1, A_dir->rp + row0, A_dir->ci, A_dir->va,
+                         right + j * n, (int64_t)1, y + row0, (int64_t)1);
     for (int64_t i = 0; i < nleft; ++i) cidx[i] = i;
     if (!d_cidx) rc = upload(ctx, cidx.data(), nleft, &d_cidx);
     if (rc) break;
