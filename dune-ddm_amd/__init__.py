@@ -77,6 +77,7 @@ SYMBOLS = {
     "ddm_csr_mv": (_I32, [_P, _P, _P, _P]),
     "ddm_csr_usmv": (_I32, [_P, _P, _D, _P, _P]),
     "ddm_csr_mm": (_I32, [_P, _P, _I32, _P, _P]),
+    "ddm_csr_row_order_tiled_host": (_I32, [_I64, _P, _P, _P, _P]),
     "ddm_ilu0_solve_multi": (_I32, [_P, _P, _I32, _P, _P]),
     "ddm_ilu0_solve_multi_f32": (_I32, [_P, _P, _I32, _P, _P]),
     "ddm_ilu0_create": (_I32, [_P, _P, _I64, _P, _PP]),
@@ -662,6 +663,19 @@ class HarmonicExtension:
             self.h = None
 
     __del__ = close
+
+
+def row_order_tiled_host(block_ptr, A):
+    """(found, order): the cache-blocked row order of the block products for a scipy CSR matrix (host only, no device needed)"""
+    lib = load_library()
+    bp = _np(block_ptr, np.int64)
+    rp = _np(A.indptr, np.int64)
+    ci = _np(A.indices, np.int32)
+    order = np.empty(A.shape[0], dtype=np.int32)
+    rc = lib.ddm_csr_row_order_tiled_host(len(bp) - 1, _hp(bp), _hp(rp), _hp(ci), _hp(order))
+    if rc < 0:
+        raise ValueError("ddm_csr_row_order_tiled_host: bad arguments")
+    return bool(rc), order
 
 
 def blockvec_gram(ctx: Context, sub_ptr, U, V):

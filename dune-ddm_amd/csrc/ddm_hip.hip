@@ -436,6 +436,7 @@ struct ddm_csr {
   int32_t *blk_row = nullptr;
   int nblk = 0;
   bool borrowed_pattern = false; // rp / ci / blk_row belong to another ddm_csr (values-only companion on the same pattern)
+  int32_t *row_order = nullptr;  // cache-blocked processing order of the rows for the block products (csr_row_order_tiled), or null
   std::thread uploader;          // device copies still in flight (csr_adopt): csr_wait_upload joins it
   int upload_rc = 0;
   std::string upload_err;
@@ -476,6 +477,7 @@ extern "C" void ddm_csr_destroy(ddm_csr *A)
 {
   if (!A) return;
   if (A->uploader.joinable()) A->uploader.join();
+  (void)hipFree(A->row_order);
   if (!A->borrowed_pattern) {
     (void)hipFree(A->rp);
     (void)hipFree(A->ci);
@@ -511,7 +513,83 @@ static int csr_wait_upload(ddm_ctx *ctx, const ddm_csr *A)
   if (M->upload_rc) return fail(ctx, M->upload_rc, "%s", M->upload_err.c_str());
   return DDM_OK;
 }
-static ddm_csr *csr_adopt(ddm_ctx *ctx, int64_t n, hvec<int64_t> &&rp, hvec<int32_t> &&ci, hvec<double> &&va, hvec<double> &&companion_values, ddm_csr **companion)
+// Cache-blocked processing order of the rows of a block-diagonal matrix whose blocks come from a STRUCTURED grid in lexicographic
+// numbering (possibly followed by irregularly numbered rows, e.g. an overlap shell): the strides s2 (one grid line) and s3 (one grid
+// plane) are read off the column offsets that most rows share; rows are then visited brick by brick (16 x 4 x 4 points, bricks in
+// lexicographic order), rows that fit no brick keep their place at the end.  Purely a performance hint -- any permutation is valid.
+// Returns false (order untouched) when no such structure is found.
+static bool csr_row_order_tiled(int64_t nblocks, const int64_t *block_ptr, const int64_t *rp, const int32_t *ci, std::vector<int32_t> &order)
+{
+  const int64_t n = block_ptr[nblocks];
+  order.resize((size_t)n);
+  std::vector<uint8_t> seen((size_t)n, 0);
+  int64_t out = 0;
+  bool any = false;
+  for (int64_t b = 0; b < nblocks; ++b) {
+    const int64_t r0 = block_ptr[b], r1 = block_ptr[b + 1], nb = r1 - r0;
+    int64_t s2 = 0, s3 = 0;
+    if (nb >= 4096) { // positive column offsets shared by most of a sample of rows from the first half of the block
+      std::map<int64_t, int> hist;
+      const int64_t sample = 2048, start = r0 + nb / 4;
+      for (int64_t i = start; i < start + sample; ++i)
+        for (int64_t k = rp[i]; k < rp[i + 1]; ++k)
+          if (ci[k] > i) hist[ci[k] - i]++;
+      std::vector<int64_t> P;
+      for (auto &kv : hist)
+        if (kv.second > sample / 2) P.push_back(kv.first);
+      auto has = [&](int64_t o) { return std::binary_search(P.begin(), P.end(), o); };
+      // 5- / 7-point stencils share the offsets {1, s2, s3}; 9- / 27-point ones {1, s2 - 1, s2, s2 + 1, s3 - s2 - 1, ..., s3 + s2 + 1}
+      if (P.size() >= 2 && P[0] == 1) {
+        const int64_t a = P[1];
+        if (has(a + 1) && has(a + 2)) s2 = a + 1;
+        else if (!has(a + 1)) s2 = a;
+        if (s2 > 1) {
+          auto it = std::upper_bound(P.begin(), P.end(), s2 + 1);
+          if (it == P.end()) s3 = ((nb + s2 - 1) / s2) * s2; // two-dimensional: one plane
+          else {
+            const int64_t c = *it;
+            if (has(c + 1) && has(c + 2)) s3 = has(c + s2 + 1) ? c + s2 + 1 : 0;
+            else if (!has(c + 1)) s3 = c;
+          }
+        }
+      }
+      if (s2 < 4 || s3 < 2 * s2) s2 = s3 = 0;
+    }
+    if (!s2) {
+      for (int64_t r = r0; r < r1; ++r) order[(size_t)out++] = (int32_t)r;
+      continue;
+    }
+    any = true;
+    const int64_t ny = s3 / s2, nz = (nb + s3 - 1) / s3;
+    constexpr int64_t TX = 16, TY = 4, TZ = 4;
+    for (int64_t z0 = 0; z0 < nz; z0 += TZ)
+      for (int64_t y0 = 0; y0 < ny; y0 += TY)
+        for (int64_t x0 = 0; x0 < s2; x0 += TX)
+          for (int64_t z = z0; z < std::min(z0 + TZ, nz); ++z)
+            for (int64_t y = y0; y < std::min(y0 + TY, ny); ++y)
+              for (int64_t x = x0; x < std::min(x0 + TX, s2); ++x) {
+                const int64_t r = x + y * s2 + z * s3;
+                if (r < nb && !seen[(size_t)(r0 + r)]) {
+                  seen[(size_t)(r0 + r)] = 1;
+                  order[(size_t)out++] = (int32_t)(r0 + r);
+                }
+              }
+    for (int64_t r = r0; r < r1; ++r) // (planes with s3 % s2 leftovers)
+      if (!seen[(size_t)r]) order[(size_t)out++] = (int32_t)r;
+  }
+  return any && out == n;
+}
+// host-only entry for the CPU tests: order_out[n]; returns 1 when a grid structure was found (else order_out is the identity)
+extern "C" int ddm_csr_row_order_tiled_host(int64_t nblocks, const int64_t *block_ptr, const int64_t *rowptr, const int32_t *col, int32_t *order_out)
+{
+  if (nblocks < 1 || !block_ptr || !rowptr || !col || !order_out || block_ptr[0] != 0) return DDM_EINVAL;
+  std::vector<int32_t> order;
+  const bool found = csr_row_order_tiled(nblocks, block_ptr, rowptr, col, order);
+  std::memcpy(order_out, order.data(), sizeof(int32_t) * order.size());
+  return found ? 1 : 0;
+}
+static ddm_csr *csr_adopt(ddm_ctx *ctx, int64_t n, hvec<int64_t> &&rp, hvec<int32_t> &&ci, hvec<double> &&va, hvec<double> &&companion_values, ddm_csr **companion,
+                          int64_t nblocks = 0, const int64_t *block_ptr = nullptr /* diagonal blocks: builds the cache-blocked row order of the block products */)
 {
   ddm_csr *A = new ddm_csr, *C = new ddm_csr;
   A->nrows = A->ncols = C->nrows = C->ncols = n;
@@ -523,7 +601,8 @@ static ddm_csr *csr_adopt(ddm_ctx *ctx, int64_t n, hvec<int64_t> &&rp, hvec<int3
   *companion = C;
   const int device = ctx->device;
   auto cv = std::make_shared<hvec<double>>(std::move(companion_values));
-  A->uploader = std::thread([A, C, cv, device]() {
+  std::vector<int64_t> bp(block_ptr ? block_ptr : nullptr, block_ptr ? block_ptr + nblocks + 1 : nullptr);
+  A->uploader = std::thread([A, C, cv, device, bp]() {
     auto up = [&](const void *src, size_t bytes, void **dst) {
       if (A->upload_rc) return;
       hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 8));
@@ -541,6 +620,10 @@ static ddm_csr *csr_adopt(ddm_ctx *ctx, int64_t n, hvec<int64_t> &&rp, hvec<int3
     up(A->h_va.data(), sizeof(double) * A->h_va.size(), (void **)&A->va);
     up(blk.data(), sizeof(int32_t) * blk.size(), (void **)&A->blk_row);
     up(cv->data(), sizeof(double) * cv->size(), (void **)&C->va);
+    if (bp.size() >= 2 && !std::getenv("DDM_SPMM_NATURAL_ORDER")) {
+      std::vector<int32_t> order;
+      if (csr_row_order_tiled((int64_t)bp.size() - 1, bp.data(), A->h_rp.data(), A->h_ci.data(), order)) up(order.data(), sizeof(int32_t) * order.size(), (void **)&A->row_order);
+    }
     C->rp = A->rp;
     C->ci = A->ci;
     C->blk_row = A->blk_row;
@@ -600,6 +683,13 @@ static int csr_mm2_ld(ddm_ctx *ctx, const ddm_csr *A1, const ddm_csr *A2, int nr
   }
   const int64_t threads = A1->nrows * (int64_t)(nrhs / 4);
   if (threads == 0) return DDM_OK;
+  if (A1->row_order && nrhs / 4 <= 8) { // cache-blocked row order: 64 rows per workgroup
+    const int nq = nrhs / 4;
+    hipLaunchKernelGGL(k_spmm_rowmajor4_tiled<true>, dim3((unsigned)((A1->nrows + 63) / 64)), dim3(64 * nq), 0, ctx->stream, A1->nrows, nq, A1->row_order, A1->rp, A1->ci, A1->va,
+                       (const double *)A2->va, X, ldx, Y1, Y2, ldy);
+    HIPCHECK(ctx, hipGetLastError());
+    return DDM_OK;
+  }
   hipLaunchKernelGGL(k_spmm_rowmajor4<true>, dim3((unsigned)((threads + WG - 1) / WG)), dim3(WG), 0, ctx->stream, A1->nrows, nrhs / 4, A1->rp, A1->ci, A1->va,
                      (const double *)A2->va, X, ldx, Y1, Y2, ldy);
   HIPCHECK(ctx, hipGetLastError());

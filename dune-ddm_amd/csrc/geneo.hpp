@@ -472,7 +472,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
   } own;
   // the host arrays move into At; its device copy and the values of C~ (same pattern, device only) are uploaded by a helper thread
   // while this one factorises / analyses on the host
-  own.At = csr_adopt(ctx, n, std::move(rpT), std::move(ciT), std::move(vaT), std::move(vaC), &own.C);
+  own.At = csr_adopt(ctx, n, std::move(rpT), std::move(ciT), std::move(vaT), std::move(vaC), &own.C, nsub, sub_ptr);
   const double t_upload = since(t_begin);
   // A~ X and C~ X of the same block in one pass (the two matrices share their pattern: build_pencil_host)
   auto apply_AC = [&](int mm, const double *X, int64_t ldx, double *YA, double *YC, int64_t ldy) -> int {

@@ -369,6 +369,49 @@ __global__ __launch_bounds__(WG) void k_spmm_rowmajor4(int64_t n, int nq /* nrhs
   if (TWO) *reinterpret_cast<d4 *>(y2 + row * ldy + j) = s2;
 }
 
+// The same product with the rows processed in a CACHE-BLOCKED order (order[]: a permutation of the rows, csr_row_order_tiled): rows of
+// a 16 x 4 x 4 brick of a structured grid are neighbours in order[], a workgroup takes 64 of them (blockDim = 64 nq threads), and the
+// workgroups of one XCD take a contiguous range of bricks (xcd_remap) -- the 27 gathered X rows of a row are then shared inside the
+// brick and with the bricks running beside it on the same L2, instead of being fetched once per grid plane (29.7 GB of L2 fills per
+// call for 12 GB of algorithmic traffic with the natural order at 216^3).  Every row is computed as before: same sums, same order.
+template <bool TWO>
+__global__ __launch_bounds__(512) void k_spmm_rowmajor4_tiled(int64_t n, int nq /* nrhs / 4 */, const int32_t *__restrict__ order, const int64_t *__restrict__ rp,
+                                                               const int32_t *__restrict__ ci, const double *__restrict__ va, const double *__restrict__ va2,
+                                                               const double *__restrict__ x, int64_t ldx, double *__restrict__ y, double *__restrict__ y2, int64_t ldy)
+{
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  const int rows_per_wg = blockDim.x / nq;
+  const int64_t wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int lr = threadIdx.x / nq;
+  const int64_t pos = wg * rows_per_wg + lr;
+  if (lr >= rows_per_wg || pos >= n) return;
+  const int64_t row = order[pos];
+  const int j = 4 * (threadIdx.x - lr * nq);
+  const int64_t k0 = rp[row], k1 = rp[row + 1];
+  d4 s = {0.0, 0.0, 0.0, 0.0}, s2 = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t kb = k0; kb < k1; kb += 4) {
+    int32_t c[4];
+    double v[4], w[4];
+    d4 xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool ok = kb + u < k1;
+      c[u] = ok ? ci[kb + u] : -1;
+      v[u] = ok ? va[kb + u] : 0.0;
+      if (TWO) w[u] = ok ? va2[kb + u] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xv[u] = c[u] >= 0 ? *reinterpret_cast<const d4 *>(x + (int64_t)c[u] * ldx + j) : d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s += v[u] * xv[u];
+      if (TWO) s2 += w[u] * xv[u];
+    }
+  }
+  *reinterpret_cast<d4 *>(y + row * ldy + j) = s;
+  if (TWO) *reinterpret_cast<d4 *>(y2 + row * ldy + j) = s2;
+}
+
 // Several consecutive small levels (each <= WG*TRSV_SMALL_ROWS rows) in ONE workgroup: the levels
 // are separated by workgroup barriers instead of kernel boundaries.  desc[l] = {m, w, row_off,
 // ent_off}.  All data of these levels is produced and consumed by this workgroup only.

@@ -97,6 +97,12 @@ int ddm_csr_usmv(ddm_ctx *ctx, const ddm_csr *A, double alpha, const double *x, 
  * eigensolvers/spectra.hh:100-105, on a block of vectors) */
 int ddm_csr_mm(ddm_ctx *ctx, const ddm_csr *A, int nrhs, const double *X, double *Y);
 
+/* Host-only (no device): the cache-blocked processing order the library uses for the block products A~ X, C~ X of the GenEO
+ * eigensolver when the diagonal blocks of the matrix come from a structured grid in lexicographic numbering (strides read off the
+ * column offsets most rows share; 16 x 4 x 4 bricks).  order_out[n] is always a permutation of the rows; returns 1 when a grid
+ * structure was found, 0 when not (identity), < 0 on bad arguments.  A performance hint only: every row is computed as before. */
+int ddm_csr_row_order_tiled_host(int64_t nblocks, const int64_t *block_ptr, const int64_t *rowptr, const int32_t *col, int32_t *order_out);
+
 /* ---- local subdomain solver: ILU(0), natural row order ------------------------------------
  * The InverseOperator behind schwarz.hh:57,92,133 for [subdomain_solver] type=loopsolver maxit=1,
  * preconditioner type=ilu n=0.  block_ptr[0..nblocks] = row ranges of the independent diagonal
