@@ -389,21 +389,22 @@ __global__ __launch_bounds__(512) void k_spmm_rowmajor4_tiled(int64_t n, int nq 
   const int j = 4 * (threadIdx.x - lr * nq);
   const int64_t k0 = rp[row], k1 = rp[row + 1];
   d4 s = {0.0, 0.0, 0.0, 0.0}, s2 = {0.0, 0.0, 0.0, 0.0};
-  for (int64_t kb = k0; kb < k1; kb += 4) {
-    int32_t c[4];
-    double v[4], w[4];
-    d4 xv[4];
+  constexpr int CH = 8; // entries whose gathers are in flight together (the kernel is bound by these dependent gathers, not by bytes)
+  for (int64_t kb = k0; kb < k1; kb += CH) {
+    int32_t c[CH];
+    double v[CH], w[CH];
+    d4 xv[CH];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < CH; ++u) {
       const bool ok = kb + u < k1;
       c[u] = ok ? ci[kb + u] : -1;
       v[u] = ok ? va[kb + u] : 0.0;
       if (TWO) w[u] = ok ? va2[kb + u] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) xv[u] = c[u] >= 0 ? *reinterpret_cast<const d4 *>(x + (int64_t)c[u] * ldx + j) : d4{0.0, 0.0, 0.0, 0.0};
+    for (int u = 0; u < CH; ++u) xv[u] = c[u] >= 0 ? *reinterpret_cast<const d4 *>(x + (int64_t)c[u] * ldx + j) : d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < CH; ++u) {
       s += v[u] * xv[u];
       if (TWO) s2 += w[u] * xv[u];
     }
