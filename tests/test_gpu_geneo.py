@@ -261,3 +261,30 @@ def test_geneo_wide_block_beyond_48_columns(ddm):
         res, rq = host_eigenpair_residuals(sd, basis[sd.id], lam_d)
         assert res.max() < 1e-4 and rq.max() < 1e-7, (sd.id, res.max(), rq.max())
     tl.ctx.close()
+
+
+def test_geneo_cache_blocked_row_order_is_bit_identical(ddm, monkeypatch):
+    """The block products A~ X, C~ X of the eigensolver run in a cache-blocked row order when the subdomain matrices come from a
+    structured grid (k_spmm_rowmajor4_tiled; tests/test_row_order.py); every row is computed exactly as in the natural order, so the
+    whole eigensolver run -- eigenvalues, basis, iteration count -- must be BIT-identical to a run with DDM_SPMM_NATURAL_ORDER=1."""
+    from dune_ddm_amd import synth
+    from dune_ddm_amd.geneo import geneo_basis
+    from dune_ddm_amd.problem import build_structured, _block_diag
+    from dune_ddm_amd.solver import TwoLevelSchwarz
+    import scipy.sparse as sp
+    dec = build_structured(synth.StructuredPoisson((37, 33, 29), (2, 1, 1)), overlap=2, pou_type="distance", neumann=True)
+    found, _ = ddm.row_order_tiled_host(np.concatenate([[0], np.cumsum([sd.n for sd in dec.subs])]), sp.csr_matrix(_block_diag([sd.A_neu for sd in dec.subs])))
+    assert found                                                                      # the tiled kernel is what runs below
+    runs = []
+    for natural in (False, True):
+        if natural:
+            monkeypatch.setenv("DDM_SPMM_NATURAL_ORDER", "1")
+        tl = TwoLevelSchwarz(dec, coarse="none")
+        basis, info = geneo_basis(tl, nev=6, tol=1e-6, return_info=True)
+        runs.append((basis, info))
+        tl.ctx.close()
+    (b0, i0), (b1, i1) = runs
+    assert i0["iterations"] == i1["iterations"] and i0["converged"] and i1["converged"]
+    for s in b0:
+        assert np.array_equal(b0[s], b1[s])
+        assert np.array_equal(i0["eigenvalues"][s], i1["eigenvalues"][s])
