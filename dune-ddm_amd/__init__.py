@@ -71,6 +71,7 @@ SYMBOLS = {
     "ddm_memcpy_h2d": (_I32, [_P, _P, _P, _I64]),
     "ddm_memcpy_d2h": (_I32, [_P, _P, _P, _I64]),
     "ddm_csr_create": (_I32, [_P, _I64, _I64, _P, _P, _P, _PP]),
+    "ddm_csr_create_host": (_I32, [_P, _I64, _I64, _P, _P, _P, _PP]),
     "ddm_csr_destroy": (None, [_P]),
     "ddm_csr_rows": (_I64, [_P]),
     "ddm_csr_nnz": (_I64, [_P]),
@@ -276,7 +277,8 @@ def _ptr(t):
 class CsrMatrix:
     """Flattened BCRSMatrix on the device (ddm_csr)."""
 
-    def __init__(self, ctx: Context, M):
+    def __init__(self, ctx: Context, M, host_only=False):
+        """host_only: no device copy (inputs the library only reads on the host: A_neu, B_neu of geneo_basis)"""
         import scipy.sparse as sp
         M = sp.csr_matrix(M)
         if not M.has_sorted_indices:
@@ -285,7 +287,8 @@ class CsrMatrix:
         self.shape = M.shape
         rp, ci, va = _np(M.indptr, np.int64), _np(M.indices, np.int32), _np(M.data, np.float64)
         h = ctypes.c_void_p()
-        ctx.check(ctx.lib.ddm_csr_create(ctx.h, M.shape[0], M.shape[1], _hp(rp), _hp(ci), _hp(va), ctypes.byref(h)))
+        create = ctx.lib.ddm_csr_create_host if host_only else ctx.lib.ddm_csr_create
+        ctx.check(create(ctx.h, M.shape[0], M.shape[1], _hp(rp), _hp(ci), _hp(va), ctypes.byref(h)))
         self.h = h
         self.nnz = int(M.nnz)
 

@@ -436,6 +436,7 @@ struct ddm_csr {
   int32_t *blk_row = nullptr;
   int nblk = 0;
   bool borrowed_pattern = false; // rp / ci / blk_row belong to another ddm_csr (values-only companion on the same pattern)
+  bool host_only = false;        // created by ddm_csr_create_host: no device arrays
   int32_t *row_order = nullptr;  // cache-blocked processing order of the rows for the block products (csr_row_order_tiled), or null
   std::thread uploader;          // device copies still in flight (csr_adopt): csr_wait_upload joins it
   int upload_rc = 0;
@@ -443,8 +444,7 @@ struct ddm_csr {
 };
 
 static std::vector<int32_t> csr_row_blocks(int64_t nrows, const int64_t *rowptr);
-extern "C" int ddm_csr_create(ddm_ctx *ctx, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *col,
-                              const double *val, ddm_csr **out)
+static int csr_create_impl(ddm_ctx *ctx, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *col, const double *val, bool host_only, ddm_csr **out)
 {
   if (!ctx || !out || nrows < 0 || !rowptr) return fail(ctx, DDM_EINVAL, "ddm_csr_create: bad arguments");
   if (nrows >= (int64_t)1 << 31 || ncols >= (int64_t)1 << 31) return fail(ctx, DDM_EINVAL, "matrix dimension exceeds int32 columns");
@@ -462,6 +462,12 @@ extern "C" int ddm_csr_create(ddm_ctx *ctx, int64_t nrows, int64_t ncols, const 
   hvec_copy(A->h_va, val, (size_t)nnz);
   const std::vector<int32_t> blk = csr_row_blocks(nrows, rowptr);
   A->nblk = (int)blk.size() - 1;
+  if (host_only) { // analysis / assembly input only (the GenEO pencil is built from the host arrays): no device copy
+    A->host_only = true;
+    A->nblk = 0;
+    *out = A;
+    return DDM_OK;
+  }
   int rc = upload(ctx, rowptr, nrows + 1, &A->rp);
   if (!rc) rc = upload(ctx, col, nnz, &A->ci);
   if (!rc) rc = upload(ctx, val, nnz, &A->va);
@@ -472,6 +478,16 @@ extern "C" int ddm_csr_create(ddm_ctx *ctx, int64_t nrows, int64_t ncols, const 
   }
   *out = A;
   return DDM_OK;
+}
+extern "C" int ddm_csr_create(ddm_ctx *ctx, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *col, const double *val, ddm_csr **out)
+{
+  return csr_create_impl(ctx, nrows, ncols, rowptr, col, val, false, out);
+}
+// the same object WITHOUT device arrays: valid as A_neu / B_neu of ddm_geneo_basis (the pencil is assembled from the host arrays) and
+// of the other coarse-space builders' host inputs; every entry point that would touch the device arrays returns DDM_EINVAL
+extern "C" int ddm_csr_create_host(ddm_ctx *ctx, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *col, const double *val, ddm_csr **out)
+{
+  return csr_create_impl(ctx, nrows, ncols, rowptr, col, val, true, out);
 }
 extern "C" void ddm_csr_destroy(ddm_csr *A)
 {
@@ -636,6 +652,7 @@ extern "C" int64_t ddm_csr_nnz(const ddm_csr *A) { return A->nnz; }
 
 static int csr_mv_impl(ddm_ctx *ctx, const ddm_csr *A, double alpha, const double *x, double *y, bool acc)
 {
+  if (A->host_only) return fail(ctx, DDM_EINVAL, "the matrix was created without device arrays (ddm_csr_create_host)");
   if (A->nblk == 0) return DDM_OK;
   if (acc)
     hipLaunchKernelGGL(k_spmv_stream<true>, dim3(A->nblk), dim3(WG), 0, ctx->stream, A->rp, A->ci, A->va, A->blk_row, A->nblk, x, y, alpha);
@@ -659,6 +676,7 @@ extern "C" int ddm_csr_usmv(ddm_ctx *ctx, const ddm_csr *A, double alpha, const 
 static int csr_mm_ld(ddm_ctx *ctx, const ddm_csr *A, int nrhs, const double *X, int64_t ldx, double *Y, int64_t ldy)
 {
   if (!A || !X || !Y || X == Y || nrhs < 1 || ldx < nrhs || ldy < nrhs) return fail(ctx, DDM_EINVAL, "ddm_csr_mm: bad arguments");
+  if (A->host_only) return fail(ctx, DDM_EINVAL, "the matrix was created without device arrays (ddm_csr_create_host)");
   const int64_t threads = A->nrows * (int64_t)nrhs;
   if (threads == 0) return DDM_OK;
   if (nrhs % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)X & 31) == 0 && ((uintptr_t)Y & 31) == 0) {
@@ -1574,6 +1592,7 @@ static int sn_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, con
   if (max_flops > 0.0 && flops > max_flops)
     return fail(ctx, DDM_ENOTIMPL, "sparse direct solver: the factorisation needs %.3g flops (limit %.3g)", flops, max_flops);
   DDMCHECK(csr_wait_upload(ctx, A)); // (matrices the library assembled itself are uploaded by a helper thread: csr_adopt)
+  if (A->host_only) return fail(ctx, DDM_EINVAL, "the matrix was created without device arrays (ddm_csr_create_host)");
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)entries * 8.0 > 0.85 * (double)free_b)
     return fail(ctx, DDM_ENOTIMPL, "sparse direct solver: the factor needs %.1f GB, %.1f GB of device memory are free", entries * 8e-9, free_b * 1e-9);
@@ -2194,20 +2213,21 @@ static void enqueue_multi_levels(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const doub
   }
 }
 // single-precision preconditioner sweeps of an ILU(0) factor (kernels.hpp: k_trsv_level_multi4_f32); D, X double
-static void enqueue_multi_levels_f32(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double *D, int64_t ldd, double *X, int64_t ldx)
+// columns [c0, c0 + nc) of the block on `stream` (nc % 4 == 0): the columns are independent, so two halves can run as two chains
+static void enqueue_multi_levels_f32(ddm_ilu0 *F, hipStream_t stream, int nrhs, int c0, int nc, const double *D, int64_t ldd, double *X, int64_t ldx)
 {
   for (int pass = 0; pass < 2; ++pass) {
     const TriSchedule &S = pass ? F->U : F->L;
     for (int64_t l = 0; l < S.nlev; ++l) {
       const LevelDesc &L = S.desc[l];
       if (L.m == 0) continue;
-      const unsigned grid = (unsigned)(((int64_t)L.m * (nrhs / 4) + WG - 1) / WG);
+      const unsigned grid = (unsigned)(((int64_t)L.m * (nc / 4) + WG - 1) / WG);
       if (pass)
-        hipLaunchKernelGGL(k_trsv_level_multi4_f32<true>, dim3(grid), dim3(WG), 0, ctx->stream, L.m, L.w, nrhs / 4, S.rows + L.row_off, S.cols + L.ent_off, S.vals_f32 + L.ent_off,
-                           S.dinv_f32 + L.row_off, D, ldd, F->xf, (int64_t)nrhs, X, ldx);
+        hipLaunchKernelGGL(k_trsv_level_multi4_f32<true>, dim3(grid), dim3(WG), 0, stream, L.m, L.w, nc / 4, S.rows + L.row_off, S.cols + L.ent_off, S.vals_f32 + L.ent_off,
+                           S.dinv_f32 + L.row_off, D + c0, ldd, F->xf + c0, (int64_t)nrhs, X + c0, ldx);
       else
-        hipLaunchKernelGGL(k_trsv_level_multi4_f32<false>, dim3(grid), dim3(WG), 0, ctx->stream, L.m, L.w, nrhs / 4, S.rows + L.row_off, S.cols + L.ent_off, S.vals_f32 + L.ent_off,
-                           (const float *)nullptr, D, ldd, F->xf, (int64_t)nrhs, X, ldx);
+        hipLaunchKernelGGL(k_trsv_level_multi4_f32<false>, dim3(grid), dim3(WG), 0, stream, L.m, L.w, nc / 4, S.rows + L.row_off, S.cols + L.ent_off, S.vals_f32 + L.ent_off,
+                           (const float *)nullptr, D + c0, ldd, F->xf + c0, (int64_t)nrhs, X + c0, ldx);
     }
   }
 }
@@ -2283,7 +2303,10 @@ static int ilu0_solve_multi_ld(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double
     enqueue_multi_levels_csr(ctx, F->Uc, true, nrhs, F->pD, nrhs, F->pX, nrhs);
     hipLaunchKernelGGL(k_perm_scatter, dim3(grid_for(F->n * nrhs)), dim3(WG), 0, ctx->stream, F->n, nrhs, F->perm, (const double *)F->pX, X, ldx);
   } else if (f32) {
-    enqueue_multi_levels_f32(ctx, F, nrhs, D, ldd, X, ldx);
+    // (Splitting the columns into two halves that run as two parallel chains of the captured graph -- a second stream joining the
+    //  capture -- was measured and is slower: 6.8 against 5.6 s for the 109 block iterations of the headline GenEO run; every level
+    //  kernel is latency-bound, so two half-width kernels cost two full ones and the chains do not overlap enough to pay for that.)
+    enqueue_multi_levels_f32(F, ctx->stream, nrhs, 0, nrhs, D, ldd, X, ldx);
   } else {
     enqueue_multi_levels(ctx, F, nrhs, D, ldd, X, ldx);
   }

@@ -63,8 +63,8 @@ def geneo_basis(tl, nev=20, tol=1e-5, shift=1e-3, maxit=400, extra=4, seed=0, ve
     import time
     t0 = time.perf_counter()
     same = all(sd.B_neu is sd.A_neu for sd in rl.subs)
-    dA = CsrMatrix(ctx, _block_diag([sd.A_neu for sd in rl.subs]))
-    dB = dA if same else CsrMatrix(ctx, _block_diag([sd.B_neu for sd in rl.subs]))
+    dA = CsrMatrix(ctx, _block_diag([sd.A_neu for sd in rl.subs]), host_only=True)       # read on the host only (pencil assembly)
+    dB = dA if same else CsrMatrix(ctx, _block_diag([sd.B_neu for sd in rl.subs]), host_only=True)
     t1 = time.perf_counter()
     par = GeneoParams()
     ctx.lib.ddm_geneo_params_default(ctypes.byref(par))

@@ -84,7 +84,11 @@ int ddm_memcpy_d2h(ddm_ctx *ctx, void *dst, const void *src, int64_t bytes); /* 
 /* ---- CSR matrix (flattened Dune::BCRSMatrix<FieldMatrix<double,1,1>>; cf. the in-tree
  *      precedent dune/ddm/strumpack.hh:36-62) ---------------------------------------------- */
 int ddm_csr_create(ddm_ctx *ctx, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *col,
-                   const double *val, ddm_csr **out); /* host arrays are copied */
+                   const double *val, ddm_csr **out);
+/* The same object without device arrays, for matrices the library only reads on the host: A_neu / B_neu of ddm_geneo_basis (the
+ * pencil A_neu + sigma D B D is assembled from the host arrays; at 216^3 the two device copies were 7 GB and 0.6 s for nothing).
+ * Entry points that need the device arrays (products, factorisations) return DDM_EINVAL for it. */
+int ddm_csr_create_host(ddm_ctx *ctx, int64_t nrows, int64_t ncols, const int64_t *rowptr, const int32_t *col, const double *val, ddm_csr **out); /* host arrays are copied */
 void ddm_csr_destroy(ddm_csr *A);
 int64_t ddm_csr_rows(const ddm_csr *A);
 int64_t ddm_csr_nnz(const ddm_csr *A);
