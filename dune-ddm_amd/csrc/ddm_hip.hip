@@ -388,6 +388,17 @@ extern "C" int ddm_timing_reset(ddm_ctx *ctx)
 }
 
 // ---- CSR ---------------------------------------------------------------------------------------
+// Worker threads of the host-side setup phases (factorisations, schedules, assembly): the cores of the machine, but never more than
+// 16 per process -- a node runs one process per GPU, and several of these pools are alive at the same time (DDM_HOST_THREADS overrides).
+static unsigned host_threads()
+{
+  static const unsigned n = []() {
+    if (const char *e = std::getenv("DDM_HOST_THREADS")) return (unsigned)std::max(1, std::atoi(e));
+    return std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  }();
+  return n;
+}
+
 // Host arrays of matrix size (10^8..10^9 entries): a std::vector whose resize() leaves the new elements UNINITIALISED -- the value
 // initialisation of std::vector is a single-threaded pass over fresh pages (0.5 s per 3 GB), the threads that fill the array then
 // touch the pages themselves.
@@ -411,7 +422,7 @@ template <class T>
 static void hvec_copy(hvec<T> &dst, const T *src, size_t n)
 {
   dst.resize(n);
-  const size_t nth = std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), std::max<size_t>(1, n >> 22));
+  const size_t nth = std::min<size_t>(host_threads(), std::max<size_t>(1, n >> 22));
   if (nth <= 1) {
     if (n) std::memcpy(dst.data(), src, sizeof(T) * n);
     return;
@@ -907,7 +918,7 @@ static int build_schedule(ddm_ctx *ctx, const ddm_csr *A, const hvec<double> &lu
   if (upper) dinv.resize(n);
   // the sliced-ELL fill (strided writes, 1.8 GB per triangle at 216^3) on several threads: levels are independent, each thread takes a
   // run of consecutive levels with about the same number of entries (the two triangles are built at the same time: half the cores each)
-  const int nfill = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::max(1u, std::thread::hardware_concurrency() / 2), nlev, ent / (1 << 20) + 1}));
+  const int nfill = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::max(1u, host_threads() / 2), nlev, ent / (1 << 20) + 1}));
   std::vector<int64_t> cut((size_t)nfill + 1, nlev);
   cut[0] = 0;
   for (int t = 1, l = 0; t < nfill; ++t) {
@@ -986,7 +997,7 @@ static void invert_supernodes(const hvec<double> &lu, const std::vector<int64_t>
   std::vector<size_t> order(ns);
   for (size_t q = 0; q < ns; ++q) order[q] = q;
   std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return SN.j1[a] - SN.j0[a] > SN.j1[b] - SN.j0[b]; }); // largest first
-  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const unsigned hw = host_threads();
   const int nth = (int)std::min<size_t>(hw, std::max<size_t>(ns, 1));
   std::atomic<size_t> next{0};
   std::vector<std::thread> th;
@@ -1353,7 +1364,7 @@ static int ilu0_create_impl(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, con
   std::vector<int64_t> diag(A->nrows);
   std::vector<int> rcs(nblocks, 0);
   {
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned hw = host_threads();
     const int nthreads = (int)std::min<int64_t>(nblocks, hw);
     std::vector<std::thread> th;
     for (int t = 0; t < nthreads; ++t)
@@ -1408,7 +1419,7 @@ static int chol_build(int64_t n, const int64_t *rp, const int32_t *ci, const dou
   std::vector<chol::PermutedLower> PL((size_t)nblocks);
   std::vector<chol::PermutedLowerLU> PU((size_t)(general ? nblocks : 0));
   std::vector<std::vector<double>> UX((size_t)(general ? nblocks : 0));
-  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const unsigned hw = host_threads();
   const int nthreads = (int)std::min<int64_t>(nblocks, hw);
   auto parallel = [&](auto fn) {
     std::vector<std::thread> th;
@@ -1551,7 +1562,7 @@ static int sn_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, con
     }
   }
   {
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned hw = host_threads();
     const int nthreads = (int)std::min<int64_t>(nblocks, hw);
     std::vector<std::thread> th;
     for (int t = 0; t < nthreads; ++t)

@@ -192,7 +192,7 @@ static void build_pencil_host(const ddm_csr *A, const ddm_csr *B, const double *
   const int64_t n = A->nrows;
   rpT.resize((size_t)n + 1);
   rpT[0] = 0;
-  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const unsigned hw = host_threads();
   const int nth = (int)std::min<int64_t>(hw, std::max<int64_t>(1, n / 65536));
   std::vector<std::thread> th;
   // pass 1: sizes of the merged rows (threads), then the prefix sum
@@ -661,7 +661,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
     }
     // Rayleigh-Ritz per subdomain on the host
     {
-      const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+      const unsigned hw = host_threads();
       const int nth = (int)std::min<int64_t>(nsub, hw);
       std::vector<std::thread> th;
       std::vector<int> ranks((size_t)nsub, 0);

@@ -467,7 +467,7 @@ inline bool build(int64_t n, const int64_t *rp, const int32_t *ci, const double 
     return false;
   }
   S.geo = Geometry(W); // the widest tile (sizes the LDS slots)
-  if (nthreads <= 0) nthreads = (int)std::max(1u, std::thread::hardware_concurrency());
+  if (nthreads <= 0) nthreads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency())); // (one process per GPU on a node: bounded pools)
   nthreads = std::min(nthreads, std::max(1, nblocks));
 
   std::vector<BlockSweep> BS((size_t)nblocks * 2);
