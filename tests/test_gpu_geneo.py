@@ -288,3 +288,28 @@ def test_geneo_cache_blocked_row_order_is_bit_identical(ddm, monkeypatch):
     for s in b0:
         assert np.array_equal(b0[s], b1[s])
         assert np.array_equal(i0["eigenvalues"][s], i1["eigenvalues"][s])
+
+
+def test_host_only_matrix_objects(ddm):
+    """ddm_csr_create_host: the GenEO inputs A_neu / B_neu are read on the host only; such an object must be refused (DDM_EINVAL with a
+    message, not a fault) by every entry point that would touch device arrays."""
+    import torch
+    from dune_ddm_amd import synth
+    ctx = ddm.torch_context(0)
+    M = synth.StructuredPoisson((9, 8, 7), (1, 1, 1)).subdomain(0).A
+    H = ddm.CsrMatrix(ctx, M, host_only=True)
+    x = torch.ones(M.shape[0], dtype=torch.float64, device="cuda")
+    y = torch.empty_like(x)
+    with pytest.raises(RuntimeError, match="without device arrays"):
+        H.mv(x, y)
+    X = torch.ones((M.shape[0], 4), dtype=torch.float64, device="cuda")
+    with pytest.raises(RuntimeError, match="without device arrays"):
+        H.mm(X, torch.empty_like(X))
+    F = ddm.Ilu0(ctx, H)                                  # ILU(0) factorises on the host and uploads its own schedule: fine
+    F.solve(x, y)
+    G = ddm.Ilu0(ctx, ddm.CsrMatrix(ctx, M))
+    z = torch.empty_like(x)
+    G.solve(x, z)
+    ctx.sync()
+    assert torch.equal(y, z)
+    ctx.close()
