@@ -1534,6 +1534,19 @@ extern "C" int ddm_chol_host_get(const ddm_chol_host *H, int32_t *perm, int64_t 
 
 // Supernodal Cholesky on the device.  Returns DDM_OK / an error code, or 1 when the factorisation is too small to be worth it and
 // force == false (the caller then takes the host path).
+// multiply-adds of a supernodal factorisation of all blocks, estimated from the first separator of the LARGEST block alone (host only,
+// one thread, ~1 s per 10^6 rows); 0 when that block has entries outside its diagonal block
+static double sn_probe_largest_block(const int64_t *rp, const int32_t *ci, int64_t nblocks, const int64_t *block_ptr, bool lu)
+{
+  int64_t bl = 0;
+  for (int64_t b = 1; b < nblocks; ++b)
+    if (block_ptr[b + 1] - block_ptr[b] > block_ptr[bl + 1] - block_ptr[bl]) bl = b;
+  const int64_t r0 = block_ptr[bl], r1 = block_ptr[bl + 1];
+  for (int64_t i = r0; i < r1; ++i)
+    for (int64_t k = rp[i]; k < rp[i + 1]; ++k)
+      if (ci[k] < r0 || ci[k] >= r1) return 0.0;
+  return (lu ? 2.0 : 1.0) * sn::estimate_flops(chol::block_graph(rp, ci, r0, r1)) * (double)nblocks;
+}
 static int sn_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, double max_flops, bool force, bool lu, bool setup_use, ddm_ilu0 **out)
 {
   const int64_t n = A->nrows;
@@ -1546,20 +1559,10 @@ static int sn_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, con
   if (max_flops > 0.0 && nblocks > 1) {
     // the largest block first, alone: when its first separator already says "a factor of four beyond the limit" the other blocks are
     // not looked at (the callers run other host work beside this analysis: one busy thread instead of one per block)
-    int64_t bl = 0;
-    for (int64_t b = 1; b < nblocks; ++b)
-      if (block_ptr[b + 1] - block_ptr[b] > block_ptr[bl + 1] - block_ptr[bl]) bl = b;
-    const int64_t r0 = block_ptr[bl], r1 = block_ptr[bl + 1];
-    bool inside = true;
-    for (int64_t i = r0; i < r1 && inside; ++i)
-      for (int64_t k = rp[i]; k < rp[i + 1]; ++k)
-        if (ci[k] < r0 || ci[k] >= r1) inside = false;
-    if (inside) {
-      const double q = (lu ? 2.0 : 1.0) * sn::estimate_flops(chol::block_graph(rp, ci, r0, r1));
-      if (q * (double)nblocks > 4.0 * max_flops)
-        return fail(ctx, DDM_ENOTIMPL, "sparse direct solver: the factorisation needs about %.1g flops (estimate from the first separator of the largest block; limit %.3g)",
-                    q * (double)nblocks, max_flops);
-    }
+    const double q = sn_probe_largest_block(rp, ci, nblocks, block_ptr, lu);
+    if (q > 4.0 * max_flops)
+      return fail(ctx, DDM_ENOTIMPL, "sparse direct solver: the factorisation needs about %.1g flops (estimate from the first separator of the largest block; limit %.3g)", q,
+                  max_flops);
   }
   {
     const unsigned hw = host_threads();

@@ -454,6 +454,20 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
     if (sub_ptr[s + 1] - sub_ptr[s] < 3 * (int64_t)m) return fail(ctx, DDM_EINVAL, "GenEO: subdomain %lld has fewer than 3 (nev + extra) = %d rows", (long long)s, 3 * m);
   const auto t_begin = std::chrono::steady_clock::now();
   auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+  // "auto": whether the sparse direct factor of A~ is affordable at all is estimated on a helper thread from the first separator of the
+  // largest block of A_neu's pattern (the pencil's pattern, or a superset of B_neu's), while the pencil is being assembled
+  struct Joiner { // (an early error return must not leave a helper thread running on this frame's variables)
+    std::thread &t;
+    ~Joiner()
+    {
+      if (t.joinable()) t.join();
+    }
+  };
+  double probe_flops = 0.0;
+  std::thread probe_thread;
+  Joiner probe_joiner{probe_thread};
+  if (P.preconditioner == 0 && P.max_direct_flops > 0.0 && nsub > 1 && !std::getenv("DDM_DIRECT_ENGINE"))
+    probe_thread = std::thread([&]() { probe_flops = sn_probe_largest_block(A_neu->h_rp.data(), A_neu->h_ci.data(), nsub, sub_ptr, false); });
   // ---- pencil ----
   hvec<int64_t> rpT;
   hvec<int32_t> ciT;
@@ -489,6 +503,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
   int rc_ilu = DDM_OK;
   std::string err_ilu;
   std::thread ilu_thread;
+  Joiner ilu_joiner{ilu_thread};
   auto start_ilu = [&]() {
     ilu_thread = std::thread([&]() {
       (void)hipSetDevice(ctx->device);
@@ -499,7 +514,14 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
   if (P.preconditioner != 2) start_ilu();
   int rc_direct = DDM_OK;
   std::string why_not;
-  if (P.preconditioner != 1) {
+  if (probe_thread.joinable()) probe_thread.join();
+  if (P.preconditioner == 0 && probe_flops > 4.0 * P.max_direct_flops) { // declined by the early probe: no second analysis
+    char buf[256];
+    std::snprintf(buf, sizeof buf, "sparse direct solver: the factorisation needs about %.1g flops (estimate from the first separator of the largest block; limit %.3g)",
+                  probe_flops, P.max_direct_flops);
+    why_not = buf;
+    rc_direct = DDM_ENOTIMPL;
+  } else if (P.preconditioner != 1) {
     rc_direct = direct_create_impl(ctx, own.At, nsub, sub_ptr, 0, P.preconditioner == 2 ? 0.0 : P.max_direct_flops, /*setup_use=*/true, &own.T);
     if (rc_direct == DDM_OK) direct = 1;
     else why_not = ddm_last_error(ctx);
