@@ -84,7 +84,7 @@ def main():
     t_host = time.perf_counter() - t0
     t1 = time.perf_counter()
     tl = TwoLevelSchwarz(dec, rank, world, local_rank, comm, schwarz_type=cfg["schwarz_type"], mode=cfg["mode"], coarse="none", subdomain_solver=cfg["local"])
-    basis = geneo_basis(tl, nev=cfg["nev"], tol=cfg["tol"])
+    basis = geneo_basis(tl, nev=cfg["nev"], tol=cfg["tol"], verbose=(rank == 0 and os.environ.get("DDM_VERBOSE") == "1"))
     tl.set_coarse_basis(basis)
     tl.rebuild_combined(cfg["mode"])
     tl.ctx.sync()
