@@ -167,6 +167,13 @@ def load_library():
     """Loads libddm_hip.so (built by __graft_entry__.build()).  Fails loudly if it is missing."""
     global _lib
     if _lib is None:
+        try:
+            # torch ships its own HIP runtime: it must be in the process BEFORE libddm_hip.so is opened, so that the library binds to
+            # the same libamdhip64 (the streams torch hands over belong to that runtime; with the opposite order ddm_ctx_create fails
+            # with "no HIP device" on a GPU box -- seen with build() followed by smoke() in one process)
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         path = os.environ.get("DDM_HIP_LIBRARY", LIB_PATH)   # (diagnostic: an experimental build of the same sources)
         if not os.path.exists(path):
             raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
