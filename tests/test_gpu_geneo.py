@@ -280,7 +280,7 @@ def test_geneo_cache_blocked_row_order_is_bit_identical(ddm, monkeypatch):
         if natural:
             monkeypatch.setenv("DDM_SPMM_NATURAL_ORDER", "1")
         tl = TwoLevelSchwarz(dec, coarse="none")
-        basis, info = geneo_basis(tl, nev=6, tol=1e-6, return_info=True)
+        basis, info = geneo_basis(tl, nev=8, tol=1e-6, return_info=True)      # block width 8 + 4 = 12: a multiple of 4, the four-column kernels run
         runs.append((basis, info))
         tl.ctx.close()
     (b0, i0), (b1, i1) = runs
