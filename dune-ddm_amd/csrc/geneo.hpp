@@ -542,6 +542,10 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
   // ILU(0) as the preconditioner of the block iteration: single-precision sweeps (the iteration only needs a fixed search direction
   // W = T r; eigenpairs and residuals are computed in double).  DDM_GENEO_ILU_F64=1 keeps the sweeps in double.
   const bool prec_f32 = !direct && !std::getenv("DDM_GENEO_ILU_F64");
+  // W <- W - X (A~X)^T W before the Rayleigh-Ritz step: twice with the exact T (W = A~^-1 r lies almost in span X near convergence: on
+  // the elasticity pencil one pass gave 68-81 block iterations in two of eight runs, none 133 in one, against 12-18), once with
+  // ILU(0) (216^3: the same 109 iterations and residuals with two, one or no pass; 5.6 / 5.2 / 4.9 s).  DDM_GENEO_ORTH_PASSES overrides.
+  const int orth_passes = std::getenv("DDM_GENEO_ORTH_PASSES") ? std::max(0, std::atoi(std::getenv("DDM_GENEO_ORTH_PASSES"))) : (direct ? 2 : 1);
   const double t_prec = since(t_begin);
   DDMCHECK(csr_wait_upload(ctx, own.At));
   const double t_setup = since(t_begin);
@@ -626,8 +630,8 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
       if (con) DDMCHECK(harmonic_apply(ctx, con, m, Wb, ld, true));    // W = P T P^T r stays in the subspace
       DDMCHECK(W.gram(AS[cur], ld, m, AS[cur], ld, m, gmm[2]));
       HIPCHECK(ctx, hipMemcpyAsync(h_aa.data(), gmm[2], sizeof(double) * h_aa.size(), hipMemcpyDeviceToHost, ctx->stream));
-      // W <- W - X (A~X)^T W   (twice), then A~-normalise the columns of W
-      for (int pass = 0; pass < 2; ++pass) {
+      // W <- W - X (A~X)^T W   (orth_passes times), then A~-normalise the columns of W
+      for (int pass = 0; pass < orth_passes; ++pass) {
         DDMCHECK(W.gram(AS[cur], ld, m, Wb, ld, m, gmm[3]));
         const double *Ux[1] = {S[cur]};
         double *Ox[1] = {Wb};
