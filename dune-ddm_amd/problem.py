@@ -108,18 +108,29 @@ def build_structured(grid, overlap=2, pou_type="distance", shrink=0, neumann=Fal
 
 
 def _block_diag(mats):
-    rp, ci, va = [np.zeros(1, dtype=np.int64)], [], []
-    roff, zoff = 0, 0
-    for M in mats:
-        M = sp.csr_matrix(M)
-        rp.append(M.indptr[1:].astype(np.int64) + zoff)
-        ci.append(M.indices.astype(np.int32) + np.int32(roff))
-        va.append(M.data.astype(np.float64))
-        roff += M.shape[0]
-        zoff += M.nnz
-    n = roff
-    return sp.csr_matrix((np.concatenate(va) if va else np.zeros(0), np.concatenate(ci) if ci else np.zeros(0, np.int32),
-                          np.concatenate(rp)), shape=(n, n))
+    """Block-diagonal CSR matrix (int64 row pointers, int32 columns, float64 values) of the given square matrices.  The three arrays
+    are allocated once and every block is written into its slice by a host thread (numpy's slice copies and in-place adds release
+    the GIL): at 216^3 the list-of-temporaries + concatenate version of this was 1.4 s per call, three calls per run."""
+    mats = [sp.csr_matrix(M) for M in mats]
+    nrows = np.array([0] + [M.shape[0] for M in mats], dtype=np.int64).cumsum()
+    nnz = np.array([0] + [M.nnz for M in mats], dtype=np.int64).cumsum()
+    n, z = int(nrows[-1]), int(nnz[-1])
+    rp = np.empty(n + 1, dtype=np.int64)
+    ci = np.empty(z, dtype=np.int32)
+    va = np.empty(z, dtype=np.float64)
+    rp[0] = 0
+
+    def put(k):
+        M = mats[k]
+        r0, r1, z0, z1 = int(nrows[k]), int(nrows[k + 1]), int(nnz[k]), int(nnz[k + 1])
+        rp[r0 + 1:r1 + 1] = M.indptr[1:]
+        rp[r0 + 1:r1 + 1] += z0
+        ci[z0:z1] = M.indices
+        ci[z0:z1] += np.int32(r0)
+        va[z0:z1] = M.data
+
+    _pmap(put, range(len(mats)))
+    return sp.csr_matrix((va, ci, rp), shape=(n, n))
 
 
 def halo_plan(pairs: dict, local_subs, sub2rank, offsets, rank, nranks):
