@@ -1,6 +1,7 @@
 // C-ABI implementation of include/ddm_hip.h: host-side runtime (contexts, plans, level schedules,
 // HIP graphs, the CG driver) around the kernels in kernels.hpp.  gfx950 only, no fallback path.
 #include "../../include/ddm_hip.h"
+#include "host_vec.hpp"
 #include "kernels.hpp"
 #include "trsv_pipe.hpp"
 #include "sparse_chol_host.hpp"
@@ -399,24 +400,6 @@ static unsigned host_threads()
   return n;
 }
 
-// Host arrays of matrix size (10^8..10^9 entries): a std::vector whose resize() leaves the new elements UNINITIALISED -- the value
-// initialisation of std::vector is a single-threaded pass over fresh pages (0.5 s per 3 GB), the threads that fill the array then
-// touch the pages themselves.
-template <class T>
-struct noinit_alloc : std::allocator<T> {
-  template <class U>
-  struct rebind {
-    using other = noinit_alloc<U>;
-  };
-  template <class U, class... Args>
-  void construct(U *p, Args &&...args)
-  {
-    if constexpr (sizeof...(Args) == 0) ::new ((void *)p) U;
-    else ::new ((void *)p) U(std::forward<Args>(args)...);
-  }
-};
-template <class T>
-using hvec = std::vector<T, noinit_alloc<T>>;
 // dst = src with `threads` memcpy workers (fresh pages: the copy is page-fault bound on one thread)
 template <class T>
 static void hvec_copy(hvec<T> &dst, const T *src, size_t n)

@@ -17,6 +17,7 @@
 // This header is plain C++17 (no HIP): it is compiled into libddm_hip.so and, for the CPU tests of the
 // schedule logic, into a host-only test library together with emulate() below.
 #pragma once
+#include "host_vec.hpp"
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
@@ -108,7 +109,7 @@ struct Schedule {
   Geometry geo;
   std::vector<Group> groups;
   std::vector<Task> tasks;
-  std::vector<unsigned char> stream;
+  hvec<unsigned char> stream; // (uninitialised on resize; the builder zero-fills it on several threads)
   std::vector<int32_t> koff;  // per task nsteps + 1 cumulative tile offsets in KiB
   std::vector<int32_t> rowL; // per L position: natural row or -1
   std::vector<int32_t> posU; // per natural row: U position
@@ -551,7 +552,8 @@ inline bool build(int64_t n, const int64_t *rp, const int32_t *ci, const double 
   S.nposL = npos[0];
   S.nposU = npos[1];
   S.tasks.resize((size_t)ntask);
-  S.stream.assign((size_t)nbytes, 0);
+  S.stream.resize((size_t)nbytes);
+  parallel_zero(S.stream.data(), (size_t)nbytes, (unsigned)nthreads);
   S.koff.assign((size_t)nkoff, 0);
   S.rowL.assign((size_t)npos[0], -1);
   S.posU.assign((size_t)n, 0);
