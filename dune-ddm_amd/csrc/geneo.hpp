@@ -542,6 +542,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
   // ILU(0) as the preconditioner of the block iteration: single-precision sweeps (the iteration only needs a fixed search direction
   // W = T r; eigenpairs and residuals are computed in double).  DDM_GENEO_ILU_F64=1 keeps the sweeps in double.
   const bool prec_f32 = !direct && !std::getenv("DDM_GENEO_ILU_F64");
+  const int refresh_period = std::getenv("DDM_GENEO_REFRESH") ? std::max(1, std::atoi(std::getenv("DDM_GENEO_REFRESH"))) : (direct ? 2 : 8);
   // W <- W - X (A~X)^T W before the Rayleigh-Ritz step: twice with the exact T (W = A~^-1 r lies almost in span X near convergence: on
   // the elasticity pencil one pass gave 68-81 block iterations in two of eight runs, none 133 in one, against 12-18), once with
   // ILU(0) (216^3: the same 109 iterations and residuals with two, one or no pass; 5.6 / 5.2 / 4.9 s).  DDM_GENEO_ORTH_PASSES overrides.
@@ -740,9 +741,16 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
       DDMCHECK(W.rotate(3, U3, O3, nullptr, ld, p, Yd, q2, ld, ld, /*gap_from=*/m, /*gap=*/m));
       cur = nxt;
     }
-    if (it > 0 && it % 8 == 0) { // refresh A~X, C X from X: the recursions drift
+    // Refresh A~X, C X from X and A~P, C P from P: the products are carried along by the rotations and drift.  With the exact T every
+    // second iteration: W and P shrink geometrically there (their scaling lives in the projected problem, the blocks are not
+    // renormalised), the Ritz coefficients of such columns are large, and products of P that are never recomputed went wrong often
+    // enough to matter -- on the elasticity pencil 12-18 block iterations in most runs but 36-120 or no convergence within 400 in
+    // about one run of seven (the device factor's atomics make every run round differently); with P refreshed as well: 12-16 in 28
+    // of 28 runs, refreshing X alone does not help (tools/geneo_variability.sh).  With ILU(0) every eighth iteration, as before.
+    if (it > 0 && it % refresh_period == 0) {
       if (con) DDMCHECK(harmonic_apply(ctx, con, m, S[cur], ld, true));
       DDMCHECK(apply_AC(m, S[cur], ld, AS[cur], CS[cur], ld));
+      DDMCHECK(apply_AC(m, S[cur] + 2 * m, ld, AS[cur] + 2 * m, CS[cur] + 2 * m, ld));
     }
   }
   const double t_loop = since(t_iter);
