@@ -544,7 +544,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
   const bool prec_f32 = !direct && !std::getenv("DDM_GENEO_ILU_F64");
   const int refresh_period = std::getenv("DDM_GENEO_REFRESH") ? std::max(1, std::atoi(std::getenv("DDM_GENEO_REFRESH"))) : (direct ? 2 : 8);
   // W <- W - X (A~X)^T W before the Rayleigh-Ritz step: twice with the exact T (W = A~^-1 r lies almost in span X near convergence: on
-  // the elasticity pencil one pass gave 68-81 block iterations in two of eight runs, none 133 in one, against 12-18), once with
+  // the elasticity pencil one pass gave 68-81 block iterations in two of eight runs, none 133 in one, against 12-18 -- measured before the products of P were refreshed, see below), once with
   // ILU(0) (216^3: the same 109 iterations and residuals with two, one or no pass; 5.6 / 5.2 / 4.9 s).  DDM_GENEO_ORTH_PASSES overrides.
   const int orth_passes = std::getenv("DDM_GENEO_ORTH_PASSES") ? std::max(0, std::atoi(std::getenv("DDM_GENEO_ORTH_PASSES"))) : (direct ? 2 : 1);
   const double t_prec = since(t_begin);
