@@ -71,6 +71,8 @@ struct ddm_ctx {
   hipEvent_t ev_fence = nullptr; // ddm_ctx_fence
 };
 
+static std::mutex g_err_mutex;
+static thread_local std::string t_last_error;
 static int fail(ddm_ctx *ctx, int code, const char *fmt, ...)
 {
   char buf[512];
@@ -78,13 +80,15 @@ static int fail(ddm_ctx *ctx, int code, const char *fmt, ...)
   va_start(ap, fmt);
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
+  t_last_error = buf;
   if (ctx) { // (setup phases run independent host work on helper threads that may fail at the same time)
-    static std::mutex err_mutex;
-    std::lock_guard<std::mutex> lock(err_mutex);
+    std::lock_guard<std::mutex> lock(g_err_mutex);
     ctx->err = buf;
   }
   return code;
 }
+// message of the last fail() on the CALLING thread (helper threads report their own failure, not whatever another thread wrote last)
+static std::string last_error_of_this_thread() { return t_last_error; }
 #define HIPCHECK(ctx, call)                                                                                   \
   do {                                                                                                        \
     hipError_t e_ = (call);                                                                                   \
@@ -223,7 +227,14 @@ extern "C" void ddm_ctx_destroy(ddm_ctx *ctx)
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
-extern "C" const char *ddm_last_error(const ddm_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+extern "C" const char *ddm_last_error(const ddm_ctx *ctx)
+{
+  if (!ctx) return "no context";
+  static thread_local std::string copy; // (a stable pointer for the caller; ctx->err may be rewritten by a helper thread)
+  std::lock_guard<std::mutex> lock(g_err_mutex);
+  copy = ctx->err;
+  return copy.c_str();
+}
 extern "C" int ddm_ctx_sync(ddm_ctx *ctx)
 {
   HIPCHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -693,6 +704,7 @@ static int csr_mm2_ld(ddm_ctx *ctx, const ddm_csr *A1, const ddm_csr *A2, int nr
     DDMCHECK(csr_mm_ld(ctx, A1, nrhs, X, ldx, Y1, ldy));
     return csr_mm_ld(ctx, A2, nrhs, X, ldx, Y2, ldy);
   }
+  if (A1->host_only || A2->host_only) return fail(ctx, DDM_EINVAL, "the matrix was created without device arrays (ddm_csr_create_host)");
   const int64_t threads = A1->nrows * (int64_t)(nrhs / 4);
   if (threads == 0) return DDM_OK;
   if (A1->row_order && nrhs / 4 <= 8) { // cache-blocked row order: 64 rows per workgroup
@@ -2267,7 +2279,12 @@ static int ilu0_solve_multi_ld(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double
   }
   if (F->sn) {
     const int w = std::min(nrhs, 48); // the panel kernels take up to 48 columns: wider blocks are solved in column panels
+    const double *partial_before = F->sn->d_partial;
     if (!sn::reserve(*F->sn, w)) return fail(ctx, DDM_EHIP, "sparse direct solver: allocation failed");
+    if (F->sn->d_partial != partial_before && F->graph) { // the single-vector graph's backward nodes hold the old scratch pointer
+      (void)hipGraphExecDestroy(F->graph);
+      F->graph = nullptr;
+    }
     if (F->pm_nrhs < w) {
       (void)hipFree(F->pD);
       F->pD = nullptr;
@@ -2775,6 +2792,7 @@ extern "C" int ddm_galerkin_products(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t
   // the slab layout of galerkin_preconditioner.hh:294 / helpers.hh:252)
   if (!A_dir || !left || !right || !out_host || nleft < 1 || nleft > COARSE_KMAX || nright < 1 || row0 < 0 || row1 > A_dir->nrows || row0 > row1)
     return fail(ctx, DDM_EINVAL, "ddm_galerkin_products: bad arguments");
+  if (A_dir->host_only) return fail(ctx, DDM_EINVAL, "the matrix was created without device arrays (ddm_csr_create_host)");
   const int64_t n = A_dir->nrows;
   double *y = nullptr, *partial = nullptr, *outd = nullptr;
   RowChunk *chunks = nullptr;
@@ -2796,6 +2814,7 @@ extern "C" int ddm_galerkin_products(ddm_ctx *ctx, const ddm_csr *A_dir, int64_t
     if (row1 > row0)
       hipLaunchKernelGGL(k_spmm_rowmajor, dim3((unsigned)((row1 - row0 + WG - 1) / WG)), dim3(WG), 0, ctx->stream, row1 - row0, 1, A_dir->rp + row0, A_dir->ci, A_dir->va,
                          right + j * n, (int64_t)1, y + row0, (int64_t)1);
+    if (hipGetLastError() != hipSuccess) rc = fail(ctx, DDM_EHIP, "ddm_galerkin_products: kernel launch failed");
     for (int64_t i = 0; i < nleft; ++i) cidx[i] = i;
     if (!d_cidx) rc = upload(ctx, cidx.data(), nleft, &d_cidx);
     if (rc) break;

@@ -508,7 +508,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
     ilu_thread = std::thread([&]() {
       (void)hipSetDevice(ctx->device);
       rc_ilu = ilu0_create_impl(ctx, own.At, nsub, sub_ptr, /*multi_rhs_only=*/true, &T_ilu);
-      if (rc_ilu) err_ilu = ddm_last_error(ctx);
+      if (rc_ilu) err_ilu = last_error_of_this_thread();
     });
   };
   if (P.preconditioner != 2) start_ilu();
@@ -524,7 +524,7 @@ static int geneo_run(ddm_ctx *ctx, const ddm_csr *A_neu, const ddm_csr *B_neu, i
   } else if (P.preconditioner != 1) {
     rc_direct = direct_create_impl(ctx, own.At, nsub, sub_ptr, 0, P.preconditioner == 2 ? 0.0 : P.max_direct_flops, /*setup_use=*/true, &own.T);
     if (rc_direct == DDM_OK) direct = 1;
-    else why_not = ddm_last_error(ctx);
+    else why_not = last_error_of_this_thread();
   }
   const double t_direct = since(t_begin);
   if (ilu_thread.joinable()) ilu_thread.join();
@@ -806,7 +806,9 @@ static int geneo_basis_impl(ddm_ctx *ctx, const char *who, const ddm_csr *A_neu,
     bool done = true;
     if (P.threshold > 0.0) {
       for (int64_t s = 0; s < nsub; ++s) done = done && eig[(size_t)s * nev + nev - 1] >= P.threshold;
-      done = done || nev >= P.nev_max || 2 * nev > kmax;
+      // the block eigensolver takes nev + extra <= GENEO_MAX_BLOCK vectors per subdomain: the doubling stops there and the last
+      // converged block is returned (info->nev tells the caller how far it got) instead of failing the whole basis build
+      done = done || nev >= P.nev_max || 2 * nev > kmax || 2 * nev + P.extra > GENEO_MAX_BLOCK;
     }
     if (done) {
       for (int64_t s = 0; s < nsub; ++s) {

@@ -29,11 +29,29 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "sn_chol_host.hpp"
 
 namespace sn {
+// runs f once per device (hipFuncSetAttribute is per device; callers may come from several host threads: late-comers wait
+// until the first one has finished)
+struct DeviceOnce {
+  std::mutex m;
+  uint64_t done = 0; // bit = device id
+  template <class F>
+  void run(F &&f)
+  {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    std::lock_guard<std::mutex> lock(m);
+    if (done & bit) return;
+    f();
+    done |= bit;
+  }
+};
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int TILE = 64;      // rows per panel / update tile
@@ -1248,12 +1266,11 @@ static inline hipError_t factorize(Factor &F, hipStream_t st, const int64_t *d_r
     if (F.lu) hipLaunchKernelGGL(k_sn_assemble_lu, dim3((unsigned)((F.n + 255) / 256)), dim3(256), 0, st, F.M, F.n, d_rp, d_ci, d_va, F.d_iperm);
     else hipLaunchKernelGGL(k_sn_assemble, dim3((unsigned)((F.n + 255) / 256)), dim3(256), 0, st, F.M, F.n, d_rp, d_ci, d_va, F.d_iperm);
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_once;
+  attr_once.run([]() {
     (void)hipFuncSetAttribute((const void *)k_sn_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (SN_MAX_COLS + 1) * SN_MAX_COLS * 8);
     (void)hipFuncSetAttribute((const void *)k_sn_lu_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (SN_MAX_COLS + 1) * SN_MAX_COLS * 8);
-    attr_set = true;
-  }
+  });
   for (int32_t l = 0; l < F.nlev; ++l) {
     const int32_t cnt = F.lev_ptr[(size_t)l + 1] - F.lev_ptr[(size_t)l];
     if (cnt == 0) continue;
@@ -1321,13 +1338,12 @@ static inline void solve_t(const Factor &F, hipStream_t st, int m, double *B, in
     }
     return;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_once; // (one per instantiation: LU / Cholesky)
+  attr_once.run([]() {
     (void)hipFuncSetAttribute((const void *)k_sn_fwd_diag<LU>, hipFuncAttributeMaxDynamicSharedMemorySize, SN_MAX_COLS * 48 * 8);
     (void)hipFuncSetAttribute((const void *)k_sn_fwd_update, hipFuncAttributeMaxDynamicSharedMemorySize, SN_MAX_COLS * 48 * 8);
     (void)hipFuncSetAttribute((const void *)k_sn_bwd_diag<LU>, hipFuncAttributeMaxDynamicSharedMemorySize, (SN_MAX_COLS + TILE) * 48 * 8);
-    attr_set = true;
-  }
+  });
   const int mpad = ((m + 15) / 16) * 16;
   for (int32_t l = 0; l < F.nlev; ++l) {
     const int32_t cnt = F.lev_ptr[(size_t)l + 1] - F.lev_ptr[(size_t)l];

@@ -1,24 +1,23 @@
-// MI355X drop-in for dune/ddm/twolevel_schwarz.hh (TwoLevelSchwarzSolver, the PDELab linear-solver backend handed to
-// StationaryLinearProblemSolver / Newton by examples/convectiondiffusiondg.cc:75-78 and nonlinearpoisson.cc:151-154).
+// MI355X adaptor for the PDELab linear-solver backend of the reference (class TwoLevelSchwarzSolver, dune/ddm/twolevel_schwarz.hh:27-174;
+// handed to StationaryLinearProblemSolver / Newton by examples/convectiondiffusiondg.cc:75-78 and nonlinearpoisson.cc:151-154).
 //
-// The reference's apply() has two halves:
-//   (1) first call only (twolevel_schwarz.hh:93-128): overlap extension, overlapping matrix, partition of unity, template vectors
-//       extended to the overlapping index set -- host code of the layer BEFORE the hot path (overlap_extension.hh, datahandles.hh,
-//       pou.hh), used unchanged in a DUNE build;
-//   (2) every call (:131-168): POUCoarseSpace -> SchwarzPreconditioner ("fine") + GalerkinPreconditioner ("coarse") in a
-//       CombinedPreconditioner whose mode key sits in the sub-tree itself, NonOverlappingOperator, solver from the "solver"
-//       sub-tree (default restarted GMRES(30), maxit 1000), right-hand side made consistent, solve, result stored.
-// Half (2) is ddm_hip::TwoLevelSchwarzCore below, written on native dune-istl types only, so that it compiles (and is tested,
-// tests/cpp/twolevel_adaptor.cc) without PDELab; the outer Krylov loop runs on the device (Dune::getHipSolver in place of
-// Dune::getSolverFromFactory: one upload and one download per solve).  TwoLevelSchwarzSolver at the end of the file is the
-// PDELab-facing class with the reference's constructor / apply / norm signatures; it needs dune-pdelab and the reference's own
-// setup headers and is therefore only compiled in a DUNE build (HAVE_DUNE_PDELAB).
+// Layout of this file
+//   ddm_hip::krylov_settings        the "solver" sub-tree of one solve, with the backend's defaults (reference :119-131)
+//   ddm_hip::TwoLevelSchwarzCore    what happens on EVERY apply(): the two levels are rebuilt around the current matrix, the Krylov
+//                                   loop runs on the device, one upload and one download per solve.  Native dune-istl types only, so it
+//                                   compiles and is GPU-tested without PDELab (tests/cpp/twolevel_adaptor.cc).
+//   ddm_hip::OverlapObjects         (HAVE_DUNE_PDELAB) the overlapping matrix / communication / partition of unity of a rank, produced
+//                                   by the REFERENCE's own host setup headers (overlap_extension.hh, datahandles.hh, pou.hh): that layer
+//                                   sits before the hot path and is used as it is in a DUNE build -- INTEGRATION.md, "PDELab backend".
+//   TwoLevelSchwarzSolver           (HAVE_DUNE_PDELAB) the class PDELab sees: constructor, apply, norm and the result storage of the
+//                                   reference (:38-56, :58, :149); owns an OverlapObjects and a TwoLevelSchwarzCore and forwards to them.
 #pragma once
 
-#include <cmath>
+#include <array>
 #include <cstddef>
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include <dune/common/parametertree.hh>
@@ -35,74 +34,67 @@
 
 namespace ddm_hip {
 
+// Settings of the outer Krylov solver for one apply(): the "solver" sub-tree when the user wrote one, otherwise restarted GMRES(30)
+// with at most 1000 iterations; only the root rank may print; the reduction PDELab asks for is passed down as a key as well.
+inline Dune::ParameterTree krylov_settings(const Dune::ParameterTree& backend_cfg, double reduction, bool root_rank)
+{
+  Dune::ParameterTree s;
+  if (backend_cfg.hasSub("solver")) s = backend_cfg.sub("solver");
+  else {
+    s["type"] = "restartedgmressolver";
+    s["restart"] = "30";
+    s["maxit"] = "1000";
+  }
+  const std::string wanted = s.get("verbose", std::string("0"));
+  s["verbose"] = root_rank ? wanted : std::string("0");
+  s["reduction"] = std::to_string(reduction);
+  return s;
+}
+
 template <class NativeMat, class NativeVec, class Communication>
 class TwoLevelSchwarzCore {
 public:
-  using FineLevel = SchwarzPreconditioner<NativeMat, NativeVec, Communication>;     // twolevel_schwarz.hh:34
-  using CoarseLevel = GalerkinPreconditioner<NativeVec, Communication>;              // :35
-  using Op = NonOverlappingOperator<NativeMat, NativeVec, NativeVec, Communication>;   // :88
+  using FineLevel = SchwarzPreconditioner<NativeMat, NativeVec, Communication>;
+  using CoarseLevel = GalerkinPreconditioner<NativeVec, Communication>;
+  using Operator = NonOverlappingOperator<NativeMat, NativeVec, NativeVec, Communication>;
+  using Levels = CombinedPreconditioner<NativeVec>;
 
-  TwoLevelSchwarzCore(std::shared_ptr<Communication> novlp_comm_, const Dune::ParameterTree& subtree_) : novlp_comm(std::move(novlp_comm_)), subtree(subtree_) {}
+  TwoLevelSchwarzCore(std::shared_ptr<Communication> nonoverlapping, const Dune::ParameterTree& backend_cfg) : novlp(std::move(nonoverlapping)), cfg(backend_cfg) {}
 
-  // the objects the first apply() of the reference builds once (:93-128)
-  void set_overlapping(std::shared_ptr<NativeMat> A_ovlp_, std::shared_ptr<Communication> ovlp_comm_, std::shared_ptr<PartitionOfUnity> pou_,
-                       std::vector<NativeVec> extended_template_vecs)
+  // The rank's overlapping objects; they outlive the solves (the matrix VALUES may be refreshed in place between two calls).
+  void set_overlapping(std::shared_ptr<NativeMat> matrix, std::shared_ptr<Communication> communication, std::shared_ptr<PartitionOfUnity> partition,
+                       std::vector<NativeVec> templates_on_overlap)
   {
-    A_ovlp = std::move(A_ovlp_);
-    ovlp_comm = std::move(ovlp_comm_);
-    pou = std::move(pou_);
-    native_template_vecs = std::move(extended_template_vecs);
-    for (const auto& v : native_template_vecs)
-      if (v.N() != A_ovlp->N()) DUNE_THROW(Dune::Exception, "Template vectors must match size of matrix");
+    for (const auto& t : templates_on_overlap)
+      if (t.N() != matrix->N()) DUNE_THROW(Dune::Exception, "Template vectors must match size of matrix");
+    ovlp = Overlapping{std::move(matrix), std::move(communication), std::move(partition), std::move(templates_on_overlap)};
   }
-  bool has_overlapping() const { return (bool)ovlp_comm; }
-  const std::shared_ptr<NativeMat>& overlapping_matrix() const { return A_ovlp; }
-  const std::shared_ptr<Communication>& overlapping_communication() const { return ovlp_comm; }
+  bool has_overlapping() const { return (bool)ovlp.comm; }
+  const std::shared_ptr<NativeMat>& overlapping_matrix() const { return ovlp.matrix; }
+  const std::shared_ptr<Communication>& overlapping_communication() const { return ovlp.comm; }
 
-  // twolevel_schwarz.hh:131-168.  A: the (additive) non-overlapping matrix; d: right-hand side, overwritten by the defect.
+  // One linear solve A z = d to the given reduction.  A is the additive non-overlapping matrix; d is made consistent in place
+  // (every holder of a shared DoF ends with the sum) because operator, scalar product and both levels work on consistent vectors,
+  // and the solver then leaves the final defect in it.
   Dune::InverseOperatorResult solve(std::shared_ptr<NativeMat> A, NativeVec& z, NativeVec& d, double reduction)
   {
     if (!has_overlapping()) DUNE_THROW(Dune::InvalidStateException, "TwoLevelSchwarzCore::solve before set_overlapping");
-    // Set up the preconditioner (:105-116)
-    POUCoarseSpace<NativeVec> coarse_space(native_template_vecs, *pou);
-    fine = std::make_shared<FineLevel>(A_ovlp, ovlp_comm, pou, subtree, "fine");
-    fine->novlp_comm = novlp_comm;   // :109
-    coarse = std::make_shared<CoarseLevel>(*A_ovlp, coarse_space.get_basis(), ovlp_comm, subtree, "coarse");
-    auto prec = std::make_shared<CombinedPreconditioner<NativeVec>>(subtree, "");
-    auto op = std::make_shared<Op>(std::move(A), novlp_comm);
-    prec->set_op(op);
-    prec->add(fine);
-    prec->add(coarse);
-
-    // Set up the solver (:119-131)
-    const int rank = ovlp_comm->communicator().rank();
-    Dune::ParameterTree solver_subtree;
-    if (subtree.hasSub("solver")) solver_subtree = subtree.sub("solver");
-    else {
-      solver_subtree["type"] = "restartedgmressolver";
-      solver_subtree["restart"] = "30";
-      solver_subtree["maxit"] = "1000";
-      solver_subtree["verbose"] = "0";
-    }
-    solver_subtree["verbose"] = rank == 0 ? solver_subtree.get("verbose", std::string("0")) : std::string("0");   // verbosity on the root rank only
-    solver_subtree["reduction"] = std::to_string(reduction);
-    auto solver = Dune::getHipSolver<NativeVec>(op, solver_subtree, prec);   // getSolverFromFactory(op, solver_subtree, prec) (:133)
-
-    // Make the rhs consistent (this is how the preconditioner, nonoverlapping operator and scalar product expect it) (:136-137)
-    novlp_comm->addOwnerCopyToAll(d, d);
-
-    // Solve the linear system (:140-141)
-    Dune::InverseOperatorResult stat;
-    solver->apply(z, d, reduction, stat);
-    return stat;
+    auto op = std::make_shared<Operator>(std::move(A), novlp);
+    auto levels = build_levels(op);
+    const bool root = ovlp.comm->communicator().rank() == 0;
+    auto krylov = Dune::getHipSolver<NativeVec>(op, krylov_settings(cfg, reduction, root), levels);
+    novlp->addOwnerCopyToAll(d, d);
+    Dune::InverseOperatorResult outcome;
+    krylov->apply(z, d, reduction, outcome);
+    return outcome;
   }
 
-  // TwoLevelSchwarzSolver::norm (:149-158): consistent copy, then the owner-masked norm
-  double norm(const NativeVec& v) const
+  // Global 2-norm of an ADDITIVE vector: summed over the holders first, then counted once per owner.
+  double norm(const NativeVec& additive) const
   {
-    auto x = v;
-    novlp_comm->addOwnerCopyToOwnerCopy(x, x);
-    return novlp_comm->norm(x);
+    NativeVec consistent = additive;
+    novlp->addOwnerCopyToOwnerCopy(consistent, consistent);
+    return novlp->norm(consistent);
   }
 
   // the levels of the last solve (inspection / tests)
@@ -110,23 +102,39 @@ public:
   std::shared_ptr<CoarseLevel> coarse;
 
 private:
-  std::shared_ptr<Communication> novlp_comm, ovlp_comm;
-  std::shared_ptr<NativeMat> A_ovlp;
-  std::shared_ptr<PartitionOfUnity> pou;
-  std::vector<NativeVec> native_template_vecs;
-  Dune::ParameterTree subtree;
+  struct Overlapping {
+    std::shared_ptr<NativeMat> matrix;
+    std::shared_ptr<Communication> comm;
+    std::shared_ptr<PartitionOfUnity> pou;
+    std::vector<NativeVec> templates;
+  };
+
+  // "fine" = Schwarz level on the overlapping matrix (it also needs the non-overlapping communication for its restriction),
+  // "coarse" = Galerkin level on the partition-of-unity-weighted template vectors; how the two are combined is the "mode" key of the
+  // backend's own sub-tree, which is why the combination is configured with an empty sub-tree name.
+  std::shared_ptr<Levels> build_levels(const std::shared_ptr<Operator>& op)
+  {
+    fine = std::make_shared<FineLevel>(ovlp.matrix, ovlp.comm, ovlp.pou, cfg, "fine");
+    fine->novlp_comm = novlp;
+    const POUCoarseSpace<NativeVec> space(ovlp.templates, *ovlp.pou);
+    coarse = std::make_shared<CoarseLevel>(*ovlp.matrix, space.get_basis(), ovlp.comm, cfg, "coarse");
+    auto both = std::make_shared<Levels>(cfg, "");
+    both->set_op(op);
+    both->add(fine);
+    both->add(coarse);
+    return both;
+  }
+
+  std::shared_ptr<Communication> novlp;
+  Dune::ParameterTree cfg;
+  Overlapping ovlp;
 };
 
 }  // namespace ddm_hip
 
 #if HAVE_DUNE_PDELAB
-// ---- PDELab-facing class: same constructor, apply and norm as the reference (twolevel_schwarz.hh:27-174) -----------------------
-// Needs dune-pdelab and the reference's host setup headers (make_communication, make_overlapping_communication, the matrix data
-// handles, PartitionOfUnity, make_additive): compiled in a DUNE build only.
-#include <dune/ddm/datahandles.hh>
-#include <dune/ddm/overlap_extension.hh>
-#include <dune/ddm/pdelab_helper.hh>
-
+#include <dune/common/ftraits.hh>
+#include <dune/common/parallel/interface.hh>
 #include <dune/common/parallel/variablesizecommunicator.hh>
 #include <dune/istl/owneroverlapcopy.hh>
 #include <dune/pdelab/backend/interface.hh>
@@ -134,76 +142,119 @@ private:
 #include <dune/pdelab/constraints/common/constraints.hh>
 #include <dune/pdelab/gridfunctionspace/interpolate.hh>
 
+// the reference's host setup layer (SURVEY 8 f-1 restates it in dune-ddm_amd/setup_dist.py for the tests; a DUNE build uses the originals)
+#include <dune/ddm/datahandles.hh>
+#include <dune/ddm/overlap_extension.hh>
+#include <dune/ddm/pdelab_helper.hh>
+
+namespace ddm_hip {
+
+// Overlapping objects of one rank, made by the reference's setup functions.  create() is the expensive first-call path (index-set
+// extension by `overlap` layers, sparsity pattern + values of the overlapping matrix, partition of unity); refresh() re-sends the
+// values only, for the later Newton steps, on the pattern and the communication plan create() left behind.
+template <class NativeMat, class NativeVec, class Communication>
+class OverlapObjects {
+public:
+  std::shared_ptr<NativeMat> matrix;
+  std::shared_ptr<Communication> comm;
+  std::shared_ptr<PartitionOfUnity> pou;
+
+  bool ready() const { return (bool)comm; }
+
+  void create(const Communication& nonoverlapping, const NativeMat& A, const Dune::ParameterTree& backend_cfg)
+  {
+    const int layers = backend_cfg.get("overlap", 1);
+    comm = make_overlapping_communication(nonoverlapping, A, layers).first;
+    const typename Communication::AllSet everyone;
+    plan.build(comm->remoteIndices(), everyone, everyone);
+    exchange = std::make_unique<Dune::VariableSizeCommunicator<>>(plan);
+    CreateMatrixDataHandle pattern(A, comm->indexSet());
+    exchange->forward(pattern);
+    matrix = std::make_shared<NativeMat>(pattern.getOverlappingMatrix());
+    send_values(A);
+    pou = std::make_shared<PartitionOfUnity>(*matrix, *comm, backend_cfg.sub("pou"), layers);
+  }
+
+  void refresh(const NativeMat& A)
+  {
+    *matrix = 0;
+    send_values(A);
+  }
+
+  // a vector on the rank's own DoFs continued onto the overlap: own part copied, the rest filled with the owners' values
+  NativeVec extended(const NativeVec& own) const
+  {
+    NativeVec e(matrix->N());
+    e = 0;
+    for (std::size_t k = 0; k < own.N(); ++k) e[k] = own[k];
+    comm->copyOwnerToAll(e, e);
+    return e;
+  }
+
+private:
+  void send_values(const NativeMat& A)
+  {
+    AddMatrixDataHandle values(A, *matrix, comm->indexSet());
+    exchange->forward(values);
+  }
+  Dune::Interface plan;
+  std::unique_ptr<Dune::VariableSizeCommunicator<>> exchange;
+};
+
+}  // namespace ddm_hip
+
 template <class Mat, class Vec>
 class TwoLevelSchwarzSolver : public Dune::PDELab::LinearResultStorage {
   using NativeMat = Dune::PDELab::Backend::Native<Mat>;
   using NativeVec = Dune::PDELab::Backend::Native<Vec>;
   using Communication = Dune::OwnerOverlapCopyCommunication<std::size_t, int>;
-  using Core = ddm_hip::TwoLevelSchwarzCore<NativeMat, NativeVec, Communication>;
+  using Real = typename Dune::template FieldTraits<typename Vec::ElementType>::real_type;
 
 public:
+  // Same arguments as the reference's constructor.  The coarse space is spanned by the bilinear monomials 1, x, y, xy of the
+  // function space, with constrained DoFs set to zero; they are kept as native vectors until the first apply() knows the overlap.
   template <class GFS, class CC>
   explicit TwoLevelSchwarzSolver(const GFS& gfs, const CC& cc, const Dune::ParameterTree& ptree, const std::string& subtree_name = "twolevelschwarz",
                                  bool matrix_is_additive = true)
-      : novlp_comm(make_communication(gfs)), subtree(ptree.sub(subtree_name)), matrix_is_additive(matrix_is_additive), core(novlp_comm, subtree)
+      : novlp_comm(make_communication(gfs)), cfg(ptree.sub(subtree_name)), additive_input(matrix_is_additive), core(novlp_comm, cfg)
   {
-    using Dune::PDELab::Backend::native;
-    // the template vectors 1, x, y, xy with the constrained DoFs zeroed (:68-81)
-    std::vector<Vec> template_vecs(4, gfs);
-    Dune::PDELab::interpolate([](auto&&) { return 1; }, gfs, template_vecs[0]);
-    Dune::PDELab::interpolate([](auto&& x) { return x[0]; }, gfs, template_vecs[1]);
-    Dune::PDELab::interpolate([](auto&& x) { return x[1]; }, gfs, template_vecs[2]);
-    Dune::PDELab::interpolate([](auto&& x) { return x[0] * x[1]; }, gfs, template_vecs[3]);
-    for (auto& v : template_vecs) Dune::PDELab::set_constrained_dofs(cc, 0., v);
-    for (auto& v : template_vecs) native_template_vecs.push_back(native(v));
+    const std::array<std::array<int, 2>, 4> exponents = {{{0, 0}, {1, 0}, {0, 1}, {1, 1}}};
+    for (const auto& e : exponents) {
+      Vec monomial(gfs);
+      Dune::PDELab::interpolate([e](const auto& x) { return (e[0] ? x[0] : 1.0) * (e[1] ? x[1] : 1.0); }, gfs, monomial);
+      Dune::PDELab::set_constrained_dofs(cc, 0., monomial);
+      templates.push_back(Dune::PDELab::Backend::native(monomial));
+    }
   }
 
-  void apply(Mat& A, Vec& z, Vec& r, typename Dune::template FieldTraits<typename Vec::ElementType>::real_type reduction)
+  void apply(Mat& A, Vec& z, Vec& r, Real reduction)
   {
     using Dune::PDELab::Backend::native;
-    if (!matrix_is_additive) ::make_additive(A, *novlp_comm);   // :90
-    if (!core.has_overlapping()) {                               // :93-128
-      const int overlap = subtree.get("overlap", 1);
-      auto ovlp_comm = make_overlapping_communication(*novlp_comm, native(A), overlap).first;
-      typename Communication::AllSet allset;
-      interface_ext.build(ovlp_comm->remoteIndices(), allset, allset);
-      varcomm = std::make_unique<Dune::VariableSizeCommunicator<>>(interface_ext);
-      CreateMatrixDataHandle cmdh(native(A), ovlp_comm->indexSet());
-      varcomm->forward(cmdh);
-      auto A_ovlp = std::make_shared<NativeMat>(cmdh.getOverlappingMatrix());
-      AddMatrixDataHandle amdh(native(A), *A_ovlp, ovlp_comm->indexSet());
-      varcomm->forward(amdh);
-      auto pou = std::make_shared<PartitionOfUnity>(*A_ovlp, *ovlp_comm, subtree.sub("pou"), overlap);
-      std::vector<NativeVec> extended(native_template_vecs.size(), NativeVec(A_ovlp->N()));
-      for (std::size_t i = 0; i < native_template_vecs.size(); ++i) {
-        extended[i] = 0;
-        for (std::size_t j = 0; j < native_template_vecs[i].N(); ++j) extended[i][j] = native_template_vecs[i][j];
-        ovlp_comm->copyOwnerToAll(extended[i], extended[i]);
-      }
-      core.set_overlapping(A_ovlp, ovlp_comm, pou, std::move(extended));
+    if (!additive_input) ::make_additive(A, *novlp_comm);
+    if (overlap.ready()) overlap.refresh(native(A));
+    else {
+      overlap.create(*novlp_comm, native(A), cfg);
+      std::vector<NativeVec> on_overlap;
+      for (const auto& t : templates) on_overlap.push_back(overlap.extended(t));
+      core.set_overlapping(overlap.matrix, overlap.comm, overlap.pou, std::move(on_overlap));
     }
-    else {   // update the overlapping matrix for subsequent calls (:122-127)
-      *core.overlapping_matrix() = 0;
-      AddMatrixDataHandle amdh(native(A), *core.overlapping_matrix(), core.overlapping_communication()->indexSet());
-      varcomm->forward(amdh);
-    }
-    const auto stat = core.solve(A.storage(), native(z), native(r), reduction);   // :131-141
-    res.converged = stat.converged;
-    res.iterations = stat.iterations;
-    res.elapsed = stat.elapsed;
-    res.reduction = stat.reduction;
-    res.conv_rate = stat.conv_rate;
+    const Dune::InverseOperatorResult outcome = core.solve(A.storage(), native(z), native(r), reduction);
+    res.converged = outcome.converged;
+    res.iterations = outcome.iterations;
+    res.elapsed = outcome.elapsed;
+    res.reduction = outcome.reduction;
+    res.conv_rate = outcome.conv_rate;
   }
 
   typename Vec::ElementType norm(const Vec& v) const { return core.norm(Dune::PDELab::Backend::native(v)); }
 
 private:
+  using Core = ddm_hip::TwoLevelSchwarzCore<NativeMat, NativeVec, Communication>;
   std::shared_ptr<Communication> novlp_comm;
-  Dune::ParameterTree subtree;
-  bool matrix_is_additive;
+  Dune::ParameterTree cfg;
+  bool additive_input;
   Core core;
-  Dune::Interface interface_ext;
-  std::unique_ptr<Dune::VariableSizeCommunicator<>> varcomm;
-  std::vector<NativeVec> native_template_vecs;
+  ddm_hip::OverlapObjects<NativeMat, NativeVec, Communication> overlap;
+  std::vector<NativeVec> templates;
 };
 #endif   // HAVE_DUNE_PDELAB

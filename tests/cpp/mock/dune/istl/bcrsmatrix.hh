@@ -52,6 +52,12 @@ public:
   {
     for (std::size_t k = 0; k < v.size(); ++k) va[k][0][0] = v[k];
   }
+  BCRSMatrix& operator=(double x)   // scalar assignment: every stored entry
+  {
+    for (auto& b : va) b[0][0] = x;
+    return *this;
+  }
+  void copy_values_from(const BCRSMatrix& o) { va = o.va; }   // (stand-in only: same pattern assumed)
   std::size_t N() const { return n; }
   std::size_t M() const { return m; }
   std::size_t nonzeroes() const { return ci.size(); }

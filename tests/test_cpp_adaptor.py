@@ -22,7 +22,8 @@ def test_adaptors_compile_and_link(ddm):
     assert os.path.exists(exe)
     # every C-ABI symbol the adaptors use must be exported by the library
     assert os.path.exists(os.path.join(CPP, "mpi_exchange_check.o"))   # mpi_exchange.hh compiles against the image's MPI headers (-DHAVE_MPI=1)
-    for e in (exe, os.path.join(CPP, "geneo_adaptor"), os.path.join(CPP, "coarse_adaptor"), os.path.join(CPP, "twolevel_adaptor")):
+    for e in (exe, os.path.join(CPP, "geneo_adaptor"), os.path.join(CPP, "coarse_adaptor"), os.path.join(CPP, "twolevel_adaptor"),
+              os.path.join(CPP, "twolevel_pdelab")):   # (the last one: the PDELab-facing class compiled with HAVE_DUNE_PDELAB=1)
         out = subprocess.run(["nm", "-D", "--undefined-only", e], capture_output=True, text=True).stdout
         used = sorted({ln.split()[-1] for ln in out.splitlines() if " ddm_" in ln})
         assert used and all(u in ddm.SYMBOLS for u in used), [u for u in used if u not in ddm.SYMBOLS]
@@ -247,3 +248,18 @@ def test_twolevel_schwarz_solver_adaptor(ddm, tmp_path, cfg):
     assert np.array_equal(z0, z1)
     assert np.abs(z0 - xo[0]).max() <= 1e-6 * np.abs(xo[0]).max()
     assert red <= 1e-8
+    # The PDELab-facing class of the same header (HAVE_DUNE_PDELAB=1; stand-in PDELab containers and single-process stand-ins of the
+    # reference's setup layer, tests/cpp/mock/dune/{pdelab,ddm}): constructor from function space + constraints, first apply() creating
+    # the overlapping objects, second one refreshing the matrix values, norm(), the result storage -- must reproduce the core's
+    # vectors bit for bit (one rank: the partition of unity is 1 everywhere, as in pou.bin).
+    assert np.all(sd.pou == 1.0)
+    q = subprocess.run([os.path.join(CPP, "twolevel_pdelab"), str(tmp_path), mode, local, krylov], capture_output=True, text=True, timeout=300)
+    assert q.returncode == 0, q.stdout[-2000:] + q.stderr[-2000:]
+    pl = [ln.split() for ln in q.stdout.splitlines() if ln.startswith("solve ")]
+    assert len(pl) == 2 and pl[0][2:] == pl[1][2:] and pl[0][2:10] == lines[0][2:10], (pl, lines)
+    zp0 = np.fromfile(tmp_path / "zp0.bin", dtype=np.float64)
+    zp1 = np.fromfile(tmp_path / "zp1.bin", dtype=np.float64)
+    assert np.array_equal(zp0, z0) and np.array_equal(zp1, z0)
+    extra = {ln.split()[0]: ln.split() for ln in q.stdout.splitlines() if ln.startswith(("nonadditive_input", "constrained"))}
+    assert extra["nonadditive_input"][2] == str(its) and extra["nonadditive_input"][4] == "1"
+    assert extra["constrained"][4] == "1"

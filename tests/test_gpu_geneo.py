@@ -305,6 +305,9 @@ def test_host_only_matrix_objects(ddm):
     X = torch.ones((M.shape[0], 4), dtype=torch.float64, device="cuda")
     with pytest.raises(RuntimeError, match="without device arrays"):
         H.mm(X, torch.empty_like(X))
+    V = torch.ones((2, M.shape[0]), dtype=torch.float64, device="cuda")
+    with pytest.raises(RuntimeError, match="without device arrays"):
+        ddm.galerkin_products(ctx, H, V, V, 0, M.shape[0])
     F = ddm.Ilu0(ctx, H)                                  # ILU(0) factorises on the host and uploads its own schedule: fine
     F.solve(x, y)
     G = ddm.Ilu0(ctx, ddm.CsrMatrix(ctx, M))

@@ -81,6 +81,33 @@ def test_device_cholesky_matches_superlu(ddm, torch_cuda, device_engine, shape, 
     ctx.close()
 
 
+def test_device_single_solve_survives_wider_multi_solve(ddm, torch_cuda, device_engine):
+    """the single-vector HIP graph holds the backward sweep's scratch pointer; a block solve in between re-allocates that
+    scratch for more columns.  The SAME d / x tensors are used before and after, so a stale graph would be replayed as is."""
+    import torch
+    dec, rl = _blocks(ddm, (21, 20, 19), (2, 2, 2))
+    ctx = ddm.torch_context(0)
+    F = ddm.Ilu0(ctx, ddm.CsrMatrix(ctx, rl.A_dir), rl.block_ptr, direct=True)
+    n = rl.n
+    rng = np.random.default_rng(17)
+    d = torch.as_tensor(rng.standard_normal(n)).cuda()
+    x = torch.zeros(n, dtype=torch.float64, device="cuda")
+    F.solve(d, x)
+    ctx.sync()
+    x0 = x.clone()
+    for m in (24, 48):
+        B = torch.as_tensor(rng.standard_normal((n, m))).cuda()
+        X = torch.zeros((n, m), dtype=torch.float64, device="cuda")
+        F.solve_multi(B, X)
+        ctx.sync()
+        x.zero_()
+        F.solve(d, x)                                      # same pointers as the captured graph
+        ctx.sync()
+        assert F.status() == 0
+        assert (x - x0).abs().max().item() <= 1e-12 * x0.abs().max().item()
+    ctx.close()
+
+
 def test_device_cholesky_rejects_indefinite_matrix(ddm, torch_cuda, device_engine):
     dec, rl = _blocks(ddm, (13, 12, 11), (1, 1, 1), overlap=1)
     M = sp.csr_matrix(rl.A_dir).copy()
