@@ -221,7 +221,7 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         engine = os.environ.get("DDM_TRSV_MODE", "pipe") if args.local_solver == "ilu0" else "direct"
         kname = {"levels": "k_trsv_lower_level + k_trsv_upper_level + k_trsv_small_levels (one launch per level, HIP graph)",
-                 "xcd2": "k_trsv_xcd2", "direct": "sparse direct factor (sn_chol.hpp panel solves or CSR level solves)"}.get(engine, "k_trsv_pipe (+ k_pipe_permute_in/out)")
+                 "xcd2": "k_trsv_xcd2", "direct": "sparse direct factor (sn_chol.hpp panel solves or CSR level solves)"}.get(engine, "k_trsv_pipe (+ k_pipe_permute_out)")
         traffic, traffic_source = None, None
         try:   # HBM bytes per launch: NOT measured in this run -- read from the committed rocprofv3 --pmc passes of this command
             #    (profiles/, separate FETCH_SIZE / WRITE_SIZE runs, gfx950-corrected: 2 x FETCH_SIZE + WRITE_SIZE); the file is named in the line

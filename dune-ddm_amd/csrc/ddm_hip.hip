@@ -816,8 +816,8 @@ struct ddm_ilu0 {
   pipe::Group *p_groups = nullptr;
   pipe::Task *p_tasks = nullptr;
   unsigned char *p_stream = nullptr;
-  int32_t *p_koff = nullptr, *p_rowL = nullptr, *p_posU = nullptr, *p_rowU = nullptr; // p_rowU: natural row of every U position (-1: padding)
-  double *p_dperm = nullptr, *p_ypos = nullptr, *p_xpos = nullptr;
+  int32_t *p_koff = nullptr, *p_posU = nullptr, *p_rowU = nullptr; // p_rowU: natural row of every U position (-1: padding)
+  double *p_ypos = nullptr, *p_xpos = nullptr;
   unsigned long long *p_progress = nullptr;
   unsigned *p_queue = nullptr;
   int64_t p_nposL = 0, p_nposU = 0;
@@ -1777,10 +1777,8 @@ extern "C" void ddm_ilu0_destroy(ddm_ilu0 *F)
   (void)hipFree(F->p_tasks);
   (void)hipFree(F->p_stream);
   (void)hipFree(F->p_koff);
-  (void)hipFree(F->p_rowL);
   (void)hipFree(F->p_posU);
   (void)hipFree(F->p_rowU);
-  (void)hipFree(F->p_dperm);
   (void)hipFree(F->p_ypos);
   (void)hipFree(F->p_xpos);
   (void)hipFree(F->p_progress);
@@ -1963,14 +1961,12 @@ static int build_pipe_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
   DDMCHECK(upload(ctx, S.tasks.data(), (int64_t)S.tasks.size(), &F->p_tasks));
   DDMCHECK(upload(ctx, S.stream.data(), (int64_t)S.stream.size(), &F->p_stream));
   DDMCHECK(upload(ctx, S.koff.data(), (int64_t)S.koff.size(), &F->p_koff));
-  DDMCHECK(upload(ctx, S.rowL.data(), (int64_t)S.rowL.size(), &F->p_rowL));
   DDMCHECK(upload(ctx, S.posU.data(), (int64_t)S.posU.size(), &F->p_posU));
   {
     std::vector<int32_t> rowU((size_t)std::max<int64_t>(S.nposU, 1), -1);
     for (size_t i = 0; i < S.posU.size(); ++i) rowU[(size_t)S.posU[i]] = (int32_t)i;
     DDMCHECK(upload(ctx, rowU.data(), (int64_t)rowU.size(), &F->p_rowU));
   }
-  HIPCHECK(ctx, hipMalloc((void **)&F->p_dperm, sizeof(double) * (size_t)std::max<int64_t>(S.nposL, 1)));
   HIPCHECK(ctx, hipMalloc((void **)&F->p_ypos, sizeof(double) * (size_t)std::max<int64_t>(S.nposL, 1)));
   HIPCHECK(ctx, hipMalloc((void **)&F->p_xpos, sizeof(double) * (size_t)std::max<int64_t>(S.nposU, 1)));
   HIPCHECK(ctx, hipMemset(F->p_ypos, 0, sizeof(double) * (size_t)std::max<int64_t>(S.nposL, 1)));
@@ -2016,7 +2012,7 @@ static void enqueue_pipe(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, 
   P.tasks = F->p_tasks;
   P.stream = F->p_stream;
   P.koff = F->p_koff;
-  P.dperm = F->p_dperm;
+  P.d = d;
   P.ypos = F->p_ypos;
   P.xpos = F->p_xpos;
   P.progress = F->p_progress;
@@ -2026,7 +2022,6 @@ static void enqueue_pipe(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, 
   P.stamps = stamps;
   P.spread = F->p_spread;
   hipLaunchKernelGGL(k_pipe_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate, F->p_queue, F->ngroups * 4);
-  hipLaunchKernelGGL(k_pipe_permute_in, dim3(perm_grid(ctx, F->p_nposL)), dim3(PERM_WG), 0, ctx->stream, F->p_nposL, F->p_rowL, d, F->p_dperm);
   if (stamps) hipLaunchKernelGGL((k_trsv_pipe<true>), dim3(F->p_grid), dim3(64 * (PIPE_NC + PIPE_NL)), PIPE_LDS_BYTES, ctx->stream, P);
   else hipLaunchKernelGGL((k_trsv_pipe<false>), dim3(F->p_grid), dim3(64 * (PIPE_NC + PIPE_NL)), PIPE_LDS_BYTES, ctx->stream, P);
   hipLaunchKernelGGL(k_pipe_permute_out, dim3(perm_grid(ctx, F->p_nposU)), dim3(PERM_WG), 0, ctx->stream, F->p_nposU, F->p_rowU, (const double *)F->p_xpos, x, scale, add);

@@ -98,22 +98,34 @@ __device__ __forceinline__ const double *pipe_uniform_ptr(const double *p)
 // The asm blocks start with s_nop 4: if the compiler has just restored a base pointer with v_readlane / v_readfirstlane
 // (a VALU write of an SGPR), a VMEM instruction may only read it 5 wait states later, and the hazard recognizer does not
 // look into inline asm.
+// RHS_SC1: the right-hand side entry is read past the L1 (backward sweep: the forward results were written by other waves of this
+// launch); the forward sweep reads the caller's vector, which nobody writes during the launch: through the L1, where a lane finds
+// the cache line of its grid line again for 16 steps.
+#define PIPE_GATHER8_REST                       \
+  "global_load_dwordx2 %1, %9, %17 sc1\n\t"  \
+  "global_load_dwordx2 %2, %10, %17 sc1\n\t" \
+  "global_load_dwordx2 %3, %11, %17 sc1\n\t" \
+  "global_load_dwordx2 %4, %12, %17 sc1\n\t" \
+  "global_load_dwordx2 %5, %13, %17 sc1\n\t" \
+  "global_load_dwordx2 %6, %14, %17 sc1\n\t" \
+  "global_load_dwordx2 %7, %15, %17 sc1"
+template <bool RHS_SC1>
 __device__ __forceinline__ void pipe_gather_asm8(const double *rhs_uniform, uint32_t own, const double *src_uniform, const uint32_t (&off)[PIPE_CHUNK], double &s0,
                                                  double (&x)[PIPE_CHUNK])
 {
   static_assert(PIPE_CHUNK == 14, "operand lists below");
-  asm volatile("s_nop 4\n\t"
-               "global_load_dwordx2 %0, %8, %16 sc1\n\t"
-               "global_load_dwordx2 %1, %9, %17 sc1\n\t"
-               "global_load_dwordx2 %2, %10, %17 sc1\n\t"
-               "global_load_dwordx2 %3, %11, %17 sc1\n\t"
-               "global_load_dwordx2 %4, %12, %17 sc1\n\t"
-               "global_load_dwordx2 %5, %13, %17 sc1\n\t"
-               "global_load_dwordx2 %6, %14, %17 sc1\n\t"
-               "global_load_dwordx2 %7, %15, %17 sc1"
-               : "=&v"(s0), "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6])
-               : "v"(own), "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "s"(rhs_uniform), "s"(src_uniform)
-               : "memory");
+  if (RHS_SC1)
+    asm volatile("s_nop 4\n\t"
+                 "global_load_dwordx2 %0, %8, %16 sc1\n\t" PIPE_GATHER8_REST
+                 : "=&v"(s0), "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6])
+                 : "v"(own), "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "s"(rhs_uniform), "s"(src_uniform)
+                 : "memory");
+  else
+    asm volatile("s_nop 4\n\t"
+                 "global_load_dwordx2 %0, %8, %16\n\t" PIPE_GATHER8_REST
+                 : "=&v"(s0), "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6])
+                 : "v"(own), "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "s"(rhs_uniform), "s"(src_uniform)
+                 : "memory");
   asm volatile("s_nop 4\n\t"
                "global_load_dwordx2 %0, %7, %14 sc1\n\t"
                "global_load_dwordx2 %1, %8, %14 sc1\n\t"
@@ -181,7 +193,7 @@ struct PipeParams {
   const pipe::Task *tasks;
   const unsigned char *stream;
   const int32_t *koff;
-  const double *dperm;          // right-hand side in L position order
+  const double *d;              // right-hand side of the solve, natural order (the forward tasks read it row by row: tile word "own")
   double *ypos, *xpos;          // forward / backward results in position order
   unsigned long long *progress; // one word per task at stride 16 (128 B): (epoch << 32) | steps stored
   unsigned *queue;              // per group 4 words at stride 32: next task of L, of U; finished tasks of L, of U
@@ -201,45 +213,14 @@ __global__ void k_pipe_prologue(XcdState *st, unsigned *queue, int nwords)
     st->epoch += 1;
   }
 }
-// The two permutations between natural order and position order (position = task base + 64 * step + lane: lane = chain, on a
-// structured grid a grid line).  Read or written by position, the natural side touches 64 different cache lines per 64 positions
-// and uses 8 bytes of each (the next step's positions hit the same lines again: L2-request bound).  Both kernels therefore work
-// on tiles of 64 lanes x 16 steps and transpose through LDS: the position side is accessed in position order, the natural side
-// with the step index running fastest, i.e. 16 consecutive rows of a chain by 16 neighbouring threads (whole 128-byte segments
-// when a chain is a grid line; any other chain shape is merely not faster than before).
+// The permutation from position order back to natural order (position = task base + 64 * step + lane: lane = chain, on a structured
+// grid a grid line).  Read by position, the natural side touches 64 different cache lines per 64 positions and uses 8 bytes of each
+// (the next step's positions hit the same lines again: L2-request bound).  The kernel therefore works on tiles of 64 lanes x 16
+// steps and transposes through LDS: the position side is read in position order, the natural side written with the step index
+// running fastest, i.e. 16 consecutive rows of a chain by 16 neighbouring threads (whole 128-byte segments when a chain is a grid
+// line; any other chain shape is merely not faster than before).  (The opposite direction is gone since round 4: the forward tasks
+// gather their right-hand side entries from the caller's vector themselves -- a lane re-uses one cache line for 16 steps.)
 constexpr int PERM_STEPS = 16, PERM_TILE = 64 * PERM_STEPS, PERM_WG = 256, PERM_PAD = 65;
-// dperm[pos] = d[row(pos)] (0 on padding positions)
-__global__ __launch_bounds__(PERM_WG) void k_pipe_permute_in(int64_t npos, const int32_t *__restrict__ rowL, const double *__restrict__ d, double *__restrict__ dperm)
-{
-  __shared__ int32_t idx[PERM_STEPS * PERM_PAD];
-  __shared__ double val[PERM_STEPS * PERM_PAD];
-  const int64_t ntile = (npos + PERM_TILE - 1) / PERM_TILE;
-  for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-    const int64_t p0 = tile * PERM_TILE;
-#pragma unroll
-    for (int q = 0; q < PERM_TILE / PERM_WG; ++q) {
-      const int e = q * PERM_WG + threadIdx.x; // position order: e = 64 * step + lane
-      const int64_t p = p0 + e;
-      idx[(e >> 6) * PERM_PAD + (e & 63)] = p < npos ? rowL[p] : -1;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < PERM_TILE / PERM_WG; ++q) {
-      const int e = q * PERM_WG + threadIdx.x; // chain order: e = 16 * lane + step
-      const int l = e / PERM_STEPS, st = e % PERM_STEPS;
-      const int32_t r = idx[st * PERM_PAD + l];
-      val[st * PERM_PAD + l] = r >= 0 ? d[r] : 0.0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < PERM_TILE / PERM_WG; ++q) {
-      const int e = q * PERM_WG + threadIdx.x;
-      const int64_t p = p0 + e;
-      if (p < npos) dperm[p] = val[(e >> 6) * PERM_PAD + (e & 63)];
-    }
-    __syncthreads();
-  }
-}
 // x[row(pos)] = xpos[pos], optionally followed by the Schwarz level's "x *= pou" and "x += coarse correction" (same operations in
 // the same order as the separate kernels, so the result is bit-identical; saves their passes over the overlapping vector)
 __global__ __launch_bounds__(PERM_WG) void k_pipe_permute_out(int64_t npos, const int32_t *__restrict__ rowU, const double *__restrict__ xpos, double *__restrict__ x,
@@ -454,7 +435,7 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
           const unsigned long long *pword0 = P.progress + (size_t)(2 * lane < nprod ? T->prod[2 * lane] : tid) * 16;
           const unsigned long long *pword1 = P.progress + (size_t)(2 * lane + 1 < nprod ? T->prod[2 * lane + 1] : tid) * 16;
           const double *src = pipe_uniform_ptr(upper ? P.xpos : P.ypos);
-          const double *rhs = pipe_uniform_ptr(upper ? P.ypos : P.dperm);
+          const double *rhs = pipe_uniform_ptr(upper ? P.ypos : P.d);
           double *dst = upper ? P.xpos : P.ypos;
           int have0 = 0, have1 = 0;
           unsigned long long st_start = 0, st_first = 0;
@@ -526,7 +507,8 @@ __global__ __launch_bounds__(64 * (PIPE_NC + PIPE_NL)) void k_trsv_pipe(PipePara
               goff[u] = pipe_gofs(op[u]);
               S.lofs[u] = pipe_lofs(op[u]);
             }
-            pipe_gather_asm8(rhs, (uint32_t)own, src, goff, S.s0, S.xg);
+            if (upper) pipe_gather_asm8<true>(rhs, (uint32_t)own, src, goff, S.s0, S.xg);
+            else pipe_gather_asm8<false>(rhs, (uint32_t)own, src, goff, S.s0, S.xg);
           };
           // may_defer: when the producers are not far enough, do not wait here (the caller still has the current step to compute):
           // S.deferred is set and fetch_late() finishes the job

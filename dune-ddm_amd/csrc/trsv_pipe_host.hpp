@@ -73,7 +73,7 @@ struct Group {
 // [3] size of the task's NEXT tile in KiB (0 behind the last one), [5] of the tile after that, [4] / [6]: bit u set =
 // entry u of some lane is a ring operand produced 1 step / 1 or 2 steps earlier (what a compute wave that shares the task
 // with 1 / 2 other waves must read AFTER the previous step has signalled),
-// word HDR_REQ0 + p/2, 16-bit half p%2: steps of producer p that must be stored; [256,512) int32[64]: U: position of the row's forward value, L: natural row; [512,1024) double[64]:
+// word HDR_REQ0 + p/2, 16-bit half p%2: steps of producer p that must be stored; [256,512) int32[64]: BYTE offset of the row's right-hand side -- U: in the forward results (position order), L: in the caller's vector (natural row * 8); [512,1024) double[64]:
 // U: inverse pivot; then idx pieces (1 KiB each: lane l holds int32[4] = operands 4q..4q+3), then value pieces
 // (1 KiB each: lane l holds double[2] = entries 2q, 2q+1).  Operand encoding: see above; the U tile's "own" word is
 // the BYTE offset of the row's forward value.  W is at least MIN_W (narrower rows are padded).  Tiles are sized by the step's own W and packed back to back.
@@ -545,7 +545,7 @@ inline bool build(int64_t n, const int64_t *rp, const int32_t *ci, const double 
     S.error = "a task has more steps than the 16-bit progress requirements hold";
     return false;
   }
-  if (npos[0] >= (int64_t)0x0fffffff || npos[1] >= (int64_t)0x0fffffff || ntask >= (int64_t)0x7fffffff) {
+  if (npos[0] >= (int64_t)0x0fffffff || npos[1] >= (int64_t)0x0fffffff || ntask >= (int64_t)0x7fffffff || n >= (int64_t)0x0fffffff) {
     S.error = "position space exceeds 32-bit operands";
     return false;
   }
@@ -622,14 +622,14 @@ inline bool build(int64_t n, const int64_t *rp, const int32_t *ci, const double 
             const int32_t i = R.rows[(size_t)t * LANES + l];
             // padding everywhere first
             for (int u = 0; u < 4 * G.idx_pieces; ++u) idx(u, l) = PAD_OP;
-            own[l] = ZERO_POS * 8;
+            own[l] = upper ? ZERO_POS * 8 : 0; // padding lanes: a reserved zero of the forward results / any finite entry of the right-hand side (the result lands in a padding position nobody reads)
             if (i < 0) continue;
             ++active;
             const int64_t g = r0 + i;
             const int64_t pos = T.pos_base + (int64_t)t * LANES + l;
             if (!upper) {
               S.rowL[(size_t)pos] = (int32_t)g;
-              own[l] = (int32_t)(pos * 8); // the row's right-hand side entry (position order)
+              own[l] = (int32_t)(g * 8); // the row's right-hand side entry, read from the caller's vector in natural order
               s0[l] = 1.0;
             } else {
               S.posU[(size_t)g] = (int32_t)pos;
@@ -687,9 +687,7 @@ inline bool build(int64_t n, const int64_t *rp, const int32_t *ci, const double 
 // progress requirements on the way.  Returns an empty string or a description of the first violation.
 inline std::string emulate(const Schedule &S, int64_t n, const double *d, double *x)
 {
-  std::vector<double> dperm((size_t)S.nposL, 0.0), ypos((size_t)S.nposL, 0.0), xpos((size_t)S.nposU, 0.0);
-  for (int64_t p = 0; p < S.nposL; ++p)
-    if (S.rowL[(size_t)p] >= 0) dperm[(size_t)p] = d[S.rowL[(size_t)p]];
+  std::vector<double> ypos((size_t)S.nposL, 0.0), xpos((size_t)S.nposU, 0.0);
   std::vector<int32_t> done(S.tasks.size(), 0);
   // position -> task lookup per sweep
   std::vector<std::pair<int64_t, int32_t>> base[2];
@@ -732,8 +730,10 @@ inline std::string emulate(const Schedule &S, int64_t n, const double *d, double
           double out[LANES];
           for (int l = 0; l < LANES; ++l) {
             const int64_t pos = T.pos_base + (int64_t)t * LANES + l;
-            if (own[l] % 8 || own[l] / 8 >= S.nposL || (!upper && own[l] / 8 != pos && own[l] / 8 != ZERO_POS)) return "right-hand side operand out of range";
-            double s = upper ? ypos[(size_t)own[l] / 8] : dperm[(size_t)own[l] / 8];
+            if (own[l] < 0 || own[l] % 8 || own[l] / 8 >= (upper ? S.nposL : n)) return "right-hand side operand out of range";
+            if (!upper && S.rowL[(size_t)pos] >= 0 && own[l] / 8 != S.rowL[(size_t)pos]) return "right-hand side operand is not the row of the position";
+            if (!upper && S.rowL[(size_t)pos] < 0 && own[l] != 0) return "padding lane with a right-hand side operand";
+            double s = upper ? ypos[(size_t)own[l] / 8] : d[(size_t)own[l] / 8];
             for (int u = 0; u < G.W; ++u) {
               const int32_t op = *reinterpret_cast<const int32_t *>(tile + G.idx_off(u, l));
               const double a = *reinterpret_cast<const double *>(tile + G.val_off(u, l));

@@ -12,6 +12,8 @@ extern "C" int pipe_test_build_and_emulate(int64_t n, const int64_t *rp, const i
   pipe::Options opt;
   opt.delta = delta;
   opt.vote = vote;
+  if (const char *e = std::getenv("PIPE_TEST_SPAN")) opt.max_span = std::atoi(e);   // (diagnostic sweeps of the schedule options: tools/pipe_sim.py)
+  if (const char *e = std::getenv("PIPE_TEST_PACK")) opt.pack_steps = std::atoi(e);
   pipe::Schedule S;
   if (!pipe::build(n, rp, ci, lu, diag, nblocks, block_ptr, opt, S)) {
     std::snprintf(err, errlen, "%s", S.error.c_str());
@@ -53,7 +55,7 @@ extern "C" int pipe_test_build_and_emulate(int64_t n, const int64_t *rp, const i
       std::fprintf(fp, "\n");
     }
     std::fclose(fp);
-    if (const char *nf = std::getenv("PIPE_DEBUG_NEEDS_BIN")) { // per task: nprod, nsteps, producer ids, then per step the steps required of each producer
+    if (const char *nf = std::getenv("PIPE_DEBUG_NEEDS_BIN")) { // per task: nprod, nsteps, producer ids, then per step the steps required of each producer, the step's W and its active rows
       FILE *fb = std::fopen(nf, "wb");
       for (const pipe::Task &T : S.tasks) {
         std::fwrite(&T.nprod, 4, 1, fb);
@@ -65,6 +67,9 @@ extern "C" int pipe_test_build_and_emulate(int64_t n, const int64_t *rp, const i
             const uint16_t rq = (uint16_t)((hdr[pipe::HDR_REQ0 + j / 2] >> (16 * (j & 1))) & 0xffffu);
             std::fwrite(&rq, 2, 1, fb);
           }
+          const uint16_t w = (uint16_t)hdr[2], act = (uint16_t)hdr[0]; // widest row and active rows of the step
+          std::fwrite(&w, 2, 1, fb);
+          std::fwrite(&act, 2, 1, fb);
         }
       }
       std::fclose(fb);

@@ -115,7 +115,10 @@ def test_full_length_cg_parity_geneo_96(ddm):
         ao.set_dot_order(0)
         ao.set_threads(1)
     ho, hh = np.asarray(hist_o), np.asarray(hist)
-    assert res.converged and conv and abs(res.iterations - it) <= 1, (res.iterations, it)
+    assert res.converged and conv, (res.converged, conv)
+    if res.iterations != it:           # the ONLY allowed difference: one iteration, because the last common iterate straddles the threshold
+        k_last = min(len(ho), len(hh)) - 1
+        assert abs(res.iterations - it) == 1 and min(hh[k_last], ho[k_last]) <= 1e-10 * ho[0] < max(hh[k_last], ho[k_last]), (res.iterations, it, hh[k_last] / ho[0], ho[k_last] / ho[0])
     m = min([len(ho), len(hh)] + [len(v[2]) for v in variants.values()])
     dev = np.abs(hh[:m] - ho[:m])
     rel = dev / ho[:m]
@@ -228,6 +231,8 @@ def test_full_size_elasticity(ddm):
     tl = TwoLevelSchwarz(dec, coarse="none", schwarz_type="restricted", mode="multiplicative", subdomain_solver="cholmod")
     basis, info = geneo_basis(tl, nev=12, tol=1e-6, return_info=True)
     assert info["converged"] and info["used_direct"]
+    # regression bound of the stale-products fix (12-17 block iterations in 48 of 48 runs since; 36-120 or none before)
+    assert info["iterations"] <= 25, info["iterations"]
     lam = info["eigenvalues"][3]                                              # a floating subdomain
     assert (np.abs(lam[:6]) < 1e-8).all() and lam[6] > 1e-6
     tl.set_coarse_basis(basis)

@@ -14,7 +14,7 @@ off=0; prods=[]; needs=[]
 for i in range(nt):
     npd, ns = struct.unpack_from("ii", data, off); off+=8
     pr = np.frombuffer(data, dtype=np.int32, count=npd, offset=off); off+=4*npd
-    nd = np.frombuffer(data, dtype=np.uint16, count=npd*ns, offset=off).reshape(ns,npd); off+=2*npd*ns
+    nd = np.frombuffer(data, dtype=np.uint16, count=(npd+2)*ns, offset=off).reshape(ns,npd+2)[:, :npd]; off+=2*(npd+2)*ns   # (+ the step's W and active rows)
     prods.append(pr); needs.append(nd)
 steps = st[g0,6].astype(int)
 sweep = meta[g0,1]

@@ -18,13 +18,14 @@ which = [int(a) for a in sys.argv[2].split(",")]
 mats = [dec.subs[k].A_dir.tocsr() for k in which]
 M = sp.block_diag(mats, format="csr"); M.sort_indices()
 bp = np.concatenate([[0], np.cumsum([m.shape[0] for m in mats])]).astype(np.int64)
-os.environ["PIPE_DEBUG_TASKS"] = "gpurun_out/pipe_tasks.txt"; os.environ["PIPE_DEBUG_NEEDS"]="1"; os.environ["PIPE_DEBUG_NEEDS_BIN"]="gpurun_out/pipe_needs.bin"
+OUT = os.environ.get("PIPE_PROBE_OUT", "gpurun_out/pipe")
+os.environ["PIPE_DEBUG_TASKS"] = OUT + "_tasks.txt"; os.environ["PIPE_DEBUG_NEEDS"]="1"; os.environ["PIPE_DEBUG_NEEDS_BIN"]=OUT + "_needs.bin"
 d = np.random.default_rng(0).standard_normal(M.shape[0])
-rc, err, x, xo, st = tps.run_pipe(lib, M, bp, d, delta=24, vote=1)
+rc, err, x, xo, st = tps.run_pipe(lib, M, bp, d, delta=int(os.environ.get("PIPE_TEST_DELTA", "24")), vote=int(os.environ.get("PIPE_TEST_VOTE", "1")))
 print(rc, err, st, "bitexact", np.array_equal(x, xo))
-T = np.array([[int(v) for v in l.split()[:9]] for l in open("gpurun_out/pipe_tasks.txt")], dtype=np.int64)
+T = np.array([[int(v) for v in l.split()[:9]] for l in open(OUT + "_tasks.txt")], dtype=np.int64)
 for g in sorted(set(T[:, 0])):
     for sw in (0, 1):
         m = (T[:, 0] == g) & (T[:, 1] == sw)
         print(f"group {g} sweep {sw}: tasks {m.sum()} steps {T[m,3].sum()} wide steps {T[m,6].sum()} ({T[m,6].sum()/T[m,3].sum():.1%}) tasks with any wide step {(T[m,6]>0).sum()}  fill {T[m,4].sum()/T[m,3].sum()/64:.2f}  slots with a gathered operand per step {T[m,8].sum()/T[m,3].sum():.2f} of 14")
-np.save("gpurun_out/pipe_tasks.npy", T)
+np.save(OUT + "_tasks.npy", T)
