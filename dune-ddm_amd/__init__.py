@@ -94,6 +94,7 @@ SYMBOLS = {
     "ddm_ilu0_engine": (_I32, [_P]),
     "ddm_chol_create": (_I32, [_P, _P, _I64, _P, _D, _PP]),
     "ddm_ilu0_is_direct": (_I32, [_P]),
+    "ddm_ilu0_refinement": (_I32, [_P, _P]),
     "ddm_sn_host_create": (_I32, [_I64, _P, _P, _I64, _P, _PP]),
     "ddm_sn_host_destroy": (None, [_P]),
     "ddm_sn_host_sizes": (_I32, [_P, _I64, _P, ctypes.POINTER(ctypes.c_double)]),
@@ -392,6 +393,12 @@ class Ilu0:
     @property
     def nnz(self):
         return int(self.ctx.lib.ddm_ilu0_nnz(self.h))
+
+    def refinement(self):
+        """(steps per solve, backward errors of the probe after 0, 1, .. steps) of a device direct factor."""
+        om = np.zeros(5)
+        steps = int(self.ctx.lib.ddm_ilu0_refinement(self.h, _hp(om)))
+        return steps, om
 
     def solve(self, d, x):
         self.ctx.check(self.ctx.lib.ddm_ilu0_solve(self.ctx.h, self.h, _ptr(d), _ptr(x)))

@@ -835,6 +835,15 @@ struct ddm_ilu0 {
   int direct = 0;
   double direct_flops = 0.0;
   sn::Factor *sn = nullptr;       // supernodal factor computed ON THE DEVICE (sn_chol.hpp); solves run on its panels, in place in pd / pD
+  // iterative refinement of the device engine (dune/ddm/eigensolvers/umfpack.hh:42-129; UMFPACK refines inside its own solve too):
+  // the number of steps is fixed when the factor is created, from the backward error of a probe solve (sn_direct_create), so that
+  // the solves stay captured HIP graphs; the matrix is kept as device copies of its three arrays
+  int refine_steps = 0;
+  double refine_omega[5] = {0, 0, 0, 0, 0}; // backward error of the probe after 0, 1, .. steps
+  int64_t *ref_rp = nullptr;
+  int32_t *ref_ci = nullptr;
+  double *ref_va = nullptr, *pr = nullptr; // pr: residual block (n x pr_cols)
+  int pr_cols = 0;
   int64_t nvirt = 0; // virtual unknowns of the supernodal transformation: the permuted work vectors hold n + nvirt entries
   hvec<double> h_lu; // factor values in the pattern of A
   TriSchedule L, U;
@@ -1542,6 +1551,131 @@ static double sn_probe_largest_block(const int64_t *rp, const int32_t *ci, int64
       if (ci[k] < r0 || ci[k] >= r1) return 0.0;
   return (lu ? 2.0 : 1.0) * sn::estimate_flops(chol::block_graph(rp, ci, r0, r1)) * (double)nblocks;
 }
+static int ilu0_solve_epilogue(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, const double *scale, const double *add);
+// Fixes the number of iterative-refinement steps of a device factor (ddm_ilu0::refine_steps) from a probe solve with a pseudo-random
+// right-hand side: the loop of dune/ddm/eigensolvers/umfpack.hh:42-129 -- backward error omega = ||b - A x|| / (||A||_inf ||x|| + ||b||),
+// stop below 1e-14, stop when a step does not halve it, at most 3 steps -- run ONCE here instead of in every solve, so that the
+// solves stay captured graphs.  DDM_DIRECT_REFINE = off | <steps> overrides.  Returns the last backward error in *omega_out.
+static int sn_probe_refinement(ddm_ctx *ctx, ddm_ilu0 *F, const ddm_csr *A, double *omega_out)
+{
+  const int64_t n = F->n;
+  *omega_out = 0.0;
+  int forced = -1, max_steps = 3;
+  if (const char *e = std::getenv("DDM_DIRECT_REFINE")) {
+    if (!std::strcmp(e, "off")) return DDM_OK;
+    forced = std::max(0, std::min(4, std::atoi(e)));
+  }
+  if (n == 0) return DDM_OK;
+  const int64_t *rp = A->h_rp.data();
+  const int32_t *ci = A->h_ci.data();
+  const double *va = A->h_va.data();
+  const unsigned nth = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  auto par_rows = [&](const std::function<void(int64_t, int64_t, unsigned)> &f) {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nth; ++t) th.emplace_back([&, t]() { f(n * t / nth, n * (t + 1) / nth, t); });
+    for (auto &t : th) t.join();
+  };
+  std::vector<double> part(nth, 0.0);
+  par_rows([&](int64_t r0, int64_t r1, unsigned t) {
+    double m = 0.0;
+    for (int64_t i = r0; i < r1; ++i) {
+      double a = 0.0;
+      for (int64_t k = rp[i]; k < rp[i + 1]; ++k) a += std::fabs(va[k]);
+      m = std::max(m, a);
+    }
+    part[t] = m;
+  });
+  double anorm = 0.0;
+  for (double v : part) anorm = std::max(anorm, v);
+  std::vector<double> b((size_t)n), x((size_t)n);
+  uint64_t lcg = 0x9E3779B97F4A7C15ull;
+  double bn2 = 0.0;
+  for (int64_t i = 0; i < n; ++i) {
+    lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+    b[(size_t)i] = (double)(int64_t)(lcg >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0;
+    bn2 += b[(size_t)i] * b[(size_t)i];
+  }
+  double *db = nullptr, *dx = nullptr;
+  HIPCHECK(ctx, hipMalloc((void **)&db, sizeof(double) * (size_t)n));
+  if (hipMalloc((void **)&dx, sizeof(double) * (size_t)n) != hipSuccess) {
+    (void)hipFree(db);
+    return fail(ctx, DDM_EHIP, "sparse direct solver: allocation failed");
+  }
+  int rc = ddm_memcpy_h2d(ctx, db, b.data(), sizeof(double) * (size_t)n);
+  auto omega_now = [&](double &om) -> int {
+    int r = ddm_memcpy_d2h(ctx, x.data(), dx, sizeof(double) * (size_t)n); // (synchronises the stream)
+    if (r) return r;
+    std::vector<double> pr(nth, 0.0), px(nth, 0.0);
+    par_rows([&](int64_t r0, int64_t r1, unsigned t) {
+      double sr = 0.0, sx = 0.0;
+      for (int64_t i = r0; i < r1; ++i) {
+        double res = b[(size_t)i];
+        for (int64_t k = rp[i]; k < rp[i + 1]; ++k) res -= va[k] * x[(size_t)ci[k]];
+        sr += res * res;
+        sx += x[(size_t)i] * x[(size_t)i];
+      }
+      pr[t] = sr;
+      px[t] = sx;
+    });
+    double sr = 0.0, sx = 0.0;
+    for (unsigned t = 0; t < nth; ++t) sr += pr[t], sx += px[t];
+    om = std::sqrt(sr) / (anorm * std::sqrt(sx) + std::sqrt(bn2));
+    return DDM_OK;
+  };
+  auto solve_with = [&](int steps) -> int {
+    if (steps > 0 && !F->ref_rp) { // device copies of the matrix for the residuals
+      HIPCHECK(ctx, hipMalloc((void **)&F->ref_rp, sizeof(int64_t) * (size_t)(n + 1)));
+      HIPCHECK(ctx, hipMalloc((void **)&F->ref_ci, sizeof(int32_t) * (size_t)std::max<int64_t>(A->nnz, 1)));
+      HIPCHECK(ctx, hipMalloc((void **)&F->ref_va, sizeof(double) * (size_t)std::max<int64_t>(A->nnz, 1)));
+      HIPCHECK(ctx, hipMalloc((void **)&F->pr, sizeof(double) * (size_t)n));
+      F->pr_cols = 1;
+      HIPCHECK(ctx, hipMemcpyAsync(F->ref_rp, A->rp, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHECK(ctx, hipMemcpyAsync(F->ref_ci, A->ci, sizeof(int32_t) * (size_t)A->nnz, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHECK(ctx, hipMemcpyAsync(F->ref_va, A->va, sizeof(double) * (size_t)A->nnz, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    F->refine_steps = steps;
+    if (F->graph) {
+      (void)hipGraphExecDestroy(F->graph);
+      F->graph = nullptr;
+    }
+    return ilu0_solve_epilogue(ctx, F, db, dx, nullptr, nullptr);
+  };
+  double om = 0.0, om_prev = 0.0;
+  int steps = 0;
+  if (!rc) rc = solve_with(0);
+  if (!rc) rc = omega_now(om);
+  F->refine_omega[0] = om;
+  while (!rc && steps < (forced >= 0 ? forced : max_steps)) {
+    if (forced < 0) {
+      if (om < 1e-14 || !(om == om)) break;            // converged (or NaN: refinement cannot help)
+      if (steps > 0 && om > om_prev / 2.0) break;      // the last step did not halve the backward error
+    }
+    om_prev = om;
+    rc = solve_with(steps + 1);
+    if (!rc) rc = omega_now(om);
+    ++steps;
+    F->refine_omega[std::min(steps, 4)] = om;
+  }
+  F->refine_steps = steps;
+  if (F->graph) { // (bound to the probe vectors)
+    (void)hipGraphExecDestroy(F->graph);
+    F->graph = nullptr;
+  }
+  if (steps == 0) {
+    (void)hipFree(F->ref_rp);
+    (void)hipFree(F->ref_ci);
+    (void)hipFree(F->ref_va);
+    (void)hipFree(F->pr);
+    F->ref_rp = nullptr;
+    F->ref_ci = nullptr;
+    F->ref_va = F->pr = nullptr;
+    F->pr_cols = 0;
+  }
+  (void)hipFree(db);
+  (void)hipFree(dx);
+  *omega_out = om;
+  return rc;
+}
 static int sn_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, double max_flops, bool force, bool lu, bool setup_use, ddm_ilu0 **out)
 {
   const int64_t n = A->nrows;
@@ -1611,14 +1745,18 @@ static int sn_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, con
     delete S;
     return fail(ctx, DDM_EHIP, "sparse direct solver (device): allocation of %.1f GB failed", entries * 8e-9);
   }
-  unsigned badsn = 0;
-  const hipError_t he = sn::factorize(*S, ctx->stream, A->rp, A->ci, A->va, &badsn);
+  unsigned badsn = 0, perturbed = 0;
+  double amax = 0.0;
+  if (lu)
+    for (double v : A->h_va) amax = std::max(amax, std::fabs(v));
+  const hipError_t he = sn::factorize(*S, ctx->stream, A->rp, A->ci, A->va, &badsn, 1.4901161193847656e-08 * amax, &perturbed);
   if (he != hipSuccess) {
     delete S;
     return fail(ctx, DDM_EHIP, "sparse direct solver (device): %s", hipGetErrorString(he));
   }
   if (badsn) {
     delete S;
+    if (lu && !force) return 1; // (not forced: the host engine takes the matrix)
     return fail(ctx, DDM_ENUMERIC, lu ? "sparse direct solver: vanishing pivot column inside the diagonal block of supernode %u (matrix singular?)"
                                      : "sparse direct solver: matrix is not positive definite (supernode %u)", badsn - 1);
   }
@@ -1640,9 +1778,19 @@ static int sn_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, con
   if (!rc && (hipMalloc((void **)&F->pd, sizeof(double) * (size_t)std::max<int64_t>(n, 1)) != hipSuccess ||
               hipMalloc((void **)&F->px, sizeof(double) * (size_t)std::max<int64_t>(n, 1)) != hipSuccess))
     rc = fail(ctx, DDM_EHIP, "sparse direct solver: allocation failed");
+  double omega = 0.0;
+  if (!rc) rc = sn_probe_refinement(ctx, F, A, &omega);
   if (rc) {
     ddm_ilu0_destroy(F);
     return rc;
+  }
+  if (std::getenv("DDM_PIPE_VERBOSE"))
+    std::fprintf(stderr, "[ddm] device supernodal %s: %d refinement step(s) per solve, backward error of the probe %.2e -> %.2e%s\n", lu ? "L U" : "Cholesky", F->refine_steps,
+                 F->refine_omega[0], omega, perturbed ? " (vanishing pivot columns replaced)" : "");
+  if (!(omega <= 1e-9)) { // element growth beyond what pivoting inside the supernodes and three refinement steps repair
+    ddm_ilu0_destroy(F);
+    if (!force) return 1;
+    return fail(ctx, DDM_ENUMERIC, "sparse direct solver (device): backward error %.2e after iterative refinement (the matrix needs pivoting across supernodes)", omega);
   }
   *out = F;
   return DDM_OK;
@@ -1747,12 +1895,23 @@ static int direct_create_impl(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, c
   return DDM_OK;
 }
 extern "C" int ddm_ilu0_is_direct(const ddm_ilu0 *F) { return F ? F->direct : 0; }
+extern "C" int ddm_ilu0_refinement(const ddm_ilu0 *F, double *omega)
+{
+  if (!F) return 0;
+  if (omega)
+    for (int k = 0; k < 5; ++k) omega[k] = F->refine_omega[k];
+  return F->refine_steps;
+}
 extern "C" int64_t ddm_ilu0_nnz(const ddm_ilu0 *F) { return F ? F->nnz : 0; }
 extern "C" void ddm_ilu0_destroy(ddm_ilu0 *F)
 {
   if (!F) return;
   if (F->graph) (void)hipGraphExecDestroy(F->graph);
   if (F->mgraph) (void)hipGraphExecDestroy(F->mgraph);
+  (void)hipFree(F->ref_rp);
+  (void)hipFree(F->ref_ci);
+  (void)hipFree(F->ref_va);
+  (void)hipFree(F->pr);
   (void)hipFree(F->xf);
   if (F->err) (void)hipHostFree(F->err);
   delete F->sn;
@@ -2127,8 +2286,15 @@ static int ilu0_solve_epilogue(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, doubl
   bool epilogue_done = false;
   if (F->sn) { // supernodal device factor: gather into the permuted work vector, solve in place on the panels, scatter
     hipLaunchKernelGGL(k_perm_gather, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, 1, F->sn->d_perm, d_user, (int64_t)1, F->pd);
-    sn::solve(*F->sn, ctx->stream, 1, F->pd, 1, F->px);
+    sn::solve(*F->sn, ctx->stream, 1, F->pd, 1, F->px, F->err); // (a time-out of the persistent top kernel lands in the factor's status word)
     hipLaunchKernelGGL(k_perm_scatter, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, 1, F->sn->d_perm, (const double *)F->pd, x_user, (int64_t)1);
+    for (int it = 0; it < F->refine_steps; ++it) { // x += A^-1 (d - A x)
+      hipLaunchKernelGGL(k_residual_rowmajor, dim3((unsigned)((F->n + WG - 1) / WG)), dim3(WG), 0, ctx->stream, F->n, 1, (const int64_t *)F->ref_rp, (const int32_t *)F->ref_ci, (const double *)F->ref_va,
+                         (const double *)x_user, (int64_t)1, d_user, (int64_t)1, F->pr, (int64_t)1);
+      hipLaunchKernelGGL(k_perm_gather, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, 1, F->sn->d_perm, (const double *)F->pr, (int64_t)1, F->pd);
+      sn::solve(*F->sn, ctx->stream, 1, F->pd, 1, F->px, F->err);
+      hipLaunchKernelGGL(k_perm_scatter_add, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, 1, F->sn->d_perm, (const double *)F->pd, x_user, (int64_t)1);
+    }
   } else {
   if (F->perm) { // sparse direct factor: solve in the fill-reducing order
     hipLaunchKernelGGL(k_perm_gather, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, 1, F->perm, d_user, (int64_t)1, F->pd);
@@ -2274,9 +2440,9 @@ static int ilu0_solve_multi_ld(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double
   }
   if (F->sn) {
     const int w = std::min(nrhs, 48); // the panel kernels take up to 48 columns: wider blocks are solved in column panels
-    const double *partial_before = F->sn->d_partial;
+    const double *partial_before = F->sn->d_partial, *contrib_before = F->sn->d_contrib;
     if (!sn::reserve(*F->sn, w)) return fail(ctx, DDM_EHIP, "sparse direct solver: allocation failed");
-    if (F->sn->d_partial != partial_before && F->graph) { // the single-vector graph's backward nodes hold the old scratch pointer
+    if ((F->sn->d_partial != partial_before || F->sn->d_contrib != contrib_before) && F->graph) { // the single-vector graph's nodes hold the old scratch pointers
       (void)hipGraphExecDestroy(F->graph);
       F->graph = nullptr;
     }
@@ -2286,6 +2452,17 @@ static int ilu0_solve_multi_ld(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double
       F->pm_nrhs = 0;
       HIPCHECK(ctx, hipMalloc((void **)&F->pD, sizeof(double) * (size_t)F->n * (size_t)w));
       F->pm_nrhs = w;
+    }
+    if (F->refine_steps > 0 && F->pr_cols < w) {
+      (void)hipFree(F->pr);
+      F->pr = nullptr;
+      F->pr_cols = 0;
+      HIPCHECK(ctx, hipMalloc((void **)&F->pr, sizeof(double) * (size_t)F->n * (size_t)w));
+      F->pr_cols = w;
+      if (F->graph) { // (the single-vector graph holds the old residual buffer)
+        (void)hipGraphExecDestroy(F->graph);
+        F->graph = nullptr;
+      }
     }
   }
   if (F->perm && F->pm_nrhs < nrhs) {
@@ -2305,6 +2482,13 @@ static int ilu0_solve_multi_ld(ddm_ctx *ctx, ddm_ilu0 *F, int nrhs, const double
       hipLaunchKernelGGL(k_perm_gather, dim3(grid_for(F->n * w)), dim3(WG), 0, ctx->stream, F->n, w, F->sn->d_perm, D + c0, ldd, F->pD);
       sn::solve(*F->sn, ctx->stream, w, F->pD, w);
       hipLaunchKernelGGL(k_perm_scatter, dim3(grid_for(F->n * w)), dim3(WG), 0, ctx->stream, F->n, w, F->sn->d_perm, (const double *)F->pD, X + c0, ldx);
+      for (int it = 0; it < F->refine_steps; ++it) { // X += A^-1 (D - A X), panel by panel
+        hipLaunchKernelGGL(k_residual_rowmajor, dim3((unsigned)((F->n * (int64_t)w + WG - 1) / WG)), dim3(WG), 0, ctx->stream, F->n, w, (const int64_t *)F->ref_rp, (const int32_t *)F->ref_ci,
+                           (const double *)F->ref_va, (const double *)(X + c0), ldx, D + c0, ldd, F->pr, (int64_t)w);
+        hipLaunchKernelGGL(k_perm_gather, dim3(grid_for(F->n * w)), dim3(WG), 0, ctx->stream, F->n, w, F->sn->d_perm, (const double *)F->pr, (int64_t)w, F->pD);
+        sn::solve(*F->sn, ctx->stream, w, F->pD, w);
+        hipLaunchKernelGGL(k_perm_scatter_add, dim3(grid_for(F->n * w)), dim3(WG), 0, ctx->stream, F->n, w, F->sn->d_perm, (const double *)F->pD, X + c0, ldx);
+      }
     }
   } else if (F->perm) { // sparse direct factor: solve in the fill-reducing order on packed work blocks
     hipLaunchKernelGGL(k_perm_gather, dim3(grid_for(F->n * nrhs)), dim3(WG), 0, ctx->stream, F->n, nrhs, F->perm, D, ldd, F->pD);

@@ -986,6 +986,28 @@ __global__ void k_perm_scatter(int64_t n, int nrhs, const int32_t *__restrict__ 
     dst[(int64_t)perm[i] * ld + (t - i * nrhs)] = src[t];
   }
 }
+// dst[perm[i]] += src[i] (the correction of an iterative-refinement step, scattered back into the solution)
+__global__ void k_perm_scatter_add(int64_t n, int nrhs, const int32_t *__restrict__ perm, const double *__restrict__ src, double *__restrict__ dst, int64_t ld)
+{
+  const int64_t tot = n * nrhs;
+  for (int64_t t = blockIdx.x * (int64_t)WG + threadIdx.x; t < tot; t += (int64_t)gridDim.x * WG) {
+    const int64_t i = t / nrhs;
+    dst[(int64_t)perm[i] * ld + (t - i * nrhs)] += src[t];
+  }
+}
+// R = D - A X for row-major blocks (n x nrhs): the residual of an iterative-refinement step (dune/ddm/eigensolvers/umfpack.hh:55-60);
+// one thread per (row, rhs), row sums in column order
+__global__ __launch_bounds__(WG) void k_residual_rowmajor(int64_t n, int nrhs, const int64_t *__restrict__ rp, const int32_t *__restrict__ ci, const double *__restrict__ va,
+                                                          const double *__restrict__ x, int64_t ldx, const double *__restrict__ d, int64_t ldd, double *__restrict__ r, int64_t ldr)
+{
+  const int64_t t = (int64_t)blockIdx.x * WG + threadIdx.x;
+  const int64_t row = t / nrhs;
+  if (row >= n) return;
+  const int j = (int)(t - row * nrhs);
+  double s = d[row * ldd + j];
+  for (int64_t k = rp[row]; k < rp[row + 1]; ++k) s -= va[k] * x[(int64_t)ci[k] * ldx + j];
+  r[row * ldr + j] = s;
+}
 __global__ void k_extend(int64_t n, const int32_t *__restrict__ ext_map, const double *__restrict__ d, double *__restrict__ dov)
 {
   for (int64_t i = blockIdx.x * (int64_t)WG + threadIdx.x; i < n; i += (int64_t)gridDim.x * WG) {

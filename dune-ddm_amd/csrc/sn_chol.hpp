@@ -29,6 +29,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -67,6 +68,11 @@ struct Meta { // device pointers
   const int32_t *rows;
   const int64_t *pptr;      // [nsn + 1] (doubles)
   const int32_t *sn_of_col; // [n]
+  // transposed row lists: the entries q of `rows` with rows[q] == c are tidx[tptr[c] .. tptr[c + 1]), ascending in q (= ascending
+  // source supernode).  The forward sweeps write the contribution of supernode s to its row rows[q] into slot q of a scratch array
+  // and the owner of column c subtracts its slots in list order: one summation order, no atomics.
+  const int64_t *tptr;      // [n + 1]
+  const int32_t *tidx;
   double *panels;
   // L U variant (non-symmetric values on the symmetric pattern): the panel of s holds the FULL diagonal block and L_{rows, s};
   // upanels holds U_{s, rows}^T as an nrow x ncol column-major block at uptr[s]; piv[first[s] + k] = row of the diagonal block
@@ -256,15 +262,17 @@ __global__ __launch_bounds__(256) void k_sn_panel(Meta M, const int32_t *__restr
 }
 
 // ---- update: lower-triangular 64 x 64 tiles of R_s R_s^T subtracted from the ancestors' panels ---------------------------------
-__global__ __launch_bounds__(256) void k_sn_update(Meta M, const int32_t *__restrict__ lev_sn, const int32_t *__restrict__ pre, int cnt)
+// (base: first work item of this launch = of the colour; pre / cnt describe the whole level)
+__global__ __launch_bounds__(256) void k_sn_update(Meta M, const int32_t *__restrict__ lev_sn, const int32_t *__restrict__ pre, int cnt, int base)
 {
   __shared__ int32_t rowid[TILE], colid[TILE], slot_of_col[TILE], slot_t[TILE], slot_first[TILE];
   __shared__ int64_t slot_base[TILE], slot_ld[TILE];
   __shared__ int32_t rpos[TILE * TILE]; // [slot][row]
   __shared__ int nslots_s;
-  const int it = find_item(pre, cnt, (int32_t)blockIdx.x);
+  const int item = (int)blockIdx.x + base;
+  const int it = find_item(pre, cnt, (int32_t)item);
   const int32_t s = lev_sn[it];
-  int u = (int)blockIdx.x - pre[it]; // index into the lower triangle of the T x T tile grid, row-major: u = ti (ti + 1) / 2 + tj
+  int u = item - pre[it]; // index into the lower triangle of the T x T tile grid, row-major: u = ti (ti + 1) / 2 + tj
   int ti = (int)((sqrt(8.0 * (double)u + 1.0) - 1.0) * 0.5);
   while ((ti + 1) * (ti + 2) / 2 <= u) ++ti;
   while (ti * (ti + 1) / 2 > u) --ti;
@@ -367,7 +375,7 @@ __global__ __launch_bounds__(256) void k_sn_update(Meta M, const int32_t *__rest
         const int32_t gr = rowid[r];
         if (gr < gc) continue; // (also gr == -1) lower triangle only
         const int32_t rp = rpos[sl * TILE + r];
-        unsafeAtomicAdd(M.panels + slot_base[sl] + rp + (int64_t)(gc - slot_first[sl]) * slot_ld[sl], -acc[a][b][q]);
+        M.panels[slot_base[sl] + rp + (int64_t)(gc - slot_first[sl]) * slot_ld[sl]] -= acc[a][b][q]; // (no other workgroup of this launch touches the entry: colours)
       }
   }
 }
@@ -403,7 +411,7 @@ __global__ __launch_bounds__(256) void k_sn_assemble_lu(Meta M, int64_t n, const
 
 // diagonal block: P D = L U with threshold partial pivoting, then both triangular inverses in place (strict lower: L^-1 with its
 // unit diagonal implied; upper incl. diagonal: U^-1)
-__global__ __launch_bounds__(256) void k_sn_lu_diag(Meta M, const int32_t *__restrict__ lev_sn, unsigned *__restrict__ err)
+__global__ __launch_bounds__(256) void k_sn_lu_diag(Meta M, const int32_t *__restrict__ lev_sn, unsigned *__restrict__ err, double tiny)
 {
   extern __shared__ __attribute__((aligned(16))) double a[];
   __shared__ double rowbuf[SN_MAX_COLS];
@@ -434,9 +442,13 @@ __global__ __launch_bounds__(256) void k_sn_lu_diag(Meta M, const int32_t *__res
       }
       const double dg = fabs(a[k + k * ldl]);
       int p = (dg > 0.0 && dg >= LU_PIVOT_THRESHOLD * amax) ? k : imax;
-      if (!(amax > 0.0) || !(amax < 1.7e308)) {
+      if (!(amax < 1.7e308)) { // NaN / Inf
         atomicCAS(err, 0u, (unsigned)s + 1u);
         a[k + k * ldl] = 1.0;
+        p = k;
+      } else if (!(amax > 0.0)) { // the whole column of the block vanishes: static perturbation (sqrt(eps) max|a_ij|, as SuperLU_DIST
+        a[k + k * ldl] = tiny;    // does for the pivots its static order cannot reach); counted, repaired by the iterative refinement
+        atomicAdd(err + 2, 1u);
         p = k;
       }
       pivot_row = p;
@@ -547,15 +559,16 @@ __global__ __launch_bounds__(256) void k_sn_lu_panel(Meta M, const int32_t *__re
 
 // update: ALL 64 x 64 tiles of L_{rows,s} U_{s,rows} subtracted from the ancestors (lower part and diagonal blocks: panel of the
 // column's owner; strictly upper part outside a diagonal block: U^T block of the row's owner)
-__global__ __launch_bounds__(256) void k_sn_lu_update(Meta M, const int32_t *__restrict__ lev_sn, const int32_t *__restrict__ pre, int cnt)
+__global__ __launch_bounds__(256) void k_sn_lu_update(Meta M, const int32_t *__restrict__ lev_sn, const int32_t *__restrict__ pre, int cnt, int base)
 {
   __shared__ int32_t rowid[TILE], colid[TILE], cslot[TILE], rslot[TILE], cs_t[TILE], rs_t[TILE];
   __shared__ int32_t posc[TILE * TILE]; // [column slot][row]: position of the row in the column owner's index list
   __shared__ int32_t posr[TILE * TILE]; // [row slot][column]: position of the column in the row owner's index list
   __shared__ int ncs_s, nrs_s;
-  const int it = find_item(pre, cnt, (int32_t)blockIdx.x);
+  const int item = (int)blockIdx.x + base;
+  const int it = find_item(pre, cnt, (int32_t)item);
   const int32_t s = lev_sn[it];
-  const int u = (int)blockIdx.x - pre[it];
+  const int u = item - pre[it];
   const int32_t nc = M.first[s + 1] - M.first[s], nr = M.nrow[s];
   const int T = (nr + TILE - 1) / TILE;
   const int ti = u / T, tj = u - ti * T;
@@ -639,13 +652,13 @@ __global__ __launch_bounds__(256) void k_sn_lu_update(Meta M, const int32_t *__r
       if (gr >= gc) { // lower part: panel of the owner of column gc
         const int32_t tt = cs_t[cslot[c]];
         const int32_t f = M.first[tt];
-        unsafeAtomicAdd(M.panels + M.pptr[tt] + posc[cslot[c] * TILE + r] + (int64_t)(gc - f) * ((int64_t)(M.first[tt + 1] - f) + M.nrow[tt]), -acc[t][q]);
+        M.panels[M.pptr[tt] + posc[cslot[c] * TILE + r] + (int64_t)(gc - f) * ((int64_t)(M.first[tt + 1] - f) + M.nrow[tt])] -= acc[t][q];
       } else { // upper part: owner of row gr
         const int32_t tt = rs_t[rslot[r]];
         const int32_t f = M.first[tt], ncc = M.first[tt + 1] - f, nrr = M.nrow[tt];
         const int32_t pc = posr[rslot[r] * TILE + c];
-        if (pc < ncc) unsafeAtomicAdd(M.panels + M.pptr[tt] + (gr - f) + (int64_t)pc * (ncc + nrr), -acc[t][q]); // inside the diagonal block
-        else unsafeAtomicAdd(M.upanels + M.uptr[tt] + (pc - ncc) + (int64_t)(gr - f) * nrr, -acc[t][q]);
+        if (pc < ncc) M.panels[M.pptr[tt] + (gr - f) + (int64_t)pc * (ncc + nrr)] -= acc[t][q]; // inside the diagonal block
+        else M.upanels[M.uptr[tt] + (pc - ncc) + (int64_t)(gr - f) * nrr] -= acc[t][q];
       }
     }
   }
@@ -658,7 +671,7 @@ constexpr int SOLVE_MT = 3;
 constexpr int SOLVE_UNROLL = 8; // k-steps (of 4) whose global operand loads are issued together
 // Y_s = W_s B_s, in place in the work block (row-major, leading dimension ldb)
 template <bool LU>
-__global__ __launch_bounds__(256) void k_sn_fwd_diag(Meta M, const int32_t *__restrict__ lev_sn, int m, double *__restrict__ B, int64_t ldb)
+__global__ __launch_bounds__(256) void k_sn_fwd_diag(Meta M, const int32_t *__restrict__ lev_sn, int m, double *__restrict__ B, int64_t ldb, const double *__restrict__ contrib)
 {
   extern __shared__ __attribute__((aligned(16))) double bs[]; // nc x mpad
   const int32_t s = lev_sn[blockIdx.x];
@@ -670,7 +683,20 @@ __global__ __launch_bounds__(256) void k_sn_fwd_diag(Meta M, const int32_t *__re
   for (int idx = tid; idx < nc * mpad; idx += 256) {
     const int k = idx / mpad, c = idx - k * mpad;
     const int ksrc = LU ? M.piv[f + k] : k; // the row exchanges of the diagonal block, applied to the right-hand side here
-    bs[idx] = c < m ? B[(int64_t)(f + ksrc) * ldb + c] : 0.0;
+    double v = 0.0;
+    if (c < m) {
+      v = B[(int64_t)(f + ksrc) * ldb + c];
+      // what the supernodes below subtract from this row: their slots, in list order (four loads in flight)
+      const int64_t q0 = M.tptr[f + ksrc], q1 = M.tptr[f + ksrc + 1];
+      int64_t q = q0;
+      for (; q + 4 <= q1; q += 4) {
+        const double c0 = contrib[(int64_t)M.tidx[q] * m + c], c1 = contrib[(int64_t)M.tidx[q + 1] * m + c], c2 = contrib[(int64_t)M.tidx[q + 2] * m + c],
+                     c3 = contrib[(int64_t)M.tidx[q + 3] * m + c];
+        v = (((v - c0) - c1) - c2) - c3;
+      }
+      for (; q < q1; ++q) v -= contrib[(int64_t)M.tidx[q] * m + c];
+    }
+    bs[idx] = v;
   }
   __syncthreads();
   const int ns = (nc + 15) >> 4;
@@ -707,9 +733,9 @@ __global__ __launch_bounds__(256) void k_sn_fwd_diag(Meta M, const int32_t *__re
     }
   }
 }
-// B[rows] -= R_s Y_s, one workgroup per 64 rows of R_s
+// slots of the rows of s <- R_s Y_s (subtracted by the rows' owners: k_sn_fwd_diag), one workgroup per 64 rows of R_s
 __global__ __launch_bounds__(256) void k_sn_fwd_update(Meta M, const int32_t *__restrict__ lev_sn, const int32_t *__restrict__ pre, int cnt, int m,
-                                                      double *__restrict__ B, int64_t ldb)
+                                                      const double *__restrict__ B, int64_t ldb, double *__restrict__ contrib)
 {
   extern __shared__ __attribute__((aligned(16))) double ys[]; // nc x mpad
   const int it = find_item(pre, cnt, (int32_t)blockIdx.x);
@@ -718,7 +744,6 @@ __global__ __launch_bounds__(256) void k_sn_fwd_update(Meta M, const int32_t *__
   const int32_t f = M.first[s], nc = M.first[s + 1] - f, nr = M.nrow[s];
   const int64_t ld = nc + nr;
   const double *P = M.panels + M.pptr[s];
-  const int32_t *R = M.rows + M.rptr[s];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 15, lr = lane >> 4;
   const int mt = (m + 15) >> 4, mpad = mt << 4;
   for (int idx = tid; idx < nc * mpad; idx += 256) {
@@ -751,7 +776,7 @@ __global__ __launch_bounds__(256) void k_sn_fwd_update(Meta M, const int32_t *__
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int r = tile * TILE + (wave << 4) + lr + 4 * q, c = (t << 4) + lc;
-      if (r < nr && c < m) unsafeAtomicAdd(B + (int64_t)R[r] * ldb + c, -acc[t][q]);
+      if (r < nr && c < m) contrib[(M.rptr[s] + r) * m + c] = acc[t][q];
     }
   }
 }
@@ -920,176 +945,15 @@ __global__ __launch_bounds__(256) void k_sn_bwd_diag(Meta M, const int32_t *__re
   }
 }
 
-// ---- ONE right-hand side (the Schwarz apply inside a Krylov loop) -----------------------------------------------------------------
-// GEMV-shaped variants of the four solve kernels: 512 threads, every thread's slice of loads in flight at once, the k range (or the
-// rows) split over thread groups and summed in a fixed order; forward: ONE launch per level -- every workgroup of a supernode
-// recomputes y_s = W_s b_s itself (at most 128^2 / 2 multiply-adds), item 0 stores it to Y (a separate vector: the others still read
-// b_s), items 1.. apply their 64 rows of the update.
-// NCMAX = 128 (4 x 128 threads) or 64 (levels whose widest supernode has at most 64 columns -- the many small supernodes at the bottom
-// of the tree: half the threads per workgroup, twice the workgroups per CU)
-__device__ __forceinline__ double s1_wave_sum(double v)
-{
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-template <bool LU, int NCMAX>
-__global__ __launch_bounds__(4 * NCMAX) void k_sn_fwd1(Meta M, const int32_t *__restrict__ lev_sn, const int32_t *__restrict__ pre, int cnt, double *__restrict__ B,
-                                                  double *__restrict__ Y)
-{
-  constexpr int YS = NCMAX / 4; // k slice of the four thread groups that compute y
-  __shared__ double bs[NCMAX], ys[NCMAX], part[4 * NCMAX];
-  int lo = 0, hi = cnt; // item -> (supernode, local item): largest i with pre[i] + i <= item (1 + T_i items per supernode)
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (pre[mid] + mid <= (int)blockIdx.x) lo = mid;
-    else hi = mid;
-  }
-  const int32_t s = lev_sn[lo];
-  const int item = (int)blockIdx.x - pre[lo] - lo;
-  const int32_t f = M.first[s], nc = M.first[s + 1] - f, nr = M.nrow[s];
-  const int64_t ld = nc + nr;
-  const double *P = M.panels + M.pptr[s];
-  const int tid = threadIdx.x;
-  if (tid < nc) bs[tid] = B[f + (LU ? M.piv[f + tid] : tid)];
-  __syncthreads();
-  {
-    const int i = tid & (NCMAX - 1), sl = tid / NCMAX; // row i of W, k slice [YS sl, YS sl + YS)
-    double acc = 0.0;
-    if (i < nc) {
-      const int k1 = min(YS * sl + YS, LU ? i : i + 1);
-      for (int kb = YS * sl; kb < k1; kb += 8) {
-        double w[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) w[u] = kb + u < k1 ? P[i + (int64_t)(kb + u) * ld] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc += w[u] * bs[min(kb + u, nc - 1)];
-      }
-    }
-    part[sl * NCMAX + i] = acc;
-  }
-  __syncthreads();
-  if (tid < nc) ys[tid] = (LU ? bs[tid] : 0.0) + ((part[tid] + part[NCMAX + tid]) + (part[2 * NCMAX + tid] + part[3 * NCMAX + tid]));
-  __syncthreads();
-  if (item == 0) {
-    if (tid < nc) Y[f + tid] = ys[tid];
-    return;
-  }
-  const int r0 = (item - 1) * TILE, rl = tid & 63, sl = tid >> 6; // row rl of the tile, k slice [16 sl, 16 sl + 16)
-  double acc = 0.0;
-  if (r0 + rl < nr) {
-    double w[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) w[u] = 16 * sl + u < nc ? P[nc + r0 + rl + (int64_t)(16 * sl + u) * ld] : 0.0;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) acc += w[u] * ys[min(16 * sl + u, nc - 1)];
-  }
-  part[sl * TILE + rl] = acc;
-  __syncthreads();
-  if (tid < TILE && r0 + tid < nr) {
-    double sum = 0.0;
-#pragma unroll
-    for (int q = 0; q < NCMAX / 16; ++q) sum += part[q * TILE + tid];
-    unsafeAtomicAdd(B + (M.rows + M.rptr[s])[r0 + tid], -sum);
-  }
-}
-// out[k] += sum over 64 rows of a tile of block[r][k] x[rows[r]]: thread = (row rl, k slice of 16); blk: first row of the tile in the
-// nrow x ncol block (leading dimension bld); results of the 64 rows are summed over the wavefront
-__device__ __forceinline__ void s1_tile_tdot(const double *__restrict__ blk, int64_t bld, int32_t nc, int rn, int rl, int sl, double xr, double (&acc)[16])
-{
-  double w[16];
-#pragma unroll
-  for (int u = 0; u < 16; ++u) w[u] = (rl < rn && 16 * sl + u < nc) ? blk[rl + (int64_t)(16 * sl + u) * bld] : 0.0;
-#pragma unroll
-  for (int u = 0; u < 16; ++u) acc[u] += w[u] * xr;
-}
-template <bool LU, int NCMAX>
-__global__ __launch_bounds__(4 * NCMAX) void k_sn_bwd1_partial(Meta M, const int32_t *__restrict__ big_sn, const int32_t *__restrict__ pre, int cnt, const double *__restrict__ X,
-                                                          double *__restrict__ partial)
-{
-  const int it = find_item(pre, cnt, (int32_t)blockIdx.x);
-  const int32_t s = big_sn[it];
-  const int item = (int)blockIdx.x - pre[it];
-  const int32_t nc = M.first[s + 1] - M.first[s], nr = M.nrow[s];
-  const double *blk = LU ? M.upanels + M.uptr[s] : M.panels + M.pptr[s] + nc;
-  const int64_t bld = LU ? (int64_t)nr : (int64_t)nc + nr;
-  const int32_t *R = M.rows + M.rptr[s];
-  const int tid = threadIdx.x, rl = tid & 63, sl = tid >> 6;
-  double acc[16];
-#pragma unroll
-  for (int u = 0; u < 16; ++u) acc[u] = 0.0;
-  for (int sub = 0; sub < BWD_ROWS / TILE; ++sub) {
-    const int r0 = item * BWD_ROWS + sub * TILE, rn = min(TILE, nr - r0);
-    if (rn <= 0) break;
-    s1_tile_tdot(blk + r0, bld, nc, rn, rl, sl, rl < rn ? X[R[r0 + rl]] : 0.0, acc);
-  }
-  double *out = partial + (int64_t)blockIdx.x * SN_MAX_COLS;
-#pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const double v = s1_wave_sum(acc[u]);
-    if (rl == 0 && 16 * sl + u < nc) out[16 * sl + u] = v;
-  }
-}
-template <bool LU, int NCMAX>
-__global__ __launch_bounds__(4 * NCMAX) void k_sn_bwd1_diag(Meta M, const int32_t *__restrict__ lev_sn, const int32_t *__restrict__ big_index, const int32_t *__restrict__ pre_big,
-                                                       const double *__restrict__ partial, const double *__restrict__ Y, double *__restrict__ B)
-{
-  constexpr int XS = NCMAX / 4;
-  __shared__ double t[NCMAX], part[4 * NCMAX];
-  const int32_t s = lev_sn[blockIdx.x];
-  const int32_t f = M.first[s], nc = M.first[s + 1] - f, nr = M.nrow[s];
-  const int64_t ld = nc + nr;
-  const double *P = M.panels + M.pptr[s];
-  const int32_t *R = M.rows + M.rptr[s];
-  const int tid = threadIdx.x, rl = tid & 63, sl = tid >> 6;
-  const int bi = big_index[blockIdx.x];
-  if (bi >= 0) {
-    if (tid < nc) {
-      double acc = Y[f + tid];
-      const double *pp = partial + (int64_t)pre_big[bi] * SN_MAX_COLS + tid;
-      const int npart = (nr + BWD_ROWS - 1) / BWD_ROWS;
-      for (int q = 0; q < npart; ++q) acc -= pp[(int64_t)q * SN_MAX_COLS];
-      t[tid] = acc;
-    }
-  } else {
-    const double *blk = LU ? M.upanels + M.uptr[s] : P + nc;
-    const int64_t bld = LU ? (int64_t)nr : ld;
-    double acc[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) acc[u] = 0.0;
-    for (int r0 = 0; r0 < nr; r0 += TILE) {
-      const int rn = min(TILE, nr - r0);
-      s1_tile_tdot(blk + r0, bld, nc, rn, rl, sl, rl < rn ? B[R[r0 + rl]] : 0.0, acc);
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const double v = s1_wave_sum(acc[u]);
-      if (rl == 0 && 16 * sl + u < nc) t[16 * sl + u] = Y[f + 16 * sl + u] - v;
-    }
-  }
-  __syncthreads();
-  { // x = W^T t (Cholesky: x_i = sum_{k >= i} W[k][i] t_k) resp. U^-1 t (x_i = sum_{k >= i} U^-1[i][k] t_k): thread = (i, k slice of 32)
-    const int i = tid & (NCMAX - 1), q = tid / NCMAX;
-    double acc = 0.0;
-    if (i < nc) {
-      const int k0 = max(XS * q, i), k1 = min(XS * q + XS, nc);
-      for (int kb = k0; kb < k1; kb += 8) {
-        double w[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) w[u] = kb + u < k1 ? (LU ? P[i + (int64_t)(kb + u) * ld] : P[kb + u + (int64_t)i * ld]) : 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc += w[u] * t[min(kb + u, nc - 1)];
-      }
-    }
-    part[q * NCMAX + i] = acc;
-  }
-  __syncthreads();
-  if (tid < nc) B[f + tid] = (part[tid] + part[NCMAX + tid]) + (part[2 * NCMAX + tid] + part[3 * NCMAX + tid]);
-}
+// ---- ONE right-hand side (the Schwarz apply inside a Krylov loop): sn_solve1.hpp ---------------------------------------------------
+} // namespace sn
+#include "sn_solve1.hpp"
+namespace sn {
 
 // ---- host driver -------------------------------------------------------------------------------------------------------------------
 struct Factor {
   int64_t n = 0, entries = 0;
+  int nblocks = 1;
   int32_t nsn = 0, nlev = 0;
   double flops = 0.0;
   Meta M{};
@@ -1097,6 +961,12 @@ struct Factor {
   std::vector<int32_t> lev_ptr;          // [nlev + 1] into lev_sn
   std::vector<int32_t> lev_big_ptr;      // [nlev + 1] into big_sn
   std::vector<int32_t> lev_maxnc;        // widest supernode of the level
+  // Colours (deterministic updates): supernodes of one level whose row lists intersect would subtract from the same ancestor entries.
+  // They get different colours; the level's list in lev_sn is sorted by colour and the update kernels run colour by colour, so every
+  // panel entry receives its contributions in ONE order (level, colour) whatever the hardware does -- no atomics.
+  std::vector<int32_t> lev_phase_ptr;    // [nlev + 1] into phase_k
+  std::vector<int32_t> phase_k;          // first position (relative to lev_ptr[l]) of every colour of every level, plus the level's end
+  std::vector<int32_t> h_preU, h_preUF;  // host copies of the update tile prefixes (launch bounds of a colour)
   // device
   int32_t *d_first = nullptr, *d_nrow = nullptr, *d_rows = nullptr, *d_sn_of_col = nullptr, *d_iperm = nullptr, *d_perm = nullptr;
   int64_t *d_rptr = nullptr, *d_pptr = nullptr;
@@ -1116,16 +986,37 @@ struct Factor {
   int32_t *d_preUF = nullptr;
   double *d_partial = nullptr;
   int64_t partial_cap = 0; // doubles
+  // single-vector solves: the persistent kernel for the top levels (sn_solve1.hpp)
+  std::vector<int32_t> sn_block;  // block of every supernode
+  int32_t ltop = 0, ntop = 0;     // tree levels ltop .. nlev - 1 are walked by k_sn_top1 (ntop = 0: level kernels only)
+  TopPlan top{};
+  int32_t *d_top_ints = nullptr;  // all integer arrays of the plan in one allocation
+  double *d_top_partial = nullptr;
+  TopSync *d_top_sync = nullptr;
+  unsigned long long *d_top_flags = nullptr;
+  int top_grid = 0;
+  int64_t *d_tptr = nullptr;  // transposed row lists (Meta::tptr / tidx)
+  int32_t *d_tidx = nullptr;
+  double *d_contrib = nullptr; // slots of the forward sweep: one per entry of `rows` and right-hand side
+  int64_t contrib_cap = 0, nrows_total = 0;
   int64_t max_big_tiles = 0;
   void release()
   {
     for (void *p : {(void *)d_first, (void *)d_nrow, (void *)d_rows, (void *)d_sn_of_col, (void *)d_iperm, (void *)d_perm, (void *)d_rptr, (void *)d_pptr, (void *)d_panels,
                     (void *)d_lev_sn, (void *)d_preT, (void *)d_preU, (void *)d_big_sn, (void *)d_big_index, (void *)d_preB, (void *)d_err, (void *)d_partial,
-                    (void *)d_upanels, (void *)d_uptr, (void *)d_piv, (void *)d_preUF})
+                    (void *)d_upanels, (void *)d_uptr, (void *)d_piv, (void *)d_preUF, (void *)d_tptr, (void *)d_tidx, (void *)d_contrib, (void *)d_top_ints, (void *)d_top_partial, (void *)d_top_sync, (void *)d_top_flags})
       if (p) (void)hipFree(p);
     d_first = d_nrow = d_rows = d_sn_of_col = d_iperm = d_perm = d_lev_sn = d_preT = d_preU = d_big_sn = d_big_index = d_preB = nullptr;
     d_rptr = d_pptr = nullptr;
-    d_panels = d_partial = d_upanels = nullptr;
+    d_panels = d_partial = d_upanels = d_contrib = nullptr;
+    d_tptr = nullptr;
+    d_tidx = nullptr;
+    d_top_ints = nullptr;
+    d_top_partial = nullptr;
+    d_top_sync = nullptr;
+    d_top_flags = nullptr;
+    top = TopPlan{};
+    ntop = 0;
     d_uptr = nullptr;
     d_piv = d_preUF = nullptr;
     d_err = nullptr;
@@ -1140,11 +1031,83 @@ static inline bool up(const std::vector<T> &h, T **d)
   return h.empty() || hipMemcpy(*d, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice) == hipSuccess;
 }
 
+// Plan of the persistent single-vector kernel (sn_solve1.hpp): the top levels are those from the first level on which every later
+// level has at most TOP_MAX_PER_LEVEL supernodes (the separator chains: one supernode per block and level); fewer than four such
+// levels are not worth a launch of their own.  DDM_SN_TOP_MAX overrides the bound (0: level kernels only).
+static inline bool build_top_plan(Factor &F, int nblocks, const std::vector<int32_t> &lev_sn, const std::vector<int32_t> &nrow)
+{
+  int top_max = 32;
+  if (const char *e = std::getenv("DDM_SN_TOP_MAX")) top_max = std::atoi(e);
+  int32_t ltop = F.nlev;
+  while (ltop > 0 && F.lev_ptr[(size_t)ltop] - F.lev_ptr[(size_t)ltop - 1] <= top_max) --ltop;
+  F.ltop = F.nlev;
+  F.ntop = 0;
+  if (F.nlev - ltop < 4) return true;
+  const int32_t ntop = F.nlev - ltop;
+  std::vector<int32_t> a_ptr((size_t)8 * ntop + 1, 0), f_ptr((size_t)8 * ntop + 1, 0), p_ptr((size_t)8 * ntop + 1, 0), a_sn, f_items, p_items, p_first((size_t)F.nsn, 0);
+  for (int c = 0; c < 8; ++c)
+    for (int32_t j = 0; j < ntop; ++j) {
+      const int32_t l = ltop + j;
+      for (int32_t k = F.lev_ptr[(size_t)l]; k < F.lev_ptr[(size_t)l + 1]; ++k) {
+        const int32_t s = lev_sn[(size_t)k];
+        if (F.sn_block[(size_t)s] % 8 != c) continue;
+        a_sn.push_back(s);
+        const int32_t nr = nrow[(size_t)s];
+        for (int32_t t = 0; t < (nr + TILE - 1) / TILE; ++t) {
+          f_items.push_back(s);
+          f_items.push_back(t);
+        }
+        p_first[(size_t)s] = (int32_t)(p_items.size() / 2);
+        for (int32_t q = 0; q < (nr + S1_CHUNK_ROWS - 1) / S1_CHUNK_ROWS; ++q) {
+          p_items.push_back(s);
+          p_items.push_back(q);
+        }
+      }
+      const size_t seg = (size_t)c * ntop + j;
+      a_ptr[seg + 1] = (int32_t)a_sn.size();
+      f_ptr[seg + 1] = (int32_t)(f_items.size() / 2);
+      p_ptr[seg + 1] = (int32_t)(p_items.size() / 2);
+    }
+  std::vector<int32_t> all;
+  auto put = [&](const std::vector<int32_t> &v) {
+    const size_t o = all.size();
+    all.insert(all.end(), v.begin(), v.end());
+    return o;
+  };
+  const size_t o_ap = put(a_ptr), o_as = put(a_sn), o_fp = put(f_ptr), o_fi = put(f_items), o_pp = put(p_ptr), o_pi = put(p_items), o_pf = put(p_first);
+  if (!up(all, &F.d_top_ints)) return false;
+  if (hipMalloc((void **)&F.d_top_partial, sizeof(double) * std::max<size_t>(p_items.size() / 2, 1) * SN_MAX_COLS) != hipSuccess) return false;
+  if (hipMalloc((void **)&F.d_top_sync, sizeof(TopSync)) != hipSuccess || hipMemset(F.d_top_sync, 0, sizeof(TopSync)) != hipSuccess) return false;
+  const size_t fbytes = sizeof(unsigned long long) * 9 * TOP_MAX_WG * TOP_FLAG_STRIDE;
+  if (hipMalloc((void **)&F.d_top_flags, fbytes) != hipSuccess || hipMemset(F.d_top_flags, 0, fbytes) != hipSuccess) return false;
+  F.top.ntop = ntop;
+  F.top.a_ptr = F.d_top_ints + o_ap;
+  F.top.a_sn = F.d_top_ints + o_as;
+  F.top.f_ptr = F.d_top_ints + o_fp;
+  F.top.f_items = F.d_top_ints + o_fi;
+  F.top.p_ptr = F.d_top_ints + o_pp;
+  F.top.p_items = F.d_top_ints + o_pi;
+  F.top.p_first = F.d_top_ints + o_pf;
+  // co-resident grid: two workgroups of 512 threads per CU
+  int dev = 0, ncu = 0, per_cu = 0;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) return true; // (no device: host-only use)
+  const void *fn = F.lu ? (const void *)k_sn_top1<true> : (const void *)k_sn_top1<false>;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, TOP_THREADS, 0) != hipSuccess || per_cu < 1) return true;
+  F.top_grid = std::min(per_cu, 2) * (ncu / 8 * 8);
+  if (F.top_grid < 8 || F.top_grid > TOP_MAX_WG) return true;
+  F.ltop = ltop;
+  F.ntop = ntop;
+  (void)nblocks;
+  return true;
+}
+
 // symbolic results of all blocks -> one global structure on the device.  Returns false on an allocation failure.
 static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *block_ptr, std::vector<BlockSym> &BS, bool lu = false)
 {
   F.n = n;
   F.lu = lu;
+  F.nblocks = (int)nblocks;
   std::vector<int32_t> first, nrow, rows, sn_of_col((size_t)n), iperm((size_t)n), level;
   std::vector<int64_t> rptr(1, 0), pptr(1, 0);
   F.h_perm.resize((size_t)n);
@@ -1162,6 +1125,7 @@ static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *b
       const int64_t nc = S.first[(size_t)s + 1] - S.first[(size_t)s];
       pptr.push_back(pptr.back() + nc * (nc + (r1 - r0)));
       level.push_back(S.level[(size_t)s]);
+      F.sn_block.push_back((int32_t)b);
       for (int32_t c = S.first[(size_t)s]; c < S.first[(size_t)s + 1]; ++c) sn_of_col[(size_t)(off + c)] = gs;
     }
     for (int32_t k = 0; k < S.n; ++k) {
@@ -1183,6 +1147,47 @@ static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *b
   for (int32_t l = 0; l < nlev; ++l) F.lev_ptr[(size_t)l + 1] += F.lev_ptr[(size_t)l];
   std::vector<int32_t> lev_sn((size_t)F.nsn), pos(F.lev_ptr.begin(), F.lev_ptr.end() - 1);
   for (int32_t s = 0; s < F.nsn; ++s) lev_sn[(size_t)pos[(size_t)level[(size_t)s]]++] = s;
+  // colours of the update phases (see Factor::lev_phase_ptr): greedy, in list order; a row remembers which colours of the CURRENT
+  // level already subtract from it
+  F.lev_phase_ptr.assign((size_t)nlev + 1, 0);
+  F.phase_k.clear();
+  {
+    std::vector<uint64_t> rowmask((size_t)n, 0);
+    std::vector<int32_t> rowstamp((size_t)n, -1), colour((size_t)F.nsn, 0), sorted;
+    for (int32_t l = 0; l < nlev; ++l) {
+      const int32_t k0 = F.lev_ptr[(size_t)l], k1 = F.lev_ptr[(size_t)l + 1];
+      int ncol = 1;
+      for (int32_t k = k0; k < k1; ++k) {
+        const int32_t s = lev_sn[(size_t)k];
+        uint64_t used = 0;
+        for (int64_t q = rptr[(size_t)s]; q < rptr[(size_t)s + 1]; ++q) {
+          const int32_t r = rows[(size_t)q];
+          if (rowstamp[(size_t)r] == l) used |= rowmask[(size_t)r];
+        }
+        if (~used == 0) return false; // more than 64 mutually conflicting supernodes in one level (not seen: <= 11 on 3-D grids)
+        const int c = __builtin_ctzll(~used);
+        colour[(size_t)s] = c;
+        ncol = std::max(ncol, c + 1);
+        for (int64_t q = rptr[(size_t)s]; q < rptr[(size_t)s + 1]; ++q) {
+          const int32_t r = rows[(size_t)q];
+          if (rowstamp[(size_t)r] != l) {
+            rowstamp[(size_t)r] = l;
+            rowmask[(size_t)r] = 0;
+          }
+          rowmask[(size_t)r] |= 1ull << c;
+        }
+      }
+      sorted.assign(lev_sn.begin() + k0, lev_sn.begin() + k1);
+      std::stable_sort(sorted.begin(), sorted.end(), [&](int32_t a, int32_t b) { return colour[(size_t)a] < colour[(size_t)b]; });
+      std::copy(sorted.begin(), sorted.end(), lev_sn.begin() + k0);
+      F.lev_phase_ptr[(size_t)l] = (int32_t)F.phase_k.size();
+      for (int32_t k = k0; k < k1; ++k)
+        if (k == k0 || colour[(size_t)lev_sn[(size_t)k]] != colour[(size_t)lev_sn[(size_t)k - 1]]) F.phase_k.push_back(k - k0);
+      F.phase_k.push_back(k1 - k0);
+      (void)ncol;
+    }
+    F.lev_phase_ptr[(size_t)nlev] = (int32_t)F.phase_k.size();
+  }
   std::vector<int32_t> preT((size_t)F.nsn + nlev), preU((size_t)F.nsn + nlev), preUF((size_t)F.nsn + nlev), big_sn, big_index((size_t)F.nsn, -1), preB;
   std::vector<int64_t> uptr(1, 0);
   for (int32_t s = 0; s < F.nsn; ++s) uptr.push_back(uptr.back() + (int64_t)nrow[(size_t)s] * (first[(size_t)s + 1] - first[(size_t)s]));
@@ -1227,6 +1232,20 @@ static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *b
     F.max_big_tiles = std::max(F.max_big_tiles, aB);
     (void)bbase;
   }
+  F.h_preU = preU;
+  F.h_preUF = preUF;
+  // transposed row lists (counting sort of the entries of `rows` by value: ascending position = ascending source supernode)
+  if (rows.size() >= (size_t)0x7fffffff) return false;
+  F.nrows_total = (int64_t)rows.size();
+  {
+    std::vector<int64_t> tptr((size_t)n + 1, 0);
+    for (int32_t r : rows) tptr[(size_t)r + 1]++;
+    for (int64_t c = 0; c < n; ++c) tptr[(size_t)c + 1] += tptr[(size_t)c];
+    std::vector<int32_t> tidx(rows.size());
+    std::vector<int64_t> fill(tptr.begin(), tptr.end() - 1);
+    for (size_t q = 0; q < rows.size(); ++q) tidx[(size_t)fill[(size_t)rows[q]]++] = (int32_t)q;
+    if (!up(tptr, &F.d_tptr) || !up(tidx, &F.d_tidx)) return false;
+  }
   bool ok = up(first, &F.d_first) && up(nrow, &F.d_nrow) && up(rows, &F.d_rows) && up(sn_of_col, &F.d_sn_of_col) && up(iperm, &F.d_iperm) && up(F.h_perm, &F.d_perm) &&
             up(rptr, &F.d_rptr) && up(pptr, &F.d_pptr) && up(lev_sn, &F.d_lev_sn) && up(preT, &F.d_preT) && up(preU, &F.d_preU) && up(big_sn, &F.d_big_sn) &&
             up(big_index, &F.d_big_index) && up(preB, &F.d_preB);
@@ -1238,6 +1257,7 @@ static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *b
     if (hipMalloc((void **)&F.d_upanels, sizeof(double) * (size_t)std::max<int64_t>(F.uentries, 1)) != hipSuccess) return false;
     if (hipMalloc((void **)&F.d_piv, sizeof(int32_t) * (size_t)std::max<int64_t>(n, 1)) != hipSuccess) return false;
   }
+  if (!build_top_plan(F, (int)nblocks, lev_sn, nrow)) return false;
   F.M.nsn = F.nsn;
   F.M.first = F.d_first;
   F.M.nrow = F.d_nrow;
@@ -1245,6 +1265,8 @@ static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *b
   F.M.rows = F.d_rows;
   F.M.pptr = F.d_pptr;
   F.M.sn_of_col = F.d_sn_of_col;
+  F.M.tptr = F.d_tptr;
+  F.M.tidx = F.d_tidx;
   F.M.panels = F.d_panels;
   F.M.upanels = F.d_upanels;
   F.M.uptr = F.d_uptr;
@@ -1253,11 +1275,13 @@ static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *b
 }
 
 // numeric factorisation of the matrix (device CSR, original numbering); *bad = supernode + 1 whose diagonal block was not positive definite
-static inline hipError_t factorize(Factor &F, hipStream_t st, const int64_t *d_rp, const int32_t *d_ci, const double *d_va, unsigned *bad)
+// tiny: replacement of a vanishing pivot column in the L U variant; *perturbed: how many were replaced
+static inline hipError_t factorize(Factor &F, hipStream_t st, const int64_t *d_rp, const int32_t *d_ci, const double *d_va, unsigned *bad, double tiny = 0.0,
+                                   unsigned *perturbed = nullptr)
 {
   hipError_t e = hipMemsetAsync(F.d_panels, 0, sizeof(double) * (size_t)std::max<int64_t>(F.entries, 1), st);
   if (e != hipSuccess) return e;
-  (void)hipMemsetAsync(F.d_err, 0, 4, st);
+  (void)hipMemsetAsync(F.d_err, 0, 16, st);
   if (F.lu) {
     e = hipMemsetAsync(F.d_upanels, 0, sizeof(double) * (size_t)std::max<int64_t>(F.uentries, 1), st);
     if (e != hipSuccess) return e;
@@ -1277,29 +1301,45 @@ static inline hipError_t factorize(Factor &F, hipStream_t st, const int64_t *d_r
     const int32_t *lsn = F.d_lev_sn + F.lev_ptr[(size_t)l];
     const int nc = F.lev_maxnc[(size_t)l];
     if (F.lu) {
-      hipLaunchKernelGGL(k_sn_lu_diag, dim3((unsigned)cnt), dim3(256), (size_t)(nc | 1) * nc * 8, st, F.M, lsn, F.d_err);
+      hipLaunchKernelGGL(k_sn_lu_diag, dim3((unsigned)cnt), dim3(256), (size_t)(nc | 1) * nc * 8, st, F.M, lsn, F.d_err, tiny);
       if (F.h_tilesT[(size_t)l] > 0)
         hipLaunchKernelGGL(k_sn_lu_panel, dim3((unsigned)F.h_tilesT[(size_t)l]), dim3(256), 0, st, F.M, lsn, (const int32_t *)(F.d_preT + F.lev_ptr[(size_t)l] + l), cnt);
-      if (F.h_tilesUF[(size_t)l] > 0)
-        hipLaunchKernelGGL(k_sn_lu_update, dim3((unsigned)F.h_tilesUF[(size_t)l]), dim3(256), 0, st, F.M, lsn, (const int32_t *)(F.d_preUF + F.lev_ptr[(size_t)l] + l), cnt);
+      for (int32_t ph = F.lev_phase_ptr[(size_t)l]; ph + 1 < F.lev_phase_ptr[(size_t)l + 1]; ++ph) { // colour by colour
+        const int32_t b0 = F.h_preUF[(size_t)(F.lev_ptr[(size_t)l] + l + F.phase_k[(size_t)ph])], b1 = F.h_preUF[(size_t)(F.lev_ptr[(size_t)l] + l + F.phase_k[(size_t)ph + 1])];
+        if (b1 > b0) hipLaunchKernelGGL(k_sn_lu_update, dim3((unsigned)(b1 - b0)), dim3(256), 0, st, F.M, lsn, (const int32_t *)(F.d_preUF + F.lev_ptr[(size_t)l] + l), cnt, (int)b0);
+      }
       continue;
     }
     hipLaunchKernelGGL(k_sn_diag, dim3((unsigned)cnt), dim3(256), (size_t)(nc | 1) * nc * 8, st, F.M, lsn, F.d_err);
     if (F.h_tilesT[(size_t)l] > 0)
       hipLaunchKernelGGL(k_sn_panel, dim3((unsigned)F.h_tilesT[(size_t)l]), dim3(256), 0, st, F.M, lsn, (const int32_t *)(F.d_preT + F.lev_ptr[(size_t)l] + l), cnt);
-    if (F.h_tilesU[(size_t)l] > 0)
-      hipLaunchKernelGGL(k_sn_update, dim3((unsigned)F.h_tilesU[(size_t)l]), dim3(256), 0, st, F.M, lsn, (const int32_t *)(F.d_preU + F.lev_ptr[(size_t)l] + l), cnt);
+    for (int32_t ph = F.lev_phase_ptr[(size_t)l]; ph + 1 < F.lev_phase_ptr[(size_t)l + 1]; ++ph) { // colour by colour
+      const int32_t b0 = F.h_preU[(size_t)(F.lev_ptr[(size_t)l] + l + F.phase_k[(size_t)ph])], b1 = F.h_preU[(size_t)(F.lev_ptr[(size_t)l] + l + F.phase_k[(size_t)ph + 1])];
+      if (b1 > b0) hipLaunchKernelGGL(k_sn_update, dim3((unsigned)(b1 - b0)), dim3(256), 0, st, F.M, lsn, (const int32_t *)(F.d_preU + F.lev_ptr[(size_t)l] + l), cnt, (int)b0);
+    }
   }
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   e = hipStreamSynchronize(st);
   if (e != hipSuccess) return e;
-  return hipMemcpy(bad, F.d_err, 4, hipMemcpyDeviceToHost);
+  unsigned words[4] = {0, 0, 0, 0};
+  e = hipMemcpy(words, F.d_err, 16, hipMemcpyDeviceToHost);
+  *bad = words[0];
+  if (perturbed) *perturbed = words[2];
+  return e;
 }
 
 // scratch of the backward sweep for m right-hand sides (call OUTSIDE a stream capture)
 static inline bool reserve(Factor &F, int m)
 {
+  const int64_t cneed = F.nrows_total * (int64_t)m; // slots of the forward sweep
+  if (cneed > F.contrib_cap) {
+    if (F.d_contrib) (void)hipFree(F.d_contrib);
+    F.d_contrib = nullptr;
+    F.contrib_cap = 0;
+    if (hipMalloc((void **)&F.d_contrib, sizeof(double) * (size_t)std::max<int64_t>(cneed, 1)) != hipSuccess) return false;
+    F.contrib_cap = cneed;
+  }
   const int64_t need = F.max_big_tiles * SN_MAX_COLS * (int64_t)m;
   if (need <= F.partial_cap) return true;
   if (F.d_partial) (void)hipFree(F.d_partial);
@@ -1311,18 +1351,24 @@ static inline bool reserve(Factor &F, int m)
 }
 
 template <bool LU>
-static inline void solve_t(const Factor &F, hipStream_t st, int m, double *B, int64_t ldb, double *Yvec)
+static inline void solve_t(const Factor &F, hipStream_t st, int m, double *B, int64_t ldb, double *Yvec, unsigned *err)
 {
-  if (m == 1 && ldb == 1 && Yvec) { // the single-vector kernels: three launches per level
-    for (int32_t l = 0; l < F.nlev; ++l) {
+  if (m == 1 && ldb == 1 && Yvec) { // the single-vector kernels (sn_solve1.hpp): level launches at the bottom, one persistent launch for the top
+    const int32_t lbot = F.ntop > 0 ? F.ltop : F.nlev; // levels [0, lbot) by launches
+    for (int32_t l = 0; l < lbot; ++l) {
       const int32_t cnt = F.lev_ptr[(size_t)l + 1] - F.lev_ptr[(size_t)l];
       if (cnt == 0) continue;
       const int32_t *lsn = F.d_lev_sn + F.lev_ptr[(size_t)l], *preT = F.d_preT + F.lev_ptr[(size_t)l] + l;
       const unsigned grid = (unsigned)(F.h_tilesT[(size_t)l] + cnt);
-      if (F.lev_maxnc[(size_t)l] <= 64) hipLaunchKernelGGL((k_sn_fwd1<LU, 64>), dim3(grid), dim3(256), 0, st, F.M, lsn, preT, cnt, B, Yvec);
-      else hipLaunchKernelGGL((k_sn_fwd1<LU, 128>), dim3(grid), dim3(512), 0, st, F.M, lsn, preT, cnt, B, Yvec);
+      if (F.lev_maxnc[(size_t)l] <= 64) hipLaunchKernelGGL((k_sn_fwd1<LU, 64>), dim3(grid), dim3(256), 0, st, F.M, lsn, preT, cnt, (const double *)B, Yvec, F.d_contrib);
+      else hipLaunchKernelGGL((k_sn_fwd1<LU, 128>), dim3(grid), dim3(512), 0, st, F.M, lsn, preT, cnt, (const double *)B, Yvec, F.d_contrib);
     }
-    for (int32_t l = F.nlev - 1; l >= 0; --l) {
+    if (F.ntop > 0) {
+      hipLaunchKernelGGL(k_sn_top_prologue, dim3(1), dim3(64), 0, st, F.d_top_sync);
+      hipLaunchKernelGGL(k_sn_top1<LU>, dim3((unsigned)F.top_grid), dim3(TOP_THREADS), 0, st, F.M, F.top, F.nblocks, F.nblocks < 8 ? 1 : 0, B, Yvec, F.d_contrib, F.d_top_partial,
+                         F.d_top_sync, F.d_top_flags, err ? err : F.d_err + 1);
+    }
+    for (int32_t l = lbot - 1; l >= 0; --l) {
       const int32_t cnt = F.lev_ptr[(size_t)l + 1] - F.lev_ptr[(size_t)l];
       if (cnt == 0) continue;
       const int32_t *lsn = F.d_lev_sn + F.lev_ptr[(size_t)l];
@@ -1350,9 +1396,10 @@ static inline void solve_t(const Factor &F, hipStream_t st, int m, double *B, in
     if (cnt == 0) continue;
     const int32_t *lsn = F.d_lev_sn + F.lev_ptr[(size_t)l];
     const size_t lds = (size_t)F.lev_maxnc[(size_t)l] * mpad * 8;
-    hipLaunchKernelGGL(k_sn_fwd_diag<LU>, dim3((unsigned)cnt), dim3(256), lds, st, F.M, lsn, m, B, ldb);
+    hipLaunchKernelGGL(k_sn_fwd_diag<LU>, dim3((unsigned)cnt), dim3(256), lds, st, F.M, lsn, m, B, ldb, (const double *)F.d_contrib);
     if (F.h_tilesT[(size_t)l] > 0)
-      hipLaunchKernelGGL(k_sn_fwd_update, dim3((unsigned)F.h_tilesT[(size_t)l]), dim3(256), lds, st, F.M, lsn, (const int32_t *)(F.d_preT + F.lev_ptr[(size_t)l] + l), cnt, m, B, ldb);
+      hipLaunchKernelGGL(k_sn_fwd_update, dim3((unsigned)F.h_tilesT[(size_t)l]), dim3(256), lds, st, F.M, lsn, (const int32_t *)(F.d_preT + F.lev_ptr[(size_t)l] + l), cnt, m,
+                         (const double *)B, ldb, F.d_contrib);
   }
   for (int32_t l = F.nlev - 1; l >= 0; --l) {
     const int32_t cnt = F.lev_ptr[(size_t)l + 1] - F.lev_ptr[(size_t)l];
@@ -1370,10 +1417,11 @@ static inline void solve_t(const Factor &F, hipStream_t st, int m, double *B, in
 
 // in-place solve (L L^T resp. P^T L U) X = B on the permuted row-major work block (n x m, leading dimension ldb); enqueues only
 // Yvec: a second n-vector for the single-vector kernels (m == 1), or nullptr = the block kernels
-static inline void solve(const Factor &F, hipStream_t st, int m, double *B, int64_t ldb, double *Yvec = nullptr)
+// err: status word of the persistent single-vector kernel (a device-visible word the caller watches; nullptr: the factor's own)
+static inline void solve(const Factor &F, hipStream_t st, int m, double *B, int64_t ldb, double *Yvec = nullptr, unsigned *err = nullptr)
 {
-  if (F.lu) solve_t<true>(F, st, m, B, ldb, Yvec);
-  else solve_t<false>(F, st, m, B, ldb, Yvec);
+  if (F.lu) solve_t<true>(F, st, m, B, ldb, Yvec, err);
+  else solve_t<false>(F, st, m, B, ldb, Yvec, err);
 }
 
 } // namespace sn

@@ -169,9 +169,16 @@ int ddm_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int
  *   device  SUPERNODAL Cholesky (general = 0) or L U (general = 1) with numeric factorisation AND solves on the GPU (csrc/sn_chol.hpp):
  *           nested-dissection supernodes of at most 128 columns, dense panels, FP64-MFMA updates, level by level of the supernodal
  *           elimination tree; the host only orders and analyses.  L U: threshold partial pivoting (0.1, UMFPACK's default) INSIDE the
- *           diagonal block of a supernode; rows are never exchanged between supernodes.  Updates of one tree level are added with
- *           hardware FP64 atomics: results are reproducible to rounding, not bit for bit.  DDM_ENOTIMPL if the panels do not fit
- *           into the free device memory.
+ *           diagonal block of a supernode; rows are never exchanged between supernodes; a pivot column that vanishes inside its block
+ *           is replaced by sqrt(eps) max|a_ij| (static perturbation).  ITERATIVE REFINEMENT as dune/ddm/eigensolvers/umfpack.hh:42-129
+ *           (and as UMFPACK's own solve): backward error omega = ||b - A x|| / (||A||_inf ||x|| + ||b||), stop below 1e-14 or when a
+ *           step does not halve it, at most 3 steps -- decided ONCE per factor on a probe right-hand side (the solves stay captured HIP
+ *           graphs), then applied in every single- and multi-vector solve (ddm_ilu0_refinement reports it; DDM_DIRECT_REFINE = off |
+ *           <steps> overrides).  A factor whose probe stays above 1e-9 is refused (DDM_ENUMERIC when the engine was forced, else the
+ *           host engine takes over).  Results are bitwise REPRODUCIBLE since round 4: supernodes of one tree level whose updates would
+ *           meet in an ancestor entry are coloured apart and the colours run one after the other; the forward sweeps write into one
+ *           slot per (supernode, row) and the row's owner adds its slots in a fixed order -- no atomics anywhere.  DDM_ENOTIMPL if the
+ *           panels do not fit into the free device memory.
  *   host    up-looking factorisation on host threads (L U without pivoting for general = 1), CSR level solves on the device
  *           (bitwise reproducible).
  * The host half of the device engine alone (no device needed; CPU tests): */
@@ -184,6 +191,9 @@ int ddm_sn_host_sizes(const ddm_sn_host *H, int64_t block, int64_t *sizes, doubl
 int ddm_sn_host_get(const ddm_sn_host *H, int64_t block, int32_t *perm, int32_t *first, int64_t *rptr, int32_t *rows, int32_t *parent, int32_t *level);
 int ddm_ilu0_is_direct(const ddm_ilu0 *F); /* 1 for a ddm_chol_create / ddm_direct_create factor */
 int64_t ddm_ilu0_nnz(const ddm_ilu0 *F);   /* stored factor entries (L + D + U) */
+/* iterative refinement of a device factor: returns the steps every solve performs; omega[5] (may be NULL) = backward error of the probe
+ * right-hand side after 0, 1, .. steps (0 where not run) */
+int ddm_ilu0_refinement(const ddm_ilu0 *F, double *omega);
 /* The host part alone (no device needed; used by the CPU tests): va == NULL stops after the symbolic analysis.
  * get: perm[n] (perm[new] = old), and the factor in the storage convention of ddm_ilu0_get_factors_host -- CSR over the
  * PERMUTED indices with pattern L + D + L^T: unit lower factor, inverse pivots on the diagonal, D L^T above. */
