@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=8)
     ap.add_argument("--no-order-leg", action="store_true", help="skip the second oracle run (other summation order) of the cpu leg")
     ap.add_argument("--no-geneo-check", action="store_true", help="skip the host (scipy) residual check of the device GenEO eigenpairs")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the second workload (configs[3], bench_convdiff.py --problem dg) appended as `secondary`")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -324,6 +325,28 @@ def main():
             "geneo": None if getattr(tl, "geneo_info", None) is None else dict({k: tl.geneo_info[k] for k in ("iterations", "converged", "worst_residual", "used_direct", "setup_s", "iterate_s", "nev")}, host_check=geneo_check),
             "roofline": roofline, "iteration_traffic": iteration, "cpu_baseline": cpu,
         }
+        # Second workload of `north_star` where the driver sees it: BASELINE configs[3] (Q1-DG convection-diffusion 512^2, GMRES, GenEO,
+        # `umfpack`-type local solves) run as a CHILD process with the same contract (bench_convdiff.py) once this process has
+        # released the GPU memory of the headline problem; its whole JSON line is embedded.  N = 1 only; --no-secondary skips it.
+        out["secondary"] = None
+        if world == 1 and not args.no_secondary and args.grid == 216:
+            import subprocess
+            try:
+                tl.ctx.close()
+                del tl
+                torch.cuda.empty_cache()
+                t_sec = time.perf_counter()
+                p = subprocess.run([sys.executable, os.path.join(ROOT, "bench_convdiff.py"), "--problem", "dg", "--steps", str(args.steps), "--warmup", str(args.warmup)],
+                                   capture_output=True, text=True, timeout=600)
+                lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+                if p.returncode == 0 and lines:
+                    out["secondary"] = json.loads(lines[-1])
+                    out["secondary"]["wall_s"] = time.perf_counter() - t_sec
+                    log(rank, f"secondary workload (configs[3], DG convection-diffusion): {out['secondary']['value']:.1f} GMRES it/s, local solve {out['secondary']['roofline']['avg_launch_ms']:.2f} ms")
+                else:
+                    out["secondary"] = {"error": (p.stderr or p.stdout)[-800:], "returncode": p.returncode}
+            except Exception as e:   # the headline number above stands on its own
+                out["secondary"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -143,14 +143,16 @@ def main():
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     traffic, traffic_source = None, None
     try:   # HBM bytes of ONE local solve (all its level launches) from the committed rocprofv3 --pmc passes of this command: NOT measured in this run
-        src = f"profiles/r03_pmc_traffic_{args.problem}.json"
+        src = f"profiles/r04_pmc_traffic_{args.problem}.json"
+        if not os.path.exists(os.path.join(ROOT, src)):
+            src = f"profiles/r03_pmc_traffic_{args.problem}.json"
         pmc = json.load(open(os.path.join(ROOT, src)))
         if pmc.get("cells") == (C if args.problem == "dg" else None) and pmc.get("refine") == (None if args.problem == "dg" else args.refine) and cfg["local"] == pmc.get("local_solver") and pmc.get("engine", "levels") == engine:
             traffic, traffic_source = pmc["local_solve_hbm_bytes_corrected"] / world, src
     except Exception:
         traffic = None
     roofline = {"bound": "hbm", "kernel": "local solve: " + ("ILU(0) triangular solve" if cfg["local"] == "ilu0" else
-                                                 "device supernodal factor, one launch per tree level and sweep (sn::k_sn_fwd1, k_sn_bwd1_partial, k_sn_bwd1_diag)" if engine == "supernodal" else
+                                                 "device supernodal factor: one launch per bottom tree level and sweep (sn::k_sn_fwd1, k_sn_bwd1_partial, k_sn_bwd1_diag), one persistent launch for the top levels (sn::k_sn_top1)" if engine == "supernodal" else
                                                  "sparse direct factor, level-scheduled CSR kernels with supernodal blocks (k_trsv_csr_level)"),
                 "engine": engine,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

@@ -1553,8 +1553,8 @@ static double sn_probe_largest_block(const int64_t *rp, const int32_t *ci, int64
 }
 static int ilu0_solve_epilogue(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, const double *scale, const double *add);
 // Fixes the number of iterative-refinement steps of a device factor (ddm_ilu0::refine_steps) from a probe solve with a pseudo-random
-// right-hand side: the loop of dune/ddm/eigensolvers/umfpack.hh:42-129 -- backward error omega = ||b - A x|| / (||A||_inf ||x|| + ||b||),
-// stop below 1e-14, stop when a step does not halve it, at most 3 steps -- run ONCE here instead of in every solve, so that the
+// right-hand side: the loop of dune/ddm/eigensolvers/umfpack.hh:42-129 -- backward error omega = ||b - A x|| / (||A||_inf ||x|| + ||b||)
+// (here: the larger of that and 1e-2 x the componentwise backward error UMFPACK's own solve refines by), stop below 1e-14, stop when a step does not halve it, at most 3 steps -- run ONCE here instead of in every solve, so that the
 // solves stay captured graphs.  DDM_DIRECT_REFINE = off | <steps> overrides.  Returns the last backward error in *omega_out.
 static int sn_probe_refinement(ddm_ctx *ctx, ddm_ilu0 *F, const ddm_csr *A, double *omega_out)
 {
@@ -1605,21 +1605,28 @@ static int sn_probe_refinement(ddm_ctx *ctx, ddm_ilu0 *F, const ddm_csr *A, doub
   auto omega_now = [&](double &om) -> int {
     int r = ddm_memcpy_d2h(ctx, x.data(), dx, sizeof(double) * (size_t)n); // (synchronises the stream)
     if (r) return r;
-    std::vector<double> pr(nth, 0.0), px(nth, 0.0);
+    std::vector<double> pr(nth, 0.0), px(nth, 0.0), pc(nth, 0.0);
     par_rows([&](int64_t r0, int64_t r1, unsigned t) {
-      double sr = 0.0, sx = 0.0;
+      double sr = 0.0, sx = 0.0, wc = 0.0;
       for (int64_t i = r0; i < r1; ++i) {
-        double res = b[(size_t)i];
-        for (int64_t k = rp[i]; k < rp[i + 1]; ++k) res -= va[k] * x[(size_t)ci[k]];
+        double res = b[(size_t)i], den = std::fabs(b[(size_t)i]);
+        for (int64_t k = rp[i]; k < rp[i + 1]; ++k) {
+          res -= va[k] * x[(size_t)ci[k]];
+          den += std::fabs(va[k] * x[(size_t)ci[k]]);
+        }
         sr += res * res;
         sx += x[(size_t)i] * x[(size_t)i];
+        if (den > 0.0) wc = std::max(wc, std::fabs(res) / den);
       }
       pr[t] = sr;
       px[t] = sx;
+      pc[t] = wc;
     });
-    double sr = 0.0, sx = 0.0;
-    for (unsigned t = 0; t < nth; ++t) sr += pr[t], sx += px[t];
-    om = std::sqrt(sr) / (anorm * std::sqrt(sx) + std::sqrt(bn2));
+    double sr = 0.0, sx = 0.0, wc = 0.0;
+    for (unsigned t = 0; t < nth; ++t) sr += pr[t], sx += px[t], wc = std::max(wc, pc[t]);
+    // normwise backward error of umfpack.hh:66-74, and the componentwise one UMFPACK's own solve refines by (max_i |r_i| / (|A||x| + |b|)_i),
+    // weighted so that ONE threshold (1e-14) means: normwise below 1e-14 and componentwise below 1e-12
+    om = std::max(std::sqrt(sr) / (anorm * std::sqrt(sx) + std::sqrt(bn2)), 1e-2 * wc);
     return DDM_OK;
   };
   auto solve_with = [&](int steps) -> int {

@@ -69,9 +69,11 @@ struct Meta { // device pointers
   const int64_t *pptr;      // [nsn + 1] (doubles)
   const int32_t *sn_of_col; // [n]
   // transposed row lists: the entries q of `rows` with rows[q] == c are tidx[tptr[c] .. tptr[c + 1]), ascending in q (= ascending
-  // source supernode).  The forward sweeps write the contribution of supernode s to its row rows[q] into slot q of a scratch array
-  // and the owner of column c subtracts its slots in list order: one summation order, no atomics.
+  // source supernode) within each of the two parts tmid separates.  The SINGLE-VECTOR forward sweep writes what a supernode of the
+  // bottom levels subtracts from its row rows[q] into slot q of a scratch array and the owner of column c subtracts its slots in list
+  // order (sn_solve1.hpp): one summation order, no atomics.  (Top levels and the block solves push coloured updates instead.)
   const int64_t *tptr;      // [n + 1]
+  const int64_t *tmid;      // [n]: tidx[tptr[c] .. tmid[c]) come from supernodes BELOW the top levels (Factor::ltop), the rest from top levels
   const int32_t *tidx;
   double *panels;
   // L U variant (non-symmetric values on the symmetric pattern): the panel of s holds the FULL diagonal block and L_{rows, s};
@@ -671,7 +673,7 @@ constexpr int SOLVE_MT = 3;
 constexpr int SOLVE_UNROLL = 8; // k-steps (of 4) whose global operand loads are issued together
 // Y_s = W_s B_s, in place in the work block (row-major, leading dimension ldb)
 template <bool LU>
-__global__ __launch_bounds__(256) void k_sn_fwd_diag(Meta M, const int32_t *__restrict__ lev_sn, int m, double *__restrict__ B, int64_t ldb, const double *__restrict__ contrib)
+__global__ __launch_bounds__(256) void k_sn_fwd_diag(Meta M, const int32_t *__restrict__ lev_sn, int m, double *__restrict__ B, int64_t ldb)
 {
   extern __shared__ __attribute__((aligned(16))) double bs[]; // nc x mpad
   const int32_t s = lev_sn[blockIdx.x];
@@ -683,20 +685,7 @@ __global__ __launch_bounds__(256) void k_sn_fwd_diag(Meta M, const int32_t *__re
   for (int idx = tid; idx < nc * mpad; idx += 256) {
     const int k = idx / mpad, c = idx - k * mpad;
     const int ksrc = LU ? M.piv[f + k] : k; // the row exchanges of the diagonal block, applied to the right-hand side here
-    double v = 0.0;
-    if (c < m) {
-      v = B[(int64_t)(f + ksrc) * ldb + c];
-      // what the supernodes below subtract from this row: their slots, in list order (four loads in flight)
-      const int64_t q0 = M.tptr[f + ksrc], q1 = M.tptr[f + ksrc + 1];
-      int64_t q = q0;
-      for (; q + 4 <= q1; q += 4) {
-        const double c0 = contrib[(int64_t)M.tidx[q] * m + c], c1 = contrib[(int64_t)M.tidx[q + 1] * m + c], c2 = contrib[(int64_t)M.tidx[q + 2] * m + c],
-                     c3 = contrib[(int64_t)M.tidx[q + 3] * m + c];
-        v = (((v - c0) - c1) - c2) - c3;
-      }
-      for (; q < q1; ++q) v -= contrib[(int64_t)M.tidx[q] * m + c];
-    }
-    bs[idx] = v;
+    bs[idx] = c < m ? B[(int64_t)(f + ksrc) * ldb + c] : 0.0;
   }
   __syncthreads();
   const int ns = (nc + 15) >> 4;
@@ -733,14 +722,17 @@ __global__ __launch_bounds__(256) void k_sn_fwd_diag(Meta M, const int32_t *__re
     }
   }
 }
-// slots of the rows of s <- R_s Y_s (subtracted by the rows' owners: k_sn_fwd_diag), one workgroup per 64 rows of R_s
+// B[rows] -= R_s Y_s, one workgroup per 64 rows of R_s; launched colour by colour (Factor::lev_phase_ptr): no other workgroup of a
+// launch touches the same rows, so the subtraction is a plain read-modify-write and every row receives its updates in one order
 __global__ __launch_bounds__(256) void k_sn_fwd_update(Meta M, const int32_t *__restrict__ lev_sn, const int32_t *__restrict__ pre, int cnt, int m,
-                                                      const double *__restrict__ B, int64_t ldb, double *__restrict__ contrib)
+                                                      double *__restrict__ B, int64_t ldb, int base)
 {
   extern __shared__ __attribute__((aligned(16))) double ys[]; // nc x mpad
-  const int it = find_item(pre, cnt, (int32_t)blockIdx.x);
+  const int item = (int)blockIdx.x + base; // (base: first row tile of this launch = of the colour)
+  const int it = find_item(pre, cnt, (int32_t)item);
   const int32_t s = lev_sn[it];
-  const int tile = (int)blockIdx.x - pre[it];
+  const int tile = item - pre[it];
+  const int32_t *R = M.rows + M.rptr[s];
   const int32_t f = M.first[s], nc = M.first[s + 1] - f, nr = M.nrow[s];
   const int64_t ld = nc + nr;
   const double *P = M.panels + M.pptr[s];
@@ -776,7 +768,7 @@ __global__ __launch_bounds__(256) void k_sn_fwd_update(Meta M, const int32_t *__
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int r = tile * TILE + (wave << 4) + lr + 4 * q, c = (t << 4) + lc;
-      if (r < nr && c < m) contrib[(M.rptr[s] + r) * m + c] = acc[t][q];
+      if (r < nr && c < m) B[(int64_t)R[r] * ldb + c] -= acc[t][q];
     }
   }
 }
@@ -966,7 +958,8 @@ struct Factor {
   // panel entry receives its contributions in ONE order (level, colour) whatever the hardware does -- no atomics.
   std::vector<int32_t> lev_phase_ptr;    // [nlev + 1] into phase_k
   std::vector<int32_t> phase_k;          // first position (relative to lev_ptr[l]) of every colour of every level, plus the level's end
-  std::vector<int32_t> h_preU, h_preUF;  // host copies of the update tile prefixes (launch bounds of a colour)
+  std::vector<int32_t> h_preU, h_preUF, h_preT; // host copies of the tile prefixes (launch bounds of a colour)
+  std::vector<int32_t> h_colour;         // colour of every supernode
   // device
   int32_t *d_first = nullptr, *d_nrow = nullptr, *d_rows = nullptr, *d_sn_of_col = nullptr, *d_iperm = nullptr, *d_perm = nullptr;
   int64_t *d_rptr = nullptr, *d_pptr = nullptr;
@@ -994,8 +987,8 @@ struct Factor {
   double *d_top_partial = nullptr;
   TopSync *d_top_sync = nullptr;
   unsigned long long *d_top_flags = nullptr;
-  int top_grid = 0;
-  int64_t *d_tptr = nullptr;  // transposed row lists (Meta::tptr / tidx)
+  int top_grid = 0, top_spread = 0;
+  int64_t *d_tptr = nullptr, *d_tmid = nullptr;  // transposed row lists (Meta::tptr / tmid / tidx)
   int32_t *d_tidx = nullptr;
   double *d_contrib = nullptr; // slots of the forward sweep: one per entry of `rows` and right-hand side
   int64_t contrib_cap = 0, nrows_total = 0;
@@ -1004,12 +997,12 @@ struct Factor {
   {
     for (void *p : {(void *)d_first, (void *)d_nrow, (void *)d_rows, (void *)d_sn_of_col, (void *)d_iperm, (void *)d_perm, (void *)d_rptr, (void *)d_pptr, (void *)d_panels,
                     (void *)d_lev_sn, (void *)d_preT, (void *)d_preU, (void *)d_big_sn, (void *)d_big_index, (void *)d_preB, (void *)d_err, (void *)d_partial,
-                    (void *)d_upanels, (void *)d_uptr, (void *)d_piv, (void *)d_preUF, (void *)d_tptr, (void *)d_tidx, (void *)d_contrib, (void *)d_top_ints, (void *)d_top_partial, (void *)d_top_sync, (void *)d_top_flags})
+                    (void *)d_upanels, (void *)d_uptr, (void *)d_piv, (void *)d_preUF, (void *)d_tptr, (void *)d_tmid, (void *)d_tidx, (void *)d_contrib, (void *)d_top_ints, (void *)d_top_partial, (void *)d_top_sync, (void *)d_top_flags})
       if (p) (void)hipFree(p);
     d_first = d_nrow = d_rows = d_sn_of_col = d_iperm = d_perm = d_lev_sn = d_preT = d_preU = d_big_sn = d_big_index = d_preB = nullptr;
     d_rptr = d_pptr = nullptr;
     d_panels = d_partial = d_upanels = d_contrib = nullptr;
-    d_tptr = nullptr;
+    d_tptr = d_tmid = nullptr;
     d_tidx = nullptr;
     d_top_ints = nullptr;
     d_top_partial = nullptr;
@@ -1031,10 +1024,10 @@ static inline bool up(const std::vector<T> &h, T **d)
   return h.empty() || hipMemcpy(*d, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice) == hipSuccess;
 }
 
-// Plan of the persistent single-vector kernel (sn_solve1.hpp): the top levels are those from the first level on which every later
-// level has at most TOP_MAX_PER_LEVEL supernodes (the separator chains: one supernode per block and level); fewer than four such
-// levels are not worth a launch of their own.  DDM_SN_TOP_MAX overrides the bound (0: level kernels only).
-static inline bool build_top_plan(Factor &F, int nblocks, const std::vector<int32_t> &lev_sn, const std::vector<int32_t> &nrow)
+// Top levels of the single-vector solve (sn_solve1.hpp): those from the first level on which every later level has at most
+// `top_max` supernodes (the separator chains: one supernode per block and level); fewer than four such levels are not worth a launch
+// of their own.  DDM_SN_TOP_MAX overrides the bound (0: level kernels only).  Needs lev_ptr; sets ltop / ntop.
+static inline void decide_top_levels(Factor &F)
 {
   int top_max = 32;
   if (const char *e = std::getenv("DDM_SN_TOP_MAX")) top_max = std::atoi(e);
@@ -1042,63 +1035,96 @@ static inline bool build_top_plan(Factor &F, int nblocks, const std::vector<int3
   while (ltop > 0 && F.lev_ptr[(size_t)ltop] - F.lev_ptr[(size_t)ltop - 1] <= top_max) --ltop;
   F.ltop = F.nlev;
   F.ntop = 0;
-  if (F.nlev - ltop < 4) return true;
-  const int32_t ntop = F.nlev - ltop;
-  std::vector<int32_t> a_ptr((size_t)8 * ntop + 1, 0), f_ptr((size_t)8 * ntop + 1, 0), p_ptr((size_t)8 * ntop + 1, 0), a_sn, f_items, p_items, p_first((size_t)F.nsn, 0);
-  for (int c = 0; c < 8; ++c)
+  if (F.nlev - ltop < 4) return;
+  int dev = 0, ncu = 0, per_cu = 0;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) return; // (no device: host-only use)
+  const void *fn = F.lu ? (const void *)k_sn_top1<true> : (const void *)k_sn_top1<false>;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, TOP_THREADS, 0) != hipSuccess || per_cu < 1) return;
+  F.top_grid = std::min(per_cu, 2) * (ncu / 8 * 8); // co-resident: at most two workgroups of 512 threads per CU
+  if (F.top_grid < 8 || F.top_grid > TOP_MAX_WG) return;
+  F.ltop = ltop;
+  F.ntop = F.nlev - ltop;
+}
+// Plan of the persistent kernel: per class (block % 8) the top supernodes by level, their forward tiles by (level, colour), their
+// backward chunks by level, and the 16-column pieces of all their columns for the gather of the bottom levels' slots.
+static inline bool build_top_plan(Factor &F, const std::vector<int32_t> &lev_sn, const std::vector<int32_t> &nrow, const std::vector<int32_t> &first)
+{
+  if (F.ntop == 0) return true;
+  const int32_t ntop = F.ntop, ltop = F.ltop;
+  // colours per top level (global over the classes: the barrier count of a level must not depend on the class)
+  std::vector<int32_t> fph((size_t)ntop + 1, 0);
+  for (int32_t j = 0; j < ntop; ++j) {
+    int nc = 1;
+    for (int32_t k = F.lev_ptr[(size_t)(ltop + j)]; k < F.lev_ptr[(size_t)(ltop + j) + 1]; ++k) nc = std::max(nc, F.h_colour[(size_t)lev_sn[(size_t)k]] + 1);
+    fph[(size_t)j + 1] = fph[(size_t)j] + nc;
+  }
+  const int32_t nph = fph[(size_t)ntop];
+  std::vector<int32_t> a_ptr((size_t)8 * ntop + 1, 0), f_ptr((size_t)8 * nph + 1, 0), p_ptr((size_t)8 * ntop + 1, 0), g_ptr(9, 0), a_sn, f_items, p_items, g_items,
+      p_first((size_t)F.nsn, 0);
+  for (int c = 0; c < 8; ++c) {
     for (int32_t j = 0; j < ntop; ++j) {
       const int32_t l = ltop + j;
       for (int32_t k = F.lev_ptr[(size_t)l]; k < F.lev_ptr[(size_t)l + 1]; ++k) {
         const int32_t s = lev_sn[(size_t)k];
         if (F.sn_block[(size_t)s] % 8 != c) continue;
         a_sn.push_back(s);
-        const int32_t nr = nrow[(size_t)s];
-        for (int32_t t = 0; t < (nr + TILE - 1) / TILE; ++t) {
-          f_items.push_back(s);
-          f_items.push_back(t);
-        }
+        const int32_t nr = nrow[(size_t)s], ncs = first[(size_t)s + 1] - first[(size_t)s];
         p_first[(size_t)s] = (int32_t)(p_items.size() / 2);
         for (int32_t q = 0; q < (nr + S1_CHUNK_ROWS - 1) / S1_CHUNK_ROWS; ++q) {
           p_items.push_back(s);
           p_items.push_back(q);
         }
+        for (int32_t q = 0; q < (ncs + 15) / 16; ++q) {
+          g_items.push_back(s);
+          g_items.push_back(q);
+        }
       }
-      const size_t seg = (size_t)c * ntop + j;
-      a_ptr[seg + 1] = (int32_t)a_sn.size();
-      f_ptr[seg + 1] = (int32_t)(f_items.size() / 2);
-      p_ptr[seg + 1] = (int32_t)(p_items.size() / 2);
+      a_ptr[(size_t)c * ntop + j + 1] = (int32_t)a_sn.size();
+      p_ptr[(size_t)c * ntop + j + 1] = (int32_t)(p_items.size() / 2);
+      for (int32_t col = 0; col < fph[(size_t)j + 1] - fph[(size_t)j]; ++col) { // forward tiles, colour by colour
+        for (int32_t k = F.lev_ptr[(size_t)l]; k < F.lev_ptr[(size_t)l + 1]; ++k) {
+          const int32_t s = lev_sn[(size_t)k];
+          if (F.sn_block[(size_t)s] % 8 != c || F.h_colour[(size_t)s] != col) continue;
+          for (int32_t t = 0; t < (nrow[(size_t)s] + TILE - 1) / TILE; ++t) {
+            f_items.push_back(s);
+            f_items.push_back(t);
+          }
+        }
+        f_ptr[(size_t)c * nph + fph[(size_t)j] + col + 1] = (int32_t)(f_items.size() / 2);
+      }
     }
+    g_ptr[(size_t)c + 1] = (int32_t)(g_items.size() / 2);
+  }
   std::vector<int32_t> all;
   auto put = [&](const std::vector<int32_t> &v) {
     const size_t o = all.size();
     all.insert(all.end(), v.begin(), v.end());
     return o;
   };
-  const size_t o_ap = put(a_ptr), o_as = put(a_sn), o_fp = put(f_ptr), o_fi = put(f_items), o_pp = put(p_ptr), o_pi = put(p_items), o_pf = put(p_first);
+  const size_t o_ap = put(a_ptr), o_as = put(a_sn), o_fh = put(fph), o_fp = put(f_ptr), o_fi = put(f_items), o_pp = put(p_ptr), o_pi = put(p_items), o_pf = put(p_first),
+               o_gp = put(g_ptr), o_gi = put(g_items);
   if (!up(all, &F.d_top_ints)) return false;
   if (hipMalloc((void **)&F.d_top_partial, sizeof(double) * std::max<size_t>(p_items.size() / 2, 1) * SN_MAX_COLS) != hipSuccess) return false;
   if (hipMalloc((void **)&F.d_top_sync, sizeof(TopSync)) != hipSuccess || hipMemset(F.d_top_sync, 0, sizeof(TopSync)) != hipSuccess) return false;
   const size_t fbytes = sizeof(unsigned long long) * 9 * TOP_MAX_WG * TOP_FLAG_STRIDE;
   if (hipMalloc((void **)&F.d_top_flags, fbytes) != hipSuccess || hipMemset(F.d_top_flags, 0, fbytes) != hipSuccess) return false;
   F.top.ntop = ntop;
+  F.top.nph = nph;
   F.top.a_ptr = F.d_top_ints + o_ap;
   F.top.a_sn = F.d_top_ints + o_as;
+  F.top.fph = F.d_top_ints + o_fh;
   F.top.f_ptr = F.d_top_ints + o_fp;
   F.top.f_items = F.d_top_ints + o_fi;
   F.top.p_ptr = F.d_top_ints + o_pp;
   F.top.p_items = F.d_top_ints + o_pi;
   F.top.p_first = F.d_top_ints + o_pf;
-  // co-resident grid: two workgroups of 512 threads per CU
-  int dev = 0, ncu = 0, per_cu = 0;
-  (void)hipGetDevice(&dev);
-  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) return true; // (no device: host-only use)
-  const void *fn = F.lu ? (const void *)k_sn_top1<true> : (const void *)k_sn_top1<false>;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, TOP_THREADS, 0) != hipSuccess || per_cu < 1) return true;
-  F.top_grid = std::min(per_cu, 2) * (ncu / 8 * 8);
-  if (F.top_grid < 8 || F.top_grid > TOP_MAX_WG) return true;
-  F.ltop = ltop;
-  F.ntop = ntop;
-  (void)nblocks;
+  F.top.g_ptr = F.d_top_ints + o_gp;
+  F.top.g_items = F.d_top_ints + o_gi;
+  // one block over all XCDs (write-through hand-overs, one barrier group) only when a block is too large for the bandwidth of one
+  // XCD; otherwise block b lives on XCD b % 8 also when fewer than 8 blocks leave XCDs idle
+  F.top_spread = (F.nblocks < 8 && (double)F.entries * 8.0 / std::max(1, F.nblocks) > 256e6) ? 1 : 0;
+  if (const char *e = std::getenv("DDM_SN_TOP_SPREAD")) F.top_spread = std::atoi(e) != 0;
   return true;
 }
 
@@ -1187,6 +1213,7 @@ static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *b
       (void)ncol;
     }
     F.lev_phase_ptr[(size_t)nlev] = (int32_t)F.phase_k.size();
+    F.h_colour = colour;
   }
   std::vector<int32_t> preT((size_t)F.nsn + nlev), preU((size_t)F.nsn + nlev), preUF((size_t)F.nsn + nlev), big_sn, big_index((size_t)F.nsn, -1), preB;
   std::vector<int64_t> uptr(1, 0);
@@ -1234,17 +1261,30 @@ static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *b
   }
   F.h_preU = preU;
   F.h_preUF = preUF;
-  // transposed row lists (counting sort of the entries of `rows` by value: ascending position = ascending source supernode)
+  F.h_preT = preT;
+  // transposed row lists (counting sort of the entries of `rows` by value; per column first the entries of bottom-level supernodes,
+  // then those of top-level ones, each part in ascending position = ascending source supernode)
   if (rows.size() >= (size_t)0x7fffffff) return false;
   F.nrows_total = (int64_t)rows.size();
+  decide_top_levels(F);
   {
-    std::vector<int64_t> tptr((size_t)n + 1, 0);
-    for (int32_t r : rows) tptr[(size_t)r + 1]++;
+    std::vector<int64_t> tptr((size_t)n + 1, 0), tmid((size_t)n, 0);
+    for (int32_t s = 0; s < F.nsn; ++s)
+      for (int64_t q = rptr[(size_t)s]; q < rptr[(size_t)s + 1]; ++q) {
+        tptr[(size_t)rows[(size_t)q] + 1]++;
+        if (level[(size_t)s] < F.ltop) tmid[(size_t)rows[(size_t)q]]++;
+      }
     for (int64_t c = 0; c < n; ++c) tptr[(size_t)c + 1] += tptr[(size_t)c];
+    for (int64_t c = 0; c < n; ++c) tmid[(size_t)c] += tptr[(size_t)c];
     std::vector<int32_t> tidx(rows.size());
-    std::vector<int64_t> fill(tptr.begin(), tptr.end() - 1);
-    for (size_t q = 0; q < rows.size(); ++q) tidx[(size_t)fill[(size_t)rows[q]]++] = (int32_t)q;
-    if (!up(tptr, &F.d_tptr) || !up(tidx, &F.d_tidx)) return false;
+    std::vector<int64_t> fill_lo(tptr.begin(), tptr.end() - 1), fill_hi(tmid);
+    for (int32_t s = 0; s < F.nsn; ++s)
+      for (int64_t q = rptr[(size_t)s]; q < rptr[(size_t)s + 1]; ++q) {
+        const int32_t r = rows[(size_t)q];
+        if (level[(size_t)s] < F.ltop) tidx[(size_t)fill_lo[(size_t)r]++] = (int32_t)q;
+        else tidx[(size_t)fill_hi[(size_t)r]++] = (int32_t)q;
+      }
+    if (!up(tptr, &F.d_tptr) || !up(tmid, &F.d_tmid) || !up(tidx, &F.d_tidx)) return false;
   }
   bool ok = up(first, &F.d_first) && up(nrow, &F.d_nrow) && up(rows, &F.d_rows) && up(sn_of_col, &F.d_sn_of_col) && up(iperm, &F.d_iperm) && up(F.h_perm, &F.d_perm) &&
             up(rptr, &F.d_rptr) && up(pptr, &F.d_pptr) && up(lev_sn, &F.d_lev_sn) && up(preT, &F.d_preT) && up(preU, &F.d_preU) && up(big_sn, &F.d_big_sn) &&
@@ -1257,7 +1297,7 @@ static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *b
     if (hipMalloc((void **)&F.d_upanels, sizeof(double) * (size_t)std::max<int64_t>(F.uentries, 1)) != hipSuccess) return false;
     if (hipMalloc((void **)&F.d_piv, sizeof(int32_t) * (size_t)std::max<int64_t>(n, 1)) != hipSuccess) return false;
   }
-  if (!build_top_plan(F, (int)nblocks, lev_sn, nrow)) return false;
+  if (!build_top_plan(F, lev_sn, nrow, first)) return false;
   F.M.nsn = F.nsn;
   F.M.first = F.d_first;
   F.M.nrow = F.d_nrow;
@@ -1266,6 +1306,7 @@ static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *b
   F.M.pptr = F.d_pptr;
   F.M.sn_of_col = F.d_sn_of_col;
   F.M.tptr = F.d_tptr;
+  F.M.tmid = F.d_tmid;
   F.M.tidx = F.d_tidx;
   F.M.panels = F.d_panels;
   F.M.upanels = F.d_upanels;
@@ -1332,7 +1373,7 @@ static inline hipError_t factorize(Factor &F, hipStream_t st, const int64_t *d_r
 // scratch of the backward sweep for m right-hand sides (call OUTSIDE a stream capture)
 static inline bool reserve(Factor &F, int m)
 {
-  const int64_t cneed = F.nrows_total * (int64_t)m; // slots of the forward sweep
+  const int64_t cneed = F.nrows_total; // slots of the single-vector forward sweep (the block solves push coloured updates)
   if (cneed > F.contrib_cap) {
     if (F.d_contrib) (void)hipFree(F.d_contrib);
     F.d_contrib = nullptr;
@@ -1365,7 +1406,7 @@ static inline void solve_t(const Factor &F, hipStream_t st, int m, double *B, in
     }
     if (F.ntop > 0) {
       hipLaunchKernelGGL(k_sn_top_prologue, dim3(1), dim3(64), 0, st, F.d_top_sync);
-      hipLaunchKernelGGL(k_sn_top1<LU>, dim3((unsigned)F.top_grid), dim3(TOP_THREADS), 0, st, F.M, F.top, F.nblocks, F.nblocks < 8 ? 1 : 0, B, Yvec, F.d_contrib, F.d_top_partial,
+      hipLaunchKernelGGL(k_sn_top1<LU>, dim3((unsigned)F.top_grid), dim3(TOP_THREADS), 0, st, F.M, F.top, F.nblocks, F.top_spread, B, Yvec, F.d_contrib, F.d_top_partial,
                          F.d_top_sync, F.d_top_flags, err ? err : F.d_err + 1);
     }
     for (int32_t l = lbot - 1; l >= 0; --l) {
@@ -1396,10 +1437,12 @@ static inline void solve_t(const Factor &F, hipStream_t st, int m, double *B, in
     if (cnt == 0) continue;
     const int32_t *lsn = F.d_lev_sn + F.lev_ptr[(size_t)l];
     const size_t lds = (size_t)F.lev_maxnc[(size_t)l] * mpad * 8;
-    hipLaunchKernelGGL(k_sn_fwd_diag<LU>, dim3((unsigned)cnt), dim3(256), lds, st, F.M, lsn, m, B, ldb, (const double *)F.d_contrib);
-    if (F.h_tilesT[(size_t)l] > 0)
-      hipLaunchKernelGGL(k_sn_fwd_update, dim3((unsigned)F.h_tilesT[(size_t)l]), dim3(256), lds, st, F.M, lsn, (const int32_t *)(F.d_preT + F.lev_ptr[(size_t)l] + l), cnt, m,
-                         (const double *)B, ldb, F.d_contrib);
+    hipLaunchKernelGGL(k_sn_fwd_diag<LU>, dim3((unsigned)cnt), dim3(256), lds, st, F.M, lsn, m, B, ldb);
+    for (int32_t ph = F.lev_phase_ptr[(size_t)l]; ph + 1 < F.lev_phase_ptr[(size_t)l + 1]; ++ph) { // colour by colour
+      const int32_t b0 = F.h_preT[(size_t)(F.lev_ptr[(size_t)l] + l + F.phase_k[(size_t)ph])], b1 = F.h_preT[(size_t)(F.lev_ptr[(size_t)l] + l + F.phase_k[(size_t)ph + 1])];
+      if (b1 > b0)
+        hipLaunchKernelGGL(k_sn_fwd_update, dim3((unsigned)(b1 - b0)), dim3(256), lds, st, F.M, lsn, (const int32_t *)(F.d_preT + F.lev_ptr[(size_t)l] + l), cnt, m, B, ldb, (int)b0);
+    }
   }
   for (int32_t l = F.nlev - 1; l >= 0; --l) {
     const int32_t cnt = F.lev_ptr[(size_t)l + 1] - F.lev_ptr[(size_t)l];

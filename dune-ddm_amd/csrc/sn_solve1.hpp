@@ -12,8 +12,11 @@
 //     another workgroup's result is an sc1 load, the levels are separated by an all-to-all flag barrier among the XCD's workgroups
 //     (plain flag stores, sc1 polls: ~1 us instead of ~15 us per launch).  With fewer than 8 subdomains all workgroups form one
 //     group and the hand-overs are write-through (sc1 stores).
-// Determinism: the forward sweep writes what supernode s subtracts from its row rows[q] into slot q of a scratch array; the owner
-// of the row subtracts its slots in list order (Meta::tptr / tidx).  No atomics: the same bits every run.
+// Determinism, no atomics anywhere: a supernode of the BOTTOM levels writes what it subtracts from its row rows[q] into slot q of a
+// scratch array, and the owner of the row subtracts its slots in list order (Meta::tptr / tmid / tidx) -- bottom-level owners in
+// k_sn_fwd1 (short lists), top-level owners in ONE parallel gather phase at the start of the persistent kernel.  A supernode of the
+// TOP levels subtracts in place, colour by colour (supernodes of one level whose row lists intersect have different colours,
+// Factor::h_colour): every entry receives its updates in one order.  The same bits every run.
 #pragma once
 
 namespace sn {
@@ -89,9 +92,10 @@ __device__ __forceinline__ void s1_lower_product(const Meta &M, int32_t s, const
   if (tid < nc) ys[tid] = (LU ? bs[tid] : 0.0) + ((part[tid] + part[NCMAX + tid]) + (part[2 * NCMAX + tid] + part[3 * NCMAX + tid]));
   __syncthreads();
 }
-// slots of the rows [64 tile, 64 tile + 64) of s <- R_s ys.  Ends with a barrier (part may be reused).
-template <int NCMAX>
-__device__ __forceinline__ void s1_forward_tile(const Meta &M, int32_t s, int tile, const double *ys, double *part, double *__restrict__ contrib, bool wt)
+// the rows [64 tile, 64 tile + 64) of s: IN_PLACE = false: their slots <- R_s ys (bottom levels); IN_PLACE = true: dst[row] -= R_s ys
+// (top levels: dst = the work vector, read past the L1; no other workgroup of the phase touches these rows).  Ends with a barrier.
+template <int NCMAX, bool IN_PLACE>
+__device__ __forceinline__ void s1_forward_tile(const Meta &M, int32_t s, int tile, const double *ys, double *part, double *__restrict__ dst, bool wt)
 {
   const int32_t nc = M.first[s + 1] - M.first[s], nr = M.nrow[s];
   const int64_t ld = nc + nr;
@@ -112,7 +116,12 @@ __device__ __forceinline__ void s1_forward_tile(const Meta &M, int32_t s, int ti
     double sum = 0.0;
 #pragma unroll
     for (int q = 0; q < NCMAX / 16; ++q) sum += part[q * TILE + tid];
-    s1_st(contrib + M.rptr[s] + r0 + tid, sum, wt);
+    if (IN_PLACE) {
+      double *p = dst + (M.rows + M.rptr[s])[r0 + tid];
+      s1_st(p, s1_ld<true>(p) - sum, wt);
+    } else {
+      dst[M.rptr[s] + r0 + tid] = sum;
+    }
   }
   __syncthreads();
 }
@@ -196,7 +205,7 @@ __global__ __launch_bounds__(4 * NCMAX) void k_sn_fwd1(Meta M, const int32_t *__
     if ((int)threadIdx.x < nc) Y[f + threadIdx.x] = ys[threadIdx.x];
     return;
   }
-  s1_forward_tile<NCMAX>(M, s, item - 1, ys, part, contrib, false);
+  s1_forward_tile<NCMAX, false>(M, s, item - 1, ys, part, contrib, false);
 }
 template <bool LU, int NCMAX>
 __global__ __launch_bounds__(4 * NCMAX) void k_sn_bwd1_partial(Meta M, const int32_t *__restrict__ big_sn, const int32_t *__restrict__ pre, int cnt, const double *__restrict__ X,
@@ -235,15 +244,16 @@ __global__ __launch_bounds__(4 * NCMAX) void k_sn_bwd1_diag(Meta M, const int32_
 }
 
 // ---- the persistent kernel for the top of the tree --------------------------------------------------------------------------------
-// Plan (host: build_top_plan): top levels j = 0 .. ntop - 1 (tree level ltop + j), supernodes split by class = block % 8;
-// segment (c, j) -> index c * ntop + j.  a_*: the supernodes; f_*: (supernode, row tile) items of the forward sweep; p_*: (supernode,
-// row chunk) items of the backward sweep; item i of p_* writes partial[i * SN_MAX_COLS ..); p_first[s] = first item of s.
+// Plan (host: build_top_plan): top levels j = 0 .. ntop - 1 (tree level ltop + j), supernodes split by class = block % 8.
+// Item i of p_* writes partial[i * SN_MAX_COLS ..); p_first[s] = first item of s.
 struct TopPlan {
-  int32_t ntop = 0;
-  const int32_t *a_ptr = nullptr, *a_sn = nullptr;
-  const int32_t *f_ptr = nullptr, *f_items = nullptr; // pairs
-  const int32_t *p_ptr = nullptr, *p_items = nullptr; // pairs
+  int32_t ntop = 0, nph = 0;                          // top levels; forward phases = sum over the levels of their colours
+  const int32_t *a_ptr = nullptr, *a_sn = nullptr;    // [8 ntop + 1]: supernodes of (class, level)
+  const int32_t *fph = nullptr;                       // [ntop + 1]: first forward phase of a level
+  const int32_t *f_ptr = nullptr, *f_items = nullptr; // [8 nph + 1]: (supernode, row tile) pairs of (class, phase)
+  const int32_t *p_ptr = nullptr, *p_items = nullptr; // [8 ntop + 1]: (supernode, row chunk) pairs of (class, level)
   const int32_t *p_first = nullptr;                   // [nsn]
+  const int32_t *g_ptr = nullptr, *g_items = nullptr; // [8 + 1]: (supernode, 16-column piece) pairs of a class: the gather phase
 };
 struct TopSync { // device words of one factor (zero-initialised; the epoch separates launches)
   unsigned tickets[8];
@@ -338,34 +348,54 @@ __global__ __launch_bounds__(TOP_THREADS) void k_sn_top1(Meta M, TopPlan P, int 
     if (sh_fail) failed = true;
   };
   const int ntop = P.ntop;
+  // ---- gather: every column of the top supernodes collects the slots the bottom levels left for it (16 columns per item, 32 lanes
+  // per column strided over the list, partial sums folded in a fixed order) ----
+  for (int c = c_begin; c < c_end; ++c)
+    for (int i = P.g_ptr[c] + (int)rank; i < P.g_ptr[c + 1]; i += (int)W) {
+      const int32_t s = P.g_items[2 * i], piece = P.g_items[2 * i + 1];
+      const int32_t f = M.first[s], nc = M.first[s + 1] - f;
+      const int k = 16 * piece + (tid >> 5), l32 = tid & 31;
+      double acc = 0.0;
+      if (k < nc) {
+        const int64_t q1 = M.tmid[f + k];
+        for (int64_t q = M.tptr[f + k] + l32; q < q1; q += 32) acc += contrib[M.tidx[q]]; // (slots of earlier launches: plain loads)
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+      if (k < nc && l32 == 0) s1_st(B + f + k, B[f + k] - acc, wt);
+    }
+  group_barrier();
   // ---- forward, bottom-up ----
   for (int j = 0; j < ntop && !failed; ++j) {
     for (int c = c_begin; c < c_end; ++c) {
       const int seg = c * ntop + j;
       for (int i = P.a_ptr[seg] + (int)rank; i < P.a_ptr[seg + 1]; i += (int)W) {
         const int32_t s = P.a_sn[i];
-        s1_gather<LU, NCMAX, true>(M, s, B, contrib, bs, part);
-        s1_lower_product<LU, NCMAX>(M, s, bs, ys, part);
         const int32_t f = M.first[s], nc = M.first[s + 1] - f;
+        if (tid < nc) bs[tid] = s1_ld<true>(B + f + (LU ? M.piv[f + tid] : tid));
+        __syncthreads();
+        s1_lower_product<LU, NCMAX>(M, s, bs, ys, part);
         if (tid < nc) s1_st(Y + f + tid, ys[tid], wt);
         __syncthreads();
       }
     }
     group_barrier();
     if (failed) break;
-    bool any = false;
-    for (int c = c_begin; c < c_end; ++c) {
-      const int seg = c * ntop + j;
-      any = any || P.f_ptr[seg + 1] > P.f_ptr[seg];
-      for (int i = P.f_ptr[seg] + (int)rank; i < P.f_ptr[seg + 1]; i += (int)W) {
-        const int32_t s = P.f_items[2 * i], tile = P.f_items[2 * i + 1];
-        const int32_t f = M.first[s], nc = M.first[s + 1] - f;
-        if (tid < nc) ys[tid] = s1_ld<true>(Y + f + tid);
-        __syncthreads();
-        s1_forward_tile<NCMAX>(M, s, tile, ys, part, contrib, wt);
+    for (int ph = P.fph[j]; ph < P.fph[j + 1] && !failed; ++ph) { // colour by colour: in-place subtraction without conflicts
+      bool any = false;
+      for (int c = c_begin; c < c_end; ++c) {
+        const int seg = c * P.nph + ph;
+        any = any || P.f_ptr[seg + 1] > P.f_ptr[seg];
+        for (int i = P.f_ptr[seg] + (int)rank; i < P.f_ptr[seg + 1]; i += (int)W) {
+          const int32_t s = P.f_items[2 * i], tile = P.f_items[2 * i + 1];
+          const int32_t f = M.first[s], nc = M.first[s + 1] - f;
+          if (tid < nc) ys[tid] = s1_ld<true>(Y + f + tid);
+          __syncthreads();
+          s1_forward_tile<NCMAX, true>(M, s, tile, ys, part, B, wt);
+        }
       }
+      if (any) group_barrier(); // (uniform over the group: the plan is the same for all its workgroups)
     }
-    if (any) group_barrier(); // (uniform over the group: the plan is the same for all its workgroups)
   }
   // ---- backward, top-down ----
   for (int j = ntop - 1; j >= 0 && !failed; --j) {

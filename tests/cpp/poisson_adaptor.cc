@@ -8,6 +8,7 @@
 //                                    Dune::getHipSolver (whole CG on the device: one upload, one download), subdomain solver
 //                                    ilu0 resp. cholmod; also exercises the Dune::InverseOperator plugin HipSubdomainSolver
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -25,6 +26,7 @@
 #include <dune/ddm/hip/schwarz.hh>
 #include <dune/ddm/hip/coarse_spaces.hh>
 #include <dune/ddm/hip/solvers.hh>
+#include <dune/ddm/hip/rccl_exchange.hh>
 
 template <class T>
 static std::vector<T> slurp(const std::string& f)
@@ -46,6 +48,11 @@ int main(int argc, char** argv)
   using Mat = Dune::BCRSMatrix<Dune::FieldMatrix<double, 1, 1>>;
   using Comm = Dune::OwnerOverlapCopyCommunication<std::size_t, int>;
   try {
+    if (std::getenv("DDM_TEST_RCCL")) {   // the in-library RCCL exchange installed the way a DUNE program would (size-1 communicator, self test)
+      auto ctx = ddm_hip::install_rccl_exchange(ddm_hip::make_rccl_id(), 0, 1, 0, /*self_test=*/true);
+      std::printf("rccl_exchange installed rank %d of %d\n", ctx->rank, ctx->nranks);
+      try { ddm_hip::install_rccl_exchange(ddm_hip::RcclId(), 2, 1); } catch (Dune::InvalidStateException&) { std::printf("rccl_bad_rank_caught\n"); }
+    }
     auto rp64 = slurp<int64_t>(dir + "/rowptr.bin");
     auto ci32 = slurp<int32_t>(dir + "/col.bin");
     auto va = slurp<double>(dir + "/val.bin");

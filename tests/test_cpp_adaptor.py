@@ -97,6 +97,16 @@ def test_adaptor_factory_style_device_solver(ddm, tmp_path, mode):
     assert np.abs(x - xo[0]).max() <= 1e-8 * np.abs(xo[0]).max()
     res = float([ln for ln in p.stdout.splitlines() if ln.startswith("plugin")][0].split()[2])
     assert res < 1e-10 and "errors_caught 2" in p.stdout
+    if mode == "device":
+        # the same run with the in-library RCCL exchange installed from C++ (dune/ddm/hip/rccl_exchange.hh: id, ncclCommInitRank on a
+        # size-1 communicator, reductions routed through ncclAllReduce -- the self-test mode): same iteration count, same bits
+        x0 = x.copy()
+        q = subprocess.run([exe, str(tmp_path), mode], capture_output=True, text=True, timeout=300, env=dict(os.environ, DDM_TEST_RCCL="1"))
+        assert q.returncode == 0, q.stdout[-2000:] + q.stderr[-2000:]
+        assert "rccl_exchange installed rank 0 of 1" in q.stdout and "rccl_bad_rank_caught" in q.stdout
+        line2 = [ln for ln in q.stdout.splitlines() if ln.startswith("device_solve")][0].split()
+        assert line2[2] == line[2] and line2[4] == "1"
+        assert np.array_equal(np.fromfile(tmp_path / "x_device.bin", dtype=np.float64), x0)
 
 
 @pytest.mark.gpu

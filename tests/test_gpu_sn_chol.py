@@ -88,7 +88,7 @@ def test_device_cholesky_matches_superlu(ddm, torch_cuda, device_engine, shape, 
     assert F2.status() == 0
     assert torch.equal(x3, x) and torch.equal(X2, X)
     steps, om = F.refinement()
-    assert steps <= 1 and om[steps] < 1e-13, (steps, om)      # SPD: the probe is at rounding level at once (or after one step)
+    assert steps <= 1 and om[steps] < 1e-12, (steps, om)      # SPD: the probe is at rounding level at once (or after one step)
     ctx.close()
 
 
@@ -296,10 +296,11 @@ def test_device_lu_matches_superlu(ddm, torch_cuda, device_engine, case):
     Xh = X.cpu().numpy()
     omega = np.linalg.norm(M @ Xh - B) / (anorm * np.linalg.norm(Xh) + np.linalg.norm(B))
     print(f"[sn lu {case}] residual {res:.2e} (SuperLU {res_ref:.2e}); refinement steps {steps}, probe backward errors {om[:steps + 1]}, block backward error {omega:.2e}")
+    # (om = max(normwise backward error, 1e-2 x componentwise backward error) of the probe right-hand side)
     assert om[steps] <= 1e-12 and omega <= 1e-12, (steps, om, omega)
     if case == "pivoting":
-        assert steps >= 1 and om[0] > 1e-11                     # (the unrefined factor is what round 3 shipped)
-    assert res <= 1e-10, (res, res_ref)
+        assert steps >= 1 and om[0] > 1e-13                     # (the unrefined factor is what round 3 shipped: residual 5e-9)
+    assert res <= 2e-11, (res, res_ref)
     # the same factor twice: same bits (no atomics)
     F2 = ddm.Ilu0(ctx, A, bp, direct=True, general=True)
     x2 = torch.zeros(n, dtype=torch.float64, device="cuda")
