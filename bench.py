@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=8)
     ap.add_argument("--no-order-leg", action="store_true", help="skip the second oracle run (other summation order) of the cpu leg")
     ap.add_argument("--no-geneo-check", action="store_true", help="skip the host (scipy) residual check of the device GenEO eigenpairs")
+    ap.add_argument("--emulate-rank-of", type=int, default=0, metavar="N",
+                    help="time the RANK-LOCAL workload of an N-GPU run on this one GPU: the first 8 / N subdomains of the decomposition, every phase, "
+                         "exchanges with the absent ranks cut (problem.restrict_decomposition); no solve, no CPU leg; not a benchmark of the metric")
     ap.add_argument("--no-secondary", action="store_true", help="skip the second workload (configs[3], bench_convdiff.py --problem dg) appended as `secondary`")
     args = ap.parse_args()
 
@@ -132,6 +135,16 @@ def main():
     if P == 1:
         coarse = "none"     # a single subdomain has no overlap region: ILU(0)-preconditioned CG
     dec = build_structured(grid, overlap=args.overlap, pou_type="distance", shrink=0, neumann=(coarse == "geneo"))
+    emulated = None
+    if args.emulate_rank_of:
+        from dune_ddm_amd.problem import restrict_decomposition
+        assert world == 1 and dec.nsub % args.emulate_rank_of == 0
+        keep = list(range(dec.nsub // args.emulate_rank_of))
+        dec = restrict_decomposition(dec, keep)
+        emulated = {"of_n_gpus": args.emulate_rank_of, "subdomains_on_this_rank": len(keep),
+                    "what": "rank 0's share of the decomposition on one GPU; halo pairs and reductions towards the other ranks are cut, everything else (local "
+                            "solves, operator, restriction / prolongation, GenEO setup of these subdomains) is the rank's real work"}
+        args.no_solve, args.cpu_iters, args.no_secondary, args.no_geneo_check = True, 0, True, True
     t_host = time.perf_counter() - t_setup0
     geneo_check = None
     log(rank, f"host setup (assembly, overlap extension, POU): {t_host:.1f} s")
@@ -188,11 +201,17 @@ def main():
     tl.ctx.timing_reset()
     barrier()
     torch.cuda.synchronize()
+    cc0 = tl.ctx.comm_counts()
     t0 = time.perf_counter()
     cg.steps(args.steps)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    cc1 = tl.ctx.comm_counts()
+    collectives = {"allreduce_launches": (cc1[0] - cc0[0]) / args.steps, "allreduce_doubles": (cc1[1] - cc0[1]) / args.steps,
+                   "halo_send_recv_groups": (cc1[2] - cc0[2]) / args.steps,
+                   "what": "RCCL launches per CG iteration as a multi-GPU run issues them (counted in the library, also at N = 1 where nothing is sent): "
+                           "<p,q>, <r,z> and the coarse defect with the previous iteration's defect norm riding on it; three grouped halo exchanges"}
     tl.ctx.timing(False)
     deff = cg.defect()
     tl.prec.check_status()      # a timed-out single-launch local solve would invalidate the timing (raises)
@@ -323,8 +342,13 @@ def main():
             "solve": solve_info,
             "setup_s": {"host": t_host, "device": t_dev},
             "geneo": None if getattr(tl, "geneo_info", None) is None else dict({k: tl.geneo_info[k] for k in ("iterations", "converged", "worst_residual", "used_direct", "setup_s", "iterate_s", "nev")}, host_check=geneo_check),
-            "roofline": roofline, "iteration_traffic": iteration, "cpu_baseline": cpu,
+            "roofline": roofline, "iteration_traffic": iteration, "collectives_per_iteration": collectives, "cpu_baseline": cpu,
         }
+        if emulated:
+            out["metric"] = "RANK-LOCAL workload of an N-GPU run timed on one GPU (not the benchmark metric): CG iterations/s of the rank's share"
+            out["emulated_rank_local"] = emulated
+            out["phase_ms_per_iteration"] = {nm: (v[0] / max(v[1], 1)) for nm, v in timers.items()}
+            out["setup_phases_s"] = {k: float(v) for k, v in tl.setup_times.items()}
         # Second workload of `north_star` where the driver sees it: BASELINE configs[3] (Q1-DG convection-diffusion 512^2, GMRES, GenEO,
         # `umfpack`-type local solves) run as a CHILD process with the same contract (bench_convdiff.py) once this process has
         # released the GPU memory of the headline problem; its whole JSON line is embedded.  N = 1 only; --no-secondary skips it.

@@ -65,6 +65,7 @@ SYMBOLS = {
     "ddm_rccl_unique_id": (_I32, [_P]),
     "ddm_ctx_set_rccl": (_I32, [_P, _I32, _I32, _P, _I32]),
     "ddm_ctx_rccl_size": (_I32, [_P, ctypes.POINTER(ctypes.c_int)]),
+    "ddm_ctx_comm_counts": (_I32, [_P, _P]),
     "ddm_malloc": (_I32, [_P, _I64, _PP]),
     "ddm_free": (_I32, [_P, _P]),
     "ddm_memset_zero": (_I32, [_P, _P, _I64]),
@@ -237,6 +238,12 @@ class Context:
         assert len(unique_id) == 128
         self.check(self.lib.ddm_ctx_set_rccl(self.h, int(rank), int(nranks), ctypes.c_char_p(unique_id), int(bool(self_test))))
         self.rank, self.nranks = rank, nranks
+
+    def comm_counts(self):
+        """(all-reduces, doubles carried, grouped halo exchanges) issued so far -- as a multi-rank run launches them."""
+        c = np.zeros(3, dtype=np.int64)
+        self.check(self.lib.ddm_ctx_comm_counts(self.h, _hp(c)))
+        return [int(v) for v in c]
 
     def rccl_size(self):
         """ranks of the in-library communicator as RCCL reports them (ncclCommCount); 0 = no in-library exchange"""

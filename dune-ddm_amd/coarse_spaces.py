@@ -33,7 +33,8 @@ def _params(ctx, nev, tol, shift, maxit, extra, seed, threshold, nev_max, precon
     par.threshold = float(threshold)
     par.nev_max = int(nev_max if nev_max is not None else 2 * nev)
     par.preconditioner = {"auto": 0, "ilu0": 1, "cholesky": 2}[preconditioner]
-    par.max_direct_flops = float(max_direct_flops)
+    if max_direct_flops is not None:          # (None: the library's per-rank time / memory budget, ddm_geneo_params_default)
+        par.max_direct_flops = float(max_direct_flops)
     par.verbose = int(bool(verbose))
     par.raw = int(bool(raw))
     return par
@@ -85,7 +86,7 @@ def _need(sd, *names):
 
 
 def msgfem_basis(tl, nev=20, tol=1e-5, shift=1e-3, maxit=400, extra=4, seed=0, verbose=False, return_info=False, threshold=-0.5, nev_max=None,
-                 preconditioner="auto", max_direct_flops=2e13, require_convergence=True):
+                 preconditioner="auto", max_direct_flops=None, require_convergence=True):
     """MsGFEMCoarseSpace(A_neu, A_dir, pou, dirichlet_mask, subdomain_boundary_mask, ptree) (coarse_spaces.hh:689-697)."""
     rl, ctx = tl.rl, tl.ctx
     for sd in rl.subs:
@@ -141,7 +142,7 @@ def _extend_and_finalize(tl, ring_vecs, rings, interiors, boundaries):
 
 
 def geneo_ring_basis(tl, ring_matrices, rings, nev=20, tol=1e-5, shift=1e-3, maxit=400, extra=4, seed=0, verbose=False, return_info=False,
-                     preconditioner="auto", max_direct_flops=2e13, require_convergence=True):
+                     preconditioner="auto", max_direct_flops=None, require_convergence=True):
     """GenEORingCoarseSpace(A_dir, A, pou, ring_to_subdomain, ptree) (coarse_spaces.hh:517-633).  ring_matrices[i]: the Neumann
     matrix on the ring's own numbering, rings[i] = ring_to_subdomain, per local subdomain."""
     rl, ctx = tl.rl, tl.ctx
@@ -175,7 +176,7 @@ def geneo_ring_basis(tl, ring_matrices, rings, nev=20, tol=1e-5, shift=1e-3, max
 
 
 def msgfem_ring_basis(tl, ring_matrices, rings, overlap, shrink=0, nev=20, tol=1e-5, shift=1e-3, maxit=400, extra=4, seed=0, verbose=False,
-                      return_info=False, preconditioner="auto", max_direct_flops=2e13, require_convergence=True):
+                      return_info=False, preconditioner="auto", max_direct_flops=None, require_convergence=True):
     """MsGFEMRingCoarseSpace(A_dir, A, overlap, pou, dirichlet_mask, subdomain_boundary_mask, ring_to_subdomain, ptree)
     (coarse_spaces.hh:931-1149)."""
     from .setup_host import bfs_distance

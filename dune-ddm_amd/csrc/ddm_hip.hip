@@ -58,6 +58,11 @@ struct ddm_ctx {
     ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
   } nccl;
   ncclComm_t rccl_comm = nullptr;
+  // collectives of the iteration, counted as a run over several ranks issues them (one count = one RCCL launch: an all-reduce or a
+  // grouped send/receive); ddm_ctx_comm_counts
+  int64_t n_allreduce = 0, n_allreduce_doubles = 0, n_halo_groups = 0;
+  // a scalar waiting to ride on the next coarse-defect all-reduce (ddm_cg_steps: the squared defect norm of the previous iteration)
+  double *piggy = nullptr;
   bool rccl = false, rccl_self = false; // rccl_self: route the self segment through RCCL too (single-GPU self test)
   // side stream of the additive combination: the coarse level's restrict / solve / prolong run beside the latency-bound local solve
   hipStream_t side = nullptr;
@@ -334,12 +339,36 @@ extern "C" int ddm_ctx_rccl_size(ddm_ctx *ctx, int *count)
 // in-place sum over all ranks of n doubles at a device pointer, enqueued on the context's stream
 static int ctx_allreduce(ddm_ctx *ctx, double *buf, int64_t n, const char *what)
 {
+  ctx->n_allreduce += 1;
+  ctx->n_allreduce_doubles += n;
   if (ctx->rccl) {
     if (ctx->nranks > 1 || ctx->rccl_self) NCCLCHECK(ctx, ctx->nccl.AllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, ctx->rccl_comm, ctx->stream));
     return DDM_OK;
   }
   if (ctx->nranks > 1)
     if (ctx->allreduce(ctx->user, buf, n) != 0) return fail(ctx, DDM_ECOMM, "allreduce callback failed (%s)", what);
+  return DDM_OK;
+}
+
+// the coarse defect (K doubles at d0, room for K + 1) summed over the ranks; a scalar waiting in ctx->piggy rides along as element K
+// (one RCCL launch instead of two) and is written back
+__global__ void k_copy_scalar(const double *__restrict__ src, double *__restrict__ dst) { *dst = *src; }
+static int coarse_allreduce(ddm_ctx *ctx, double *d0, int64_t K)
+{
+  double *rider = ctx->piggy;
+  ctx->piggy = nullptr;
+  if (!rider) return ctx_allreduce(ctx, d0, K, "coarse defect");
+  hipLaunchKernelGGL(k_copy_scalar, dim3(1), dim3(1), 0, ctx->stream, (const double *)rider, d0 + K);
+  DDMCHECK(ctx_allreduce(ctx, d0, K + 1, "coarse defect + deferred defect norm"));
+  hipLaunchKernelGGL(k_copy_scalar, dim3(1), dim3(1), 0, ctx->stream, (const double *)(d0 + K), rider);
+  return DDM_OK;
+}
+extern "C" int ddm_ctx_comm_counts(ddm_ctx *ctx, int64_t *counts)
+{
+  if (!ctx || !counts) return DDM_EINVAL;
+  counts[0] = ctx->n_allreduce;
+  counts[1] = ctx->n_allreduce_doubles;
+  counts[2] = ctx->n_halo_groups;
   return DDM_OK;
 }
 
@@ -1324,21 +1353,34 @@ static int ilu0_build_engines(ddm_ctx *ctx, ddm_ilu0 *F, const ddm_csr *A, const
                    (long long)F->n, (long long)F->nnz, SN.j0.size(), min_sn, (long long)SN.nvirt, (long long)F->Lc.nlev, (long long)F->Uc.nlev, (long long)F->Lc.nrows);
     F->L.nlev = F->Lc.nlev;
     F->U.nlev = F->Uc.nlev;
-  } else { // the two triangles on two host threads (each is a single pass over the factor with scattered writes: 1.3 s at 216^3)
-    int rcU = DDM_OK;
-    std::thread tu([&]() {
-      (void)hipSetDevice(ctx->device);
-      rcU = build_schedule(ctx, A, F->h_lu, diag, true, F->U);
-    });
-    rc = build_schedule(ctx, A, F->h_lu, diag, false, F->L);
-    tu.join();
-    if (!rc) rc = rcU;
   }
   if (const char *m = std::getenv("DDM_TRSV_MODE")) F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "xcd2") ? 4 : 8);
   if (multi_rhs_only) F->mode = 0; // only ddm_ilu0_solve_multi will be called (level kernels): no pipe schedule, no tile stream
   F->A = A;
   F->h_diag = diag;
   F->h_block_ptr.assign(block_ptr, block_ptr + nblocks + 1);
+  bool pipe_started = false;
+  if (!F->direct) { // the two triangles of the level schedules on two host threads (each is a single pass over the factor with scattered
+                    // writes: 1.3 s at 216^3), the pipe schedule (its own thread pool) beside them
+    int rcU = DDM_OK, rcP = DDM_OK;
+    std::thread tu([&]() {
+      (void)hipSetDevice(ctx->device);
+      rcU = build_schedule(ctx, A, F->h_lu, diag, true, F->U);
+    });
+    std::thread tp;
+    if (F->mode == 8 && F->n > 0) {
+      pipe_started = true;
+      tp = std::thread([&]() {
+        (void)hipSetDevice(ctx->device);
+        rcP = build_pipe_schedule(ctx, F); // (not applicable: pipe_state < 0, see ddm_ilu0_solve)
+      });
+    }
+    rc = build_schedule(ctx, A, F->h_lu, diag, false, F->L);
+    tu.join();
+    if (tp.joinable()) tp.join();
+    if (!rc) rc = rcU;
+    if (!rc) rc = rcP;
+  }
   // status word of the single-launch engines in pinned, device-mapped HOST memory: a wave that gives up waiting writes its code
   // straight into it, so the host can look at it without synchronising the stream (ilu0_peek_status: every apply checks the
   // applies before it -- fail fast instead of returning stale results until somebody calls ddm_ilu0_status)
@@ -1346,7 +1388,7 @@ static int ilu0_build_engines(ddm_ctx *ctx, ddm_ilu0 *F, const ddm_csr *A, const
     if (hipHostMalloc((void **)&F->err, 128, hipHostMallocMapped) != hipSuccess) rc = fail(ctx, DDM_EHIP, "ILU(0): allocation failed");
     else std::memset(F->err, 0, 128);
   }
-  if (!rc && F->mode == 8 && F->n > 0) rc = build_pipe_schedule(ctx, F); // part of the setup, not of the first solve (not applicable: pipe_state < 0, see ddm_ilu0_solve)
+  if (!rc && F->mode == 8 && F->n > 0 && !pipe_started) rc = build_pipe_schedule(ctx, F); // part of the setup, not of the first solve
   return rc;
 }
 static int ilu0_create_impl(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, bool multi_rhs_only, ddm_ilu0 **out);
@@ -1791,6 +1833,9 @@ static int sn_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, con
     ddm_ilu0_destroy(F);
     return rc;
   }
+  if (std::getenv("DDM_PIPE_VERBOSE"))
+    std::fprintf(stderr, "[ddm] device supernodal %s: single-vector solve: levels 0..%d by launches, %d top levels by the persistent kernel (%d forward phases, grid %d, %s)\n",
+                 lu ? "L U" : "Cholesky", S->ltop - 1, S->ntop, S->top.nph, S->top_grid, S->top_spread ? "one group over all XCDs" : "block b on XCD b % 8");
   if (std::getenv("DDM_PIPE_VERBOSE"))
     std::fprintf(stderr, "[ddm] device supernodal %s: %d refinement step(s) per solve, backward error of the probe %.2e -> %.2e%s\n", lu ? "L U" : "Cholesky", F->refine_steps,
                  F->refine_omega[0], omega, perturbed ? " (vanishing pivot columns replaced)" : "");
@@ -2621,6 +2666,7 @@ static int halo_exchange_impl(ddm_ctx *ctx, ddm_halo *H, const double *src, doub
   if (H->nsend == 0 && H->ndst == 0 && !H->remote) return DDM_OK;
   if (H->nsend > 0) hipLaunchKernelGGL(k_pack, dim3(grid_for(H->nsend)), dim3(WG), 0, ctx->stream, H->nsend, H->send_idx, src, H->sendbuf);
   const double *rbuf = H->recvbuf;
+  ctx->n_halo_groups += 1;
   if (ctx->rccl && (ctx->nranks > 1 || ctx->rccl_self)) {
     // one grouped point-to-point exchange on the context's stream (xGMI links are point-to-point: every peer pair is its own
     // transfer); the self segment stays a device copy unless the single-GPU self test routes it through RCCL as well
@@ -2907,7 +2953,7 @@ extern "C" int ddm_galerkin_create(ddm_ctx *ctx, int64_t n, int64_t n_novlp, con
   };
   dalloc(&G->basis, kmax * G->ld);
   dalloc(&G->partial, (int64_t)G->nchunk * kmax);
-  dalloc(&G->d0, K);
+  dalloc(&G->d0, K + 1); // (+ 1: a scalar may ride on the all-reduce, coarse_allreduce)
   dalloc(&G->x0, K);
   dalloc(&G->d_ovlp, n);
   dalloc(&G->x_ovlp, n);
@@ -2954,7 +3000,7 @@ static int galerkin_apply_impl(ddm_ctx *ctx, ddm_galerkin *G, double *x, const d
   hipLaunchKernelGGL(k_coarse_restrict_final, dim3(1), dim3(WG), 0, ctx->stream, (int)G->nsub, (int)G->kmax, G->sub_chunk_ptr, G->partial,
                      G->coarse_index, G->K, G->d0);
   HIPCHECK(ctx, hipGetLastError());
-  DDMCHECK(ctx_allreduce(ctx, G->d0, G->K, "coarse defect")); // replaces MPI_Gatherv (:170-171): every rank obtains the full coarse defect
+  DDMCHECK(coarse_allreduce(ctx, G->d0, G->K)); // replaces MPI_Gatherv (:170-171): every rank obtains the full coarse defect
   hipLaunchKernelGGL(k_dense_mv, dim3((unsigned)((G->K + 3) / 4)), dim3(WG), 0, ctx->stream, G->K, G->a0inv, G->d0, G->x0); // :174-179 (replicated)
   hipLaunchKernelGGL(k_coarse_prolong, dim3(G->nchunk), dim3(WG), 0, ctx->stream, (int)G->kmax, G->ld, G->basis, G->x0, G->coarse_index,
                      G->chunks, G->x_ovlp, G->nchunk);       // :186-188
@@ -3091,7 +3137,7 @@ static int combined_apply_fused(ddm_ctx *ctx, ddm_combined *C, double *x, const 
     ScopedTimer t(ctx, "GalerkinPrec/apply");
     hipLaunchKernelGGL(k_coarse_restrict_partial, dim3(grid), dim3(WG), 0, ctx->stream, (int)G->kmax, G->ld, G->basis, (const double *)S->d_ovlp, G->chunks, G->partial, G->nchunk);
     hipLaunchKernelGGL(k_coarse_restrict_final, dim3(1), dim3(WG), 0, ctx->stream, (int)G->nsub, (int)G->kmax, G->sub_chunk_ptr, G->partial, G->coarse_index, G->K, G->d0);
-    DDMCHECK(ctx_allreduce(ctx, G->d0, G->K, "coarse defect"));
+    DDMCHECK(coarse_allreduce(ctx, G->d0, G->K));
     hipLaunchKernelGGL(k_dense_mv, dim3((unsigned)((G->K + 3) / 4)), dim3(WG), 0, ctx->stream, G->K, G->a0inv, G->d0, G->x0);
     hipLaunchKernelGGL(k_coarse_prolong, dim3(grid), dim3(WG), 0, ctx->stream, (int)G->kmax, G->ld, G->basis, G->x0, G->coarse_index, G->chunks, G->x_ovlp, G->nchunk);
     return DDM_OK;
@@ -3227,9 +3273,17 @@ extern "C" int ddm_cg_steps(ddm_ctx *ctx, ddm_cg *S, int k)
       else
         hipLaunchKernelGGL(k_cg_update_norm<false>, dim3(nb), dim3(WG), 0, ctx->stream, S->n, scal, S->op->owner, S->p, S->q, S->x, S->b, ctx->partial);
       hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(WG), 0, ctx->stream, nb, ctx->partial, scal + 5);
-      DDMCHECK(ctx_allreduce(ctx, scal + 5, 1, "scalar product"));
+      // The rank-local sum is complete; its all-reduce rides on the coarse-defect all-reduce of the NEXT iteration's preconditioner
+      // (one RCCL launch saved per iteration) unless this is the chunk's last iteration -- whoever reads the defect (ddm_cg_defect)
+      // needs it now -- or there is no coarse level to ride on.
+      if (i + 1 < k && S->prec->galerkin) ctx->piggy = scal + 5;
+      else DDMCHECK(ctx_allreduce(ctx, scal + 5, 1, "scalar product"));
     }
     S->it += 1;
+  }
+  if (ctx->piggy) { // (cannot happen: the last iteration of a chunk reduces its own norm)
+    ctx->piggy = nullptr;
+    DDMCHECK(ctx_allreduce(ctx, scal + 5, 1, "scalar product"));
   }
   HIPCHECK(ctx, hipGetLastError());
   return DDM_OK;

@@ -43,7 +43,16 @@ extern "C" int ddm_geneo_params_default(ddm_geneo_params *p)
   p->extra = 4;
   p->seed = 0;
   p->preconditioner = 0;
-  p->max_direct_flops = 2e13; // multiply-adds: a few seconds of the device factorisation (sn_chol.hpp); the host engine is only taken below 1e11
+  // The exact preconditioner (sparse Cholesky of the pencil) is decided PER RANK by time and memory, not by a fixed size: a time budget
+  // (DDM_GENEO_DIRECT_SECONDS, default 6 s: what the ILU(0)-preconditioned iteration costs at the headline size) times the measured
+  // rate of the device factorisation (1.1e13 multiply-adds / s, sn_chol.hpp) gives this bound on the multiply-adds -- 8 x 111^3 blocks
+  // on one GPU (2.1e14, 154 GB) stay with ILU(0), ONE 111^3 block per GPU (2.6e13, 19 GB: the 8-GPU layout) gets the exact factor
+  // in ~2.4 s and ~20 block iterations -- and the panels must fit into 85 % of the free device memory (sn_direct_create).
+  {
+    double seconds = 6.0;
+    if (const char *e = std::getenv("DDM_GENEO_DIRECT_SECONDS")) seconds = std::atof(e);
+    p->max_direct_flops = seconds * 1.1e13;
+  }
   p->verbose = 0;
   p->raw = 0;
   return DDM_OK;

@@ -29,6 +29,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
@@ -75,6 +76,7 @@ struct Meta { // device pointers
   const int64_t *tptr;      // [n + 1]
   const int64_t *tmid;      // [n]: tidx[tptr[c] .. tmid[c]) come from supernodes BELOW the top levels (Factor::ltop), the rest from top levels
   const int32_t *tidx;
+  const int32_t *tpos;      // [entries of rows]: tidx[tpos[q]] == q: the slot of (supernode, row) q in its row's list (slots are stored in list order)
   double *panels;
   // L U variant (non-symmetric values on the symmetric pattern): the panel of s holds the FULL diagonal block and L_{rows, s};
   // upanels holds U_{s, rows}^T as an nrow x ncol column-major block at uptr[s]; piv[first[s] + k] = row of the diagonal block
@@ -953,6 +955,7 @@ struct Factor {
   std::vector<int32_t> lev_ptr;          // [nlev + 1] into lev_sn
   std::vector<int32_t> lev_big_ptr;      // [nlev + 1] into big_sn
   std::vector<int32_t> lev_maxnc;        // widest supernode of the level
+  std::vector<int32_t> lev_maxnr;        // longest row list of the level
   // Colours (deterministic updates): supernodes of one level whose row lists intersect would subtract from the same ancestor entries.
   // They get different colours; the level's list in lev_sn is sorted by colour and the update kernels run colour by colour, so every
   // panel entry receives its contributions in ONE order (level, colour) whatever the hardware does -- no atomics.
@@ -986,24 +989,36 @@ struct Factor {
   int32_t *d_top_ints = nullptr;  // all integer arrays of the plan in one allocation
   double *d_top_partial = nullptr;
   TopSync *d_top_sync = nullptr;
-  unsigned long long *d_top_flags = nullptr;
+  unsigned long long *d_top_flags = nullptr, *d_top_stamps = nullptr; // stamps: diagnostics (DDM_SN_TOP_STAMPS)
   int top_grid = 0, top_spread = 0;
   int64_t *d_tptr = nullptr, *d_tmid = nullptr;  // transposed row lists (Meta::tptr / tmid / tidx)
-  int32_t *d_tidx = nullptr;
+  int32_t *d_tidx = nullptr, *d_tpos = nullptr;
   double *d_contrib = nullptr; // slots of the forward sweep: one per entry of `rows` and right-hand side
   int64_t contrib_cap = 0, nrows_total = 0;
   int64_t max_big_tiles = 0;
   void release()
   {
+    if (d_top_stamps) { // diagnostics: barrier log of the LAST launch of the persistent kernel
+      std::vector<unsigned long long> h(4000);
+      if (hipMemcpy(h.data(), d_top_stamps, 8 * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+        std::fprintf(stderr, "[ddm] k_sn_top1 barrier log (us since the first barrier; work = arrival - previous release, wait = release - arrival):\n");
+        const unsigned long long t0 = h[3];
+        for (int c = 1; c < 2000 && h[2 * c + 1]; ++c)
+          std::fprintf(stderr, "  barrier %3d: arrive %8.2f release %8.2f  work %6.2f wait %6.2f\n", c, (double)(h[2 * c] - t0) / 100.0, (double)(h[2 * c + 1] - t0) / 100.0,
+                       c > 1 ? (double)(h[2 * c] - h[2 * c - 1]) / 100.0 : 0.0, (double)(h[2 * c + 1] - h[2 * c]) / 100.0);
+      }
+      (void)hipFree(d_top_stamps);
+      d_top_stamps = nullptr;
+    }
     for (void *p : {(void *)d_first, (void *)d_nrow, (void *)d_rows, (void *)d_sn_of_col, (void *)d_iperm, (void *)d_perm, (void *)d_rptr, (void *)d_pptr, (void *)d_panels,
                     (void *)d_lev_sn, (void *)d_preT, (void *)d_preU, (void *)d_big_sn, (void *)d_big_index, (void *)d_preB, (void *)d_err, (void *)d_partial,
-                    (void *)d_upanels, (void *)d_uptr, (void *)d_piv, (void *)d_preUF, (void *)d_tptr, (void *)d_tmid, (void *)d_tidx, (void *)d_contrib, (void *)d_top_ints, (void *)d_top_partial, (void *)d_top_sync, (void *)d_top_flags})
+                    (void *)d_upanels, (void *)d_uptr, (void *)d_piv, (void *)d_preUF, (void *)d_tptr, (void *)d_tmid, (void *)d_tidx, (void *)d_tpos, (void *)d_contrib, (void *)d_top_ints, (void *)d_top_partial, (void *)d_top_sync, (void *)d_top_flags})
       if (p) (void)hipFree(p);
     d_first = d_nrow = d_rows = d_sn_of_col = d_iperm = d_perm = d_lev_sn = d_preT = d_preU = d_big_sn = d_big_index = d_preB = nullptr;
     d_rptr = d_pptr = nullptr;
     d_panels = d_partial = d_upanels = d_contrib = nullptr;
     d_tptr = d_tmid = nullptr;
-    d_tidx = nullptr;
+    d_tidx = d_tpos = nullptr;
     d_top_ints = nullptr;
     d_top_partial = nullptr;
     d_top_sync = nullptr;
@@ -1071,7 +1086,7 @@ static inline bool build_top_plan(Factor &F, const std::vector<int32_t> &lev_sn,
         a_sn.push_back(s);
         const int32_t nr = nrow[(size_t)s], ncs = first[(size_t)s + 1] - first[(size_t)s];
         p_first[(size_t)s] = (int32_t)(p_items.size() / 2);
-        for (int32_t q = 0; q < (nr + S1_CHUNK_ROWS - 1) / S1_CHUNK_ROWS; ++q) {
+        for (int32_t q = 0; q < (nr + TILE - 1) / TILE; ++q) { // backward: one partial product per 64-row tile
           p_items.push_back(s);
           p_items.push_back(q);
         }
@@ -1089,6 +1104,10 @@ static inline bool build_top_plan(Factor &F, const std::vector<int32_t> &lev_sn,
           for (int32_t t = 0; t < (nrow[(size_t)s] + TILE - 1) / TILE; ++t) {
             f_items.push_back(s);
             f_items.push_back(t);
+          }
+          if (nrow[(size_t)s] == 0) { // no rows below (a root): the pseudo tile -1 computes and stores y_s
+            f_items.push_back(s);
+            f_items.push_back(-1);
           }
         }
         f_ptr[(size_t)c * nph + fph[(size_t)j] + col + 1] = (int32_t)(f_items.size() / 2);
@@ -1109,6 +1128,9 @@ static inline bool build_top_plan(Factor &F, const std::vector<int32_t> &lev_sn,
   if (hipMalloc((void **)&F.d_top_sync, sizeof(TopSync)) != hipSuccess || hipMemset(F.d_top_sync, 0, sizeof(TopSync)) != hipSuccess) return false;
   const size_t fbytes = sizeof(unsigned long long) * 9 * TOP_MAX_WG * TOP_FLAG_STRIDE;
   if (hipMalloc((void **)&F.d_top_flags, fbytes) != hipSuccess || hipMemset(F.d_top_flags, 0, fbytes) != hipSuccess) return false;
+  if (std::getenv("DDM_SN_TOP_STAMPS")) {
+    if (hipMalloc((void **)&F.d_top_stamps, 8 * 4000) != hipSuccess || hipMemset(F.d_top_stamps, 0, 8 * 4000) != hipSuccess) return false;
+  }
   F.top.ntop = ntop;
   F.top.nph = nph;
   F.top.a_ptr = F.d_top_ints + o_ap;
@@ -1224,6 +1246,7 @@ static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *b
   F.h_tilesU.assign((size_t)nlev, 0);
   F.h_tilesB.assign((size_t)nlev, 0);
   F.lev_maxnc.assign((size_t)nlev, 0);
+  F.lev_maxnr.assign((size_t)nlev, 0);
   F.lev_big_ptr.assign((size_t)nlev + 1, 0);
   for (int32_t l = 0; l < nlev; ++l) {
     int64_t aT = 0, aU = 0, aB = 0, aUF = 0;
@@ -1246,6 +1269,7 @@ static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *b
         preB.push_back((int32_t)aB);
       }
       F.lev_maxnc[(size_t)l] = std::max(F.lev_maxnc[(size_t)l], first[(size_t)s + 1] - first[(size_t)s]);
+      F.lev_maxnr[(size_t)l] = std::max(F.lev_maxnr[(size_t)l], nrow[(size_t)s]);
     }
     if (aU > 2000000000ll || (lu && aUF > 2000000000ll)) return false;
     preUF[(size_t)(base + F.lev_ptr[(size_t)l + 1] - F.lev_ptr[(size_t)l])] = (int32_t)aUF;
@@ -1284,7 +1308,9 @@ static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *b
         if (level[(size_t)s] < F.ltop) tidx[(size_t)fill_lo[(size_t)r]++] = (int32_t)q;
         else tidx[(size_t)fill_hi[(size_t)r]++] = (int32_t)q;
       }
-    if (!up(tptr, &F.d_tptr) || !up(tmid, &F.d_tmid) || !up(tidx, &F.d_tidx)) return false;
+    std::vector<int32_t> tpos(rows.size());
+    for (size_t k = 0; k < tidx.size(); ++k) tpos[(size_t)tidx[k]] = (int32_t)k;
+    if (!up(tptr, &F.d_tptr) || !up(tmid, &F.d_tmid) || !up(tidx, &F.d_tidx) || !up(tpos, &F.d_tpos)) return false;
   }
   bool ok = up(first, &F.d_first) && up(nrow, &F.d_nrow) && up(rows, &F.d_rows) && up(sn_of_col, &F.d_sn_of_col) && up(iperm, &F.d_iperm) && up(F.h_perm, &F.d_perm) &&
             up(rptr, &F.d_rptr) && up(pptr, &F.d_pptr) && up(lev_sn, &F.d_lev_sn) && up(preT, &F.d_preT) && up(preU, &F.d_preU) && up(big_sn, &F.d_big_sn) &&
@@ -1308,6 +1334,7 @@ static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *b
   F.M.tptr = F.d_tptr;
   F.M.tmid = F.d_tmid;
   F.M.tidx = F.d_tidx;
+  F.M.tpos = F.d_tpos;
   F.M.panels = F.d_panels;
   F.M.upanels = F.d_upanels;
   F.M.uptr = F.d_uptr;
@@ -1396,18 +1423,22 @@ static inline void solve_t(const Factor &F, hipStream_t st, int m, double *B, in
 {
   if (m == 1 && ldb == 1 && Yvec) { // the single-vector kernels (sn_solve1.hpp): level launches at the bottom, one persistent launch for the top
     const int32_t lbot = F.ntop > 0 ? F.ltop : F.nlev; // levels [0, lbot) by launches
+    const char *sk = std::getenv("DDM_SN_SMALL_KERNELS");
+    const bool small_kernels = !(sk && sk[0] == '0');
     for (int32_t l = 0; l < lbot; ++l) {
       const int32_t cnt = F.lev_ptr[(size_t)l + 1] - F.lev_ptr[(size_t)l];
       if (cnt == 0) continue;
       const int32_t *lsn = F.d_lev_sn + F.lev_ptr[(size_t)l], *preT = F.d_preT + F.lev_ptr[(size_t)l] + l;
       const unsigned grid = (unsigned)(F.h_tilesT[(size_t)l] + cnt);
-      if (F.lev_maxnc[(size_t)l] <= 64) hipLaunchKernelGGL((k_sn_fwd1<LU, 64>), dim3(grid), dim3(256), 0, st, F.M, lsn, preT, cnt, (const double *)B, Yvec, F.d_contrib);
+      if (F.lev_maxnc[(size_t)l] <= 64 && F.lev_maxnr[(size_t)l] <= 192 && small_kernels) // a wavefront per supernode
+        hipLaunchKernelGGL(k_sn_fwd1_small<LU>, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, st, F.M, lsn, cnt, (const double *)B, Yvec, F.d_contrib);
+      else if (F.lev_maxnc[(size_t)l] <= 64) hipLaunchKernelGGL((k_sn_fwd1<LU, 64>), dim3(grid), dim3(256), 0, st, F.M, lsn, preT, cnt, (const double *)B, Yvec, F.d_contrib);
       else hipLaunchKernelGGL((k_sn_fwd1<LU, 128>), dim3(grid), dim3(512), 0, st, F.M, lsn, preT, cnt, (const double *)B, Yvec, F.d_contrib);
     }
     if (F.ntop > 0) {
       hipLaunchKernelGGL(k_sn_top_prologue, dim3(1), dim3(64), 0, st, F.d_top_sync);
       hipLaunchKernelGGL(k_sn_top1<LU>, dim3((unsigned)F.top_grid), dim3(TOP_THREADS), 0, st, F.M, F.top, F.nblocks, F.top_spread, B, Yvec, F.d_contrib, F.d_top_partial,
-                         F.d_top_sync, F.d_top_flags, err ? err : F.d_err + 1);
+                         F.d_top_sync, F.d_top_flags, err ? err : F.d_err + 1, F.d_top_stamps);
     }
     for (int32_t l = lbot - 1; l >= 0; --l) {
       const int32_t cnt = F.lev_ptr[(size_t)l + 1] - F.lev_ptr[(size_t)l];
@@ -1416,6 +1447,10 @@ static inline void solve_t(const Factor &F, hipStream_t st, int m, double *B, in
       const int32_t nbig = F.lev_big_ptr[(size_t)l + 1] - F.lev_big_ptr[(size_t)l];
       const int32_t *preB = F.d_preB + F.lev_big_ptr[(size_t)l] + l, *bsn = F.d_big_sn + F.lev_big_ptr[(size_t)l], *bidx = F.d_big_index + F.lev_ptr[(size_t)l];
       const bool small = F.lev_maxnc[(size_t)l] <= 64;
+      if (small && F.lev_maxnr[(size_t)l] <= 192 && small_kernels) {
+        hipLaunchKernelGGL(k_sn_bwd1_small<LU>, dim3((unsigned)((cnt + 3) / 4)), dim3(256), 0, st, F.M, lsn, cnt, (const double *)Yvec, B);
+        continue;
+      }
       if (nbig > 0) {
         if (small) hipLaunchKernelGGL((k_sn_bwd1_partial<LU, 64>), dim3((unsigned)F.h_tilesB[(size_t)l]), dim3(256), 0, st, F.M, bsn, preB, nbig, (const double *)B, F.d_partial);
         else hipLaunchKernelGGL((k_sn_bwd1_partial<LU, 128>), dim3((unsigned)F.h_tilesB[(size_t)l]), dim3(512), 0, st, F.M, bsn, preB, nbig, (const double *)B, F.d_partial);

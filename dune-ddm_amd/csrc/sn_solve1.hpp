@@ -55,12 +55,11 @@ __device__ __forceinline__ void s1_gather(const Meta &M, int32_t s, const double
     row = f + (LU ? M.piv[f + i] : i);
     const int64_t q0 = M.tptr[row], q1 = M.tptr[row + 1];
     int64_t q = q0 + g;
-    for (; q + 12 < q1; q += 16) { // four loads in flight per thread
-      const double c0 = s1_ld<SC1>(contrib + M.tidx[q]), c1 = s1_ld<SC1>(contrib + M.tidx[q + 4]), c2 = s1_ld<SC1>(contrib + M.tidx[q + 8]),
-                   c3 = s1_ld<SC1>(contrib + M.tidx[q + 12]);
+    for (; q + 12 < q1; q += 16) { // four loads in flight per thread (the slots of a row are contiguous: target-major layout)
+      const double c0 = s1_ld<SC1>(contrib + q), c1 = s1_ld<SC1>(contrib + q + 4), c2 = s1_ld<SC1>(contrib + q + 8), c3 = s1_ld<SC1>(contrib + q + 12);
       acc = (((acc + c0) + c1) + c2) + c3;
     }
-    for (; q < q1; q += 4) acc += s1_ld<SC1>(contrib + M.tidx[q]);
+    for (; q < q1; q += 4) acc += s1_ld<SC1>(contrib + q);
   }
   part[g * NCMAX + i] = acc;
   __syncthreads();
@@ -120,7 +119,7 @@ __device__ __forceinline__ void s1_forward_tile(const Meta &M, int32_t s, int ti
       double *p = dst + (M.rows + M.rptr[s])[r0 + tid];
       s1_st(p, s1_ld<true>(p) - sum, wt);
     } else {
-      dst[M.rptr[s] + r0 + tid] = sum;
+      dst[M.tpos[M.rptr[s] + r0 + tid]] = sum; // (slot of this (supernode, row) in the ROW's list: the owner reads its list contiguously)
     }
   }
   __syncthreads();
@@ -243,9 +242,92 @@ __global__ __launch_bounds__(4 * NCMAX) void k_sn_bwd1_diag(Meta M, const int32_
   s1_upper_product<LU, NCMAX>(M, s, t, part, B, false);
 }
 
+// ---- levels of SMALL supernodes (at most 64 columns: the leaves and the first levels above them, thousands per level) ---------------
+// One WAVEFRONT per supernode, four per workgroup, no LDS and no barrier: lane = column (products with the inverse diagonal block)
+// resp. lane = row (tiles of the block below); the vector entries of the other lanes come by shuffles.  The 256-thread kernels above
+// spend a whole workgroup (and, forward, one per row tile) on ~30 columns x ~40 rows: 70-84 us per level and sweep on the DG problem
+// (22 700 leaves), measured; profiles/r04_kernel_stats_sn_solve_dg.csv.
+template <bool LU>
+__global__ __launch_bounds__(256) void k_sn_fwd1_small(Meta M, const int32_t *__restrict__ lev_sn, int cnt, const double *__restrict__ B, double *__restrict__ Y,
+                                                       double *__restrict__ contrib)
+{
+  const int lane = threadIdx.x & 63;
+  const int it = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (it >= cnt) return; // (the whole wavefront: nothing below synchronises across wavefronts)
+  const int32_t s = lev_sn[it];
+  const int32_t f = M.first[s], nc = M.first[s + 1] - f, nr = M.nrow[s];
+  const int64_t ld = nc + nr;
+  const double *P = M.panels + M.pptr[s];
+  double b = 0.0;
+  if (lane < nc) {
+    const int64_t row = f + (LU ? M.piv[f + lane] : lane);
+    b = B[row];
+    for (int64_t q = M.tptr[row]; q < M.tptr[row + 1]; ++q) b -= contrib[q]; // slots of the supernodes below, in list order
+  }
+  double y = LU ? b : 0.0; // (L U: unit lower factor, strict part stored)
+  for (int k0 = 0; k0 < nc; k0 += 8) {
+    double w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w[u] = (lane < nc && k0 + u < (LU ? lane : lane + 1)) ? P[lane + (int64_t)(k0 + u) * ld] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) y += w[u] * __shfl(b, k0 + u);
+  }
+  if (lane < nc) Y[f + lane] = y;
+  for (int r0 = 0; r0 < nr; r0 += 64) {
+    const int r = r0 + lane;
+    double acc = 0.0;
+    for (int k0 = 0; k0 < nc; k0 += 8) {
+      double w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w[u] = (r < nr && k0 + u < nc) ? P[nc + r + (int64_t)(k0 + u) * ld] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += w[u] * __shfl(y, k0 + u);
+    }
+    if (r < nr) contrib[M.tpos[M.rptr[s] + r]] = acc;
+  }
+}
+template <bool LU>
+__global__ __launch_bounds__(256) void k_sn_bwd1_small(Meta M, const int32_t *__restrict__ lev_sn, int cnt, const double *__restrict__ Y, double *__restrict__ B)
+{
+  const int lane = threadIdx.x & 63;
+  const int it = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (it >= cnt) return;
+  const int32_t s = lev_sn[it];
+  const int32_t f = M.first[s], nc = M.first[s + 1] - f, nr = M.nrow[s];
+  const int64_t ld = nc + nr;
+  const double *P = M.panels + M.pptr[s];
+  const double *blk = LU ? M.upanels + M.uptr[s] : P + nc; // rows x columns of the block the backward sweep multiplies with
+  const int64_t bld = LU ? (int64_t)nr : ld;
+  const int32_t *R = M.rows + M.rptr[s];
+  double t = lane < nc ? Y[f + lane] : 0.0; // lane = column k: t_k = y_k - sum_r block[r][k] x[rows[r]], rows in order
+  for (int r0 = 0; r0 < nr; r0 += 64) {
+    const double xr = r0 + lane < nr ? B[R[r0 + lane]] : 0.0;
+    const int rn = min(64, nr - r0);
+    for (int rr = 0; rr < rn; rr += 8) {
+      double w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w[u] = (lane < nc && rr + u < rn) ? blk[r0 + rr + u + (int64_t)lane * bld] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t -= w[u] * __shfl(xr, rr + u);
+    }
+  }
+  double x = 0.0; // lane = column i: x_i = sum_{k >= i} (W^T resp. U^-1)[i][k] t_k
+  for (int k0 = 0; k0 < nc; k0 += 8) {
+    double w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + u;
+      w[u] = (lane < nc && k >= lane && k < nc) ? (LU ? P[lane + (int64_t)k * ld] : P[k + (int64_t)lane * ld]) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x += w[u] * __shfl(t, k0 + u);
+  }
+  if (lane < nc) B[f + lane] = x;
+}
+
 // ---- the persistent kernel for the top of the tree --------------------------------------------------------------------------------
 // Plan (host: build_top_plan): top levels j = 0 .. ntop - 1 (tree level ltop + j), supernodes split by class = block % 8.
-// Item i of p_* writes partial[i * SN_MAX_COLS ..); p_first[s] = first item of s.
+// Item i of p_* (a 64-row tile of a supernode) writes partial[i * SN_MAX_COLS ..); p_first[s] = first item of s.
 struct TopPlan {
   int32_t ntop = 0, nph = 0;                          // top levels; forward phases = sum over the levels of their colours
   const int32_t *a_ptr = nullptr, *a_sn = nullptr;    // [8 ntop + 1]: supernodes of (class, level)
@@ -275,7 +357,7 @@ __device__ __forceinline__ unsigned s1_xcc_id() { return __builtin_amdgcn_s_getr
 
 template <bool LU>
 __global__ __launch_bounds__(TOP_THREADS) void k_sn_top1(Meta M, TopPlan P, int nblocks, int spread, double *__restrict__ B, double *__restrict__ Y, double *__restrict__ contrib,
-                                                     double *__restrict__ partial, TopSync *st, unsigned long long *flags, unsigned *err)
+                                                     double *__restrict__ partial, TopSync *st, unsigned long long *flags, unsigned *err, unsigned long long *stamps)
 {
   constexpr int NCMAX = SN_MAX_COLS;
   __shared__ double bs[NCMAX], ys[NCMAX], part[4 * NCMAX];
@@ -317,15 +399,24 @@ __global__ __launch_bounds__(TOP_THREADS) void k_sn_top1(Meta M, TopPlan P, int 
   unsigned count = 0;
   bool failed = false;
   // all-to-all flag barrier among the W workgroups of the group: every storing wave drains, one lane publishes, wave 0 polls all flags
-  auto group_barrier = [&]() __attribute__((always_inline)) {
+  // all-to-all flag barrier among the W workgroups of the group, in two halves so that panel loads for the next phase can be issued
+  // in between: barrier_arrive -- every storing wave drains, one lane publishes; barrier_wait -- wave 0 polls all flags
+  unsigned long long t_arrive = 0;
+  auto barrier_arrive = [&]() __attribute__((always_inline)) {
+    if (stamps) t_arrive = __builtin_amdgcn_s_memrealtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     ++count;
-    const unsigned long long want = ((unsigned long long)epoch << 32) | count;
     if (tid == 0) {
+      const unsigned long long want = ((unsigned long long)epoch << 32) | count;
       if (wt) __hip_atomic_store(gflags + (size_t)rank * TOP_FLAG_STRIDE, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else gflags[(size_t)rank * TOP_FLAG_STRIDE] = want;
+      else {
+        gflags[(size_t)rank * TOP_FLAG_STRIDE] = want;
+        asm volatile("" ::: "memory");
+      }
     }
+  };
+  auto barrier_wait = [&]() __attribute__((always_inline)) {
     if (tid < 64) {
       for (unsigned spins = 0;; ++spins) {
         bool ok = true;
@@ -346,10 +437,15 @@ __global__ __launch_bounds__(TOP_THREADS) void k_sn_top1(Meta M, TopPlan P, int 
     }
     __syncthreads();
     if (sh_fail) failed = true;
+    // diagnostics (DDM_SN_TOP_STAMPS): rank 0 of the group on XCD 0 records when it arrived at barrier `count` and when it left
+    if (stamps && rank == 0 && xcc == 0 && tid == 0 && count < 2000) {
+      stamps[2 * count] = t_arrive;
+      stamps[2 * count + 1] = __builtin_amdgcn_s_memrealtime();
+    }
   };
   const int ntop = P.ntop;
   // ---- gather: every column of the top supernodes collects the slots the bottom levels left for it (16 columns per item, 32 lanes
-  // per column strided over the list, partial sums folded in a fixed order) ----
+  // per column strided over the row's contiguous slots, four loads in flight, partial sums folded in a fixed order) ----
   for (int c = c_begin; c < c_end; ++c)
     for (int i = P.g_ptr[c] + (int)rank; i < P.g_ptr[c + 1]; i += (int)W) {
       const int32_t s = P.g_items[2 * i], piece = P.g_items[2 * i + 1];
@@ -358,76 +454,197 @@ __global__ __launch_bounds__(TOP_THREADS) void k_sn_top1(Meta M, TopPlan P, int 
       double acc = 0.0;
       if (k < nc) {
         const int64_t q1 = M.tmid[f + k];
-        for (int64_t q = M.tptr[f + k] + l32; q < q1; q += 32) acc += contrib[M.tidx[q]]; // (slots of earlier launches: plain loads)
+        int64_t q = M.tptr[f + k] + l32;
+        for (; q + 96 < q1; q += 128) {
+          double v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = contrib[q + 32 * u]; // (slots of earlier launches: plain loads)
+          acc += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        for (; q < q1; q += 32) acc += contrib[q];
       }
 #pragma unroll
       for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
       if (k < nc && l32 == 0) s1_st(B + f + k, B[f + k] - acc, wt);
     }
-  group_barrier();
-  // ---- forward, bottom-up ----
-  for (int j = 0; j < ntop && !failed; ++j) {
-    for (int c = c_begin; c < c_end; ++c) {
-      const int seg = c * ntop + j;
-      for (int i = P.a_ptr[seg] + (int)rank; i < P.a_ptr[seg + 1]; i += (int)W) {
-        const int32_t s = P.a_sn[i];
-        const int32_t f = M.first[s], nc = M.first[s + 1] - f;
-        if (tid < nc) bs[tid] = s1_ld<true>(B + f + (LU ? M.piv[f + tid] : tid));
-        __syncthreads();
-        s1_lower_product<LU, NCMAX>(M, s, bs, ys, part);
-        if (tid < nc) s1_st(Y + f + tid, ys[tid], wt);
-        __syncthreads();
-      }
+  // Register prefetch: what an item needs from the PANELS does not depend on anybody's results, so it is loaded before the barrier
+  // the item waits behind -- the dependent part of a level is then: barrier, one sc1 round trip for the vector entries, arithmetic
+  // on registers / LDS, one store.  (Without it every level was a chain of 4-5 dependent HBM round trips by one workgroup: ~36 us
+  // per level and sweep pair, measured; tools/sn_solve_probe.py.)
+  double wreg[32], treg[16];
+  int pref_item = -1;
+  // W_s slice of thread (i, sl): forward W[i][32 sl + u] (lower product), backward the transposed access of s1_upper_product
+  auto load_w_fwd = [&](int32_t s) __attribute__((always_inline)) {
+    const int32_t nc = M.first[s + 1] - M.first[s];
+    const int64_t ld = nc + M.nrow[s];
+    const double *Pn = M.panels + M.pptr[s];
+    const int i = tid & (NCMAX - 1), sl = tid / NCMAX;
+    const int k1 = i < nc ? min(32 * sl + 32, LU ? i : i + 1) : 0;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) wreg[u] = 32 * sl + u < k1 ? Pn[i + (int64_t)(32 * sl + u) * ld] : 0.0;
+  };
+  auto load_w_bwd = [&](int32_t s) __attribute__((always_inline)) {
+    const int32_t nc = M.first[s + 1] - M.first[s];
+    const int64_t ld = nc + M.nrow[s];
+    const double *Pn = M.panels + M.pptr[s];
+    const int i = tid & (NCMAX - 1), q = tid / NCMAX;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      const int k = 32 * q + u;
+      wreg[u] = (i < nc && k >= i && k < nc) ? (LU ? Pn[i + (int64_t)k * ld] : Pn[k + (int64_t)i * ld]) : 0.0;
     }
-    group_barrier();
-    if (failed) break;
-    for (int ph = P.fph[j]; ph < P.fph[j + 1] && !failed; ++ph) { // colour by colour: in-place subtraction without conflicts
-      bool any = false;
-      for (int c = c_begin; c < c_end; ++c) {
-        const int seg = c * P.nph + ph;
-        any = any || P.f_ptr[seg + 1] > P.f_ptr[seg];
-        for (int i = P.f_ptr[seg] + (int)rank; i < P.f_ptr[seg + 1]; i += (int)W) {
-          const int32_t s = P.f_items[2 * i], tile = P.f_items[2 * i + 1];
-          const int32_t f = M.first[s], nc = M.first[s + 1] - f;
-          if (tid < nc) ys[tid] = s1_ld<true>(Y + f + tid);
-          __syncthreads();
-          s1_forward_tile<NCMAX, true>(M, s, tile, ys, part, B, wt);
-        }
-      }
-      if (any) group_barrier(); // (uniform over the group: the plan is the same for all its workgroups)
+  };
+  // rows [64 tile, 64 tile + 64) of the block below the diagonal (upper = false: L_{rows,s} in the panel; true: the block the
+  // backward sweep multiplies with: the same for Cholesky, U_{s,rows}^T for L U): thread (rl, sl) holds columns 16 sl .. 16 sl + 15
+  auto load_tile = [&](int32_t s, int tile, bool upper) __attribute__((always_inline)) {
+    const int32_t nc = M.first[s + 1] - M.first[s], nr = M.nrow[s];
+    const double *blk = (LU && upper) ? M.upanels + M.uptr[s] : M.panels + M.pptr[s] + nc;
+    const int64_t bld = (LU && upper) ? (int64_t)nr : (int64_t)nc + nr;
+    const int r = tile * TILE + (tid & 63), sl = tid >> 6;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) treg[u] = (tile >= 0 && r < nr && 16 * sl + u < nc) ? blk[r + (int64_t)(16 * sl + u) * bld] : 0.0;
+  };
+  auto product_from_regs = [&](int32_t nc, const double *vec, double *out, bool add_unit) __attribute__((always_inline)) {
+    // out[i] = sum_k wreg(i, k) vec[k] (+ vec[i] for the unit diagonal of the L U lower factor); ends with a barrier
+    const int i = tid & (NCMAX - 1), sl = tid / NCMAX;
+    double acc = 0.0;
+#pragma unroll
+    for (int u0 = 0; u0 < 32; u0 += 8) { // (eight LDS operands at a time: all 32 at once would not fit beside the prefetched slices)
+      double v8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v8[u] = vec[min(32 * sl + u0 + u, NCMAX - 1)];
+      asm volatile("" : "+v"(v8[0]), "+v"(v8[1]), "+v"(v8[2]), "+v"(v8[3]), "+v"(v8[4]), "+v"(v8[5]), "+v"(v8[6]), "+v"(v8[7]));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += wreg[u0 + u] * v8[u];
+    }
+    part[sl * NCMAX + i] = acc;
+    __syncthreads();
+    if (tid < NCMAX) out[tid] = tid < nc ? (add_unit ? vec[tid] : 0.0) + ((part[tid] + part[NCMAX + tid]) + (part[2 * NCMAX + tid] + part[3 * NCMAX + tid])) : 0.0; // (zeros beyond nc: the callers multiply them with zero panel entries)
+    __syncthreads();
+  };
+  // first item of a forward phase / backward partial phase / backward tail phase that this workgroup will work on (-1: none)
+  auto first_fwd = [&](int ph) { for (int c = c_begin; c < c_end; ++c) { const int i = P.f_ptr[c * P.nph + ph] + (int)rank; if (i < P.f_ptr[c * P.nph + ph + 1]) return i; } return -1; };
+  auto first_part = [&](int j) { for (int c = c_begin; c < c_end; ++c) { const int i = P.p_ptr[c * ntop + j] + (int)rank; if (i < P.p_ptr[c * ntop + j + 1]) return i; } return -1; };
+  auto first_tail = [&](int j) { for (int c = c_begin; c < c_end; ++c) { const int i = P.a_ptr[c * ntop + j] + (int)rank; if (i < P.a_ptr[c * ntop + j + 1]) return i; } return -1; };
+  barrier_arrive();
+  if (ntop > 0 && P.fph[1] > P.fph[0]) {
+    pref_item = first_fwd(0);
+    if (pref_item >= 0) {
+      load_w_fwd(P.f_items[2 * pref_item]);
+      load_tile(P.f_items[2 * pref_item], P.f_items[2 * pref_item + 1], false);
     }
   }
-  // ---- backward, top-down ----
-  for (int j = ntop - 1; j >= 0 && !failed; --j) {
-    bool any = false;
+  barrier_wait();
+  // ---- forward, bottom-up.  An item = (supernode s, row tile t); its workgroup recomputes y_s = W_s b_s itself (no barrier between
+  // "y" and "tiles"; the 128 x 128 inverse block comes from L2 for all but the first), tile 0 (or the pseudo tile -1 of a supernode
+  // without rows) also stores y_s for the backward sweep.  Colour by colour: in-place subtraction without conflicts. ----
+  const int nph = P.nph;
+  for (int ph = 0; ph < nph && !failed; ++ph) {
     for (int c = c_begin; c < c_end; ++c) {
-      const int seg = c * ntop + j;
-      any = any || P.p_ptr[seg + 1] > P.p_ptr[seg];
-      for (int i = P.p_ptr[seg] + (int)rank; i < P.p_ptr[seg + 1]; i += (int)W) {
-        const int32_t s = P.p_items[2 * i], chunk = P.p_items[2 * i + 1];
-        const int32_t nr = M.nrow[s];
-        s1_backward_rows<LU, NCMAX, true>(M, s, chunk * S1_CHUNK_ROWS, min(nr, (chunk + 1) * S1_CHUNK_ROWS), B, partial + (int64_t)i * SN_MAX_COLS, wt);
+      const int seg = c * nph + ph;
+      for (int i = P.f_ptr[seg] + (int)rank; i < P.f_ptr[seg + 1]; i += (int)W) {
+        const int32_t s = P.f_items[2 * i], tile = P.f_items[2 * i + 1];
+        const int32_t f = M.first[s], nc = M.first[s + 1] - f, nr = M.nrow[s];
+        if (i != pref_item) {
+          load_w_fwd(s);
+          load_tile(s, tile, false);
+        }
+        if (tid < nc) bs[tid] = s1_ld<true>(B + f + (LU ? M.piv[f + tid] : tid));
+        if (tid >= nc && tid < NCMAX) bs[tid] = 0.0;
+        __syncthreads();
+        product_from_regs(nc, bs, ys, LU);
+        if (tile <= 0 && tid < nc) s1_st(Y + f + tid, ys[tid], wt);
+        if (tile >= 0) {
+          const int rl = tid & 63, sl = tid >> 6;
+          double acc = 0.0;
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc += treg[u] * ys[min(16 * sl + u, NCMAX - 1)];
+          part[sl * TILE + rl] = acc;
+          __syncthreads();
+          if (tid < TILE && tile * TILE + tid < nr) {
+            double sum = 0.0;
+#pragma unroll
+            for (int q = 0; q < NCMAX / 16; ++q) sum += part[q * TILE + tid];
+            double *pb = B + (M.rows + M.rptr[s])[tile * TILE + tid];
+            s1_st(pb, s1_ld<true>(pb) - sum, wt);
+          }
+        }
+        __syncthreads();
       }
     }
-    if (any) group_barrier();
+    // what the next phase (or the first backward phase) needs from the panels: issued between the two halves of the barrier
+    barrier_arrive();
+    pref_item = -1;
+    if (ph + 1 < nph) {
+      pref_item = first_fwd(ph + 1);
+      if (pref_item >= 0) {
+        load_w_fwd(P.f_items[2 * pref_item]);
+        load_tile(P.f_items[2 * pref_item], P.f_items[2 * pref_item + 1], false);
+      }
+    } else {
+      pref_item = first_part(ntop - 1);
+      if (pref_item >= 0) load_tile(P.p_items[2 * pref_item], P.p_items[2 * pref_item + 1], true);
+    }
+    barrier_wait();
+  }
+  // ---- backward, top-down: partial[item] = (64 rows of the block)^T x(rows); barrier; x_s = W_s^T (y_s - sum of the partials) ----
+  for (int j = ntop - 1; j >= 0 && !failed; --j) {
+    for (int c = c_begin; c < c_end; ++c) {
+      const int seg = c * ntop + j;
+      for (int i = P.p_ptr[seg] + (int)rank; i < P.p_ptr[seg + 1]; i += (int)W) {
+        const int32_t s = P.p_items[2 * i], tile = P.p_items[2 * i + 1];
+        const int32_t nc = M.first[s + 1] - M.first[s], nr = M.nrow[s];
+        if (i != pref_item) load_tile(s, tile, true);
+        const int rl = tid & 63, sl = tid >> 6, r = tile * TILE + rl;
+        const double xr = r < nr ? s1_ld<true>(B + (M.rows + M.rptr[s])[r]) : 0.0;
+        double *out = partial + (int64_t)i * SN_MAX_COLS;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const double v = s1_wave_sum(treg[u] * xr);
+          if (rl == 0 && 16 * sl + u < nc) s1_st(out + 16 * sl + u, v, wt);
+        }
+      }
+    }
+    barrier_arrive();
+    pref_item = first_tail(j);
+    if (pref_item >= 0) load_w_bwd(P.a_sn[pref_item]);
+    barrier_wait();
     if (failed) break;
     for (int c = c_begin; c < c_end; ++c) {
       const int seg = c * ntop + j;
       for (int i = P.a_ptr[seg] + (int)rank; i < P.a_ptr[seg + 1]; i += (int)W) {
         const int32_t s = P.a_sn[i];
         const int32_t f = M.first[s], nc = M.first[s + 1] - f, nr = M.nrow[s];
-        if (tid < nc) {
-          double acc = s1_ld<true>(Y + f + tid);
-          const int npart = (nr + S1_CHUNK_ROWS - 1) / S1_CHUNK_ROWS;
-          const double *pp = partial + (int64_t)P.p_first[s] * SN_MAX_COLS + tid;
-          for (int q = 0; q < npart; ++q) acc -= s1_ld<true>(pp + (int64_t)q * SN_MAX_COLS);
-          bs[tid] = acc;
+        if (i != pref_item) load_w_bwd(s);
+        { // t = y_s - sum of the tile partials: the four thread groups take every fourth partial (four loads in flight each), the
+          // group sums are folded in a fixed order
+          const int i = tid & (NCMAX - 1), g = tid / NCMAX;
+          double acc = 0.0;
+          if (i < nc) {
+            const int npart = (nr + TILE - 1) / TILE;
+            const double *pp = partial + (int64_t)P.p_first[s] * SN_MAX_COLS + i;
+            int q = g;
+            for (; q + 12 < npart; q += 16) {
+              const double p0 = s1_ld<true>(pp + (int64_t)q * SN_MAX_COLS), p1 = s1_ld<true>(pp + (int64_t)(q + 4) * SN_MAX_COLS), p2 = s1_ld<true>(pp + (int64_t)(q + 8) * SN_MAX_COLS),
+                           p3 = s1_ld<true>(pp + (int64_t)(q + 12) * SN_MAX_COLS);
+              acc = (((acc + p0) + p1) + p2) + p3;
+            }
+            for (; q < npart; q += 4) acc += s1_ld<true>(pp + (int64_t)q * SN_MAX_COLS);
+          }
+          part[g * NCMAX + i] = acc;
+          __syncthreads();
+          if (tid < NCMAX) bs[tid] = tid < nc ? s1_ld<true>(Y + f + tid) - ((part[tid] + part[NCMAX + tid]) + (part[2 * NCMAX + tid] + part[3 * NCMAX + tid])) : 0.0;
         }
         __syncthreads();
-        s1_upper_product<LU, NCMAX>(M, s, bs, part, B, wt);
+        product_from_regs(nc, bs, ys, false);
+        if (tid < nc) s1_st(B + f + tid, ys[tid], wt);
+        __syncthreads();
       }
     }
-    group_barrier();
+    barrier_arrive();
+    pref_item = j > 0 ? first_part(j - 1) : -1;
+    if (pref_item >= 0) load_tile(P.p_items[2 * pref_item], P.p_items[2 * pref_item + 1], true);
+    barrier_wait();
   }
 }
 

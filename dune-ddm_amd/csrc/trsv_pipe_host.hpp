@@ -469,21 +469,22 @@ inline bool build(int64_t n, const int64_t *rp, const int32_t *ci, const double 
   }
   S.geo = Geometry(W); // the widest tile (sizes the LDS slots)
   if (nthreads <= 0) nthreads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency())); // (one process per GPU on a node: bounded pools)
-  nthreads = std::min(nthreads, std::max(1, nblocks));
+  nthreads = std::min(nthreads, std::max(1, 2 * nblocks));
 
   std::vector<BlockSweep> BS((size_t)nblocks * 2);
   std::vector<int> regrouped((size_t)nblocks * 2, 0);
-  auto run_blocks = [&](const std::function<void(int)> &f) {
+  // work items = (block, sweep) pairs: the two sweeps of a block are independent of each other
+  auto run_blocks = [&](const std::function<void(int, int)> &f) {
     std::vector<std::thread> th;
     for (int t = 0; t < nthreads; ++t)
       th.emplace_back([&, t]() {
-        for (int b = t; b < nblocks; b += nthreads) f(b);
+        for (int w = t; w < 2 * nblocks; w += nthreads) f(w >> 1, w & 1);
       });
     for (auto &t : th) t.join();
   };
-  run_blocks([&](int b) {
+  run_blocks([&](int b, int sweep) {
     const int64_t r0 = block_ptr[b], nb = block_ptr[b + 1] - r0;
-    for (int sweep = 0; sweep < 2; ++sweep) {
+    {
       const bool upper = sweep == 1;
       auto deps = [&](int64_t i, auto &&f) {
         const int64_t g = r0 + i;
@@ -592,11 +593,11 @@ inline bool build(int64_t n, const int64_t *rp, const int32_t *ci, const double 
       }
   }
   // emit the tiles
-  std::vector<Stats> bstats(nblocks);
-  run_blocks([&](int b) {
+  std::vector<Stats> bstats((size_t)nblocks * 2);
+  run_blocks([&](int b, int sweep) {
     const int64_t r0 = block_ptr[b];
-    Stats &st = bstats[b];
-    for (int sweep = 0; sweep < 2; ++sweep) {
+    Stats &st = bstats[(size_t)b * 2 + sweep];
+    {
       const bool upper = sweep == 1;
       const BlockSweep &B = BS[(size_t)b * 2 + sweep];
       const BlockSweep &BL = BS[(size_t)b * 2];

@@ -50,7 +50,7 @@ def geneo_basis_from_params(tl, eig_ptree=None, **kw):
 
 
 def geneo_basis(tl, nev=20, tol=1e-5, shift=1e-3, maxit=400, extra=4, seed=0, verbose=False, return_info=False, threshold=-0.5,
-                nev_max=None, preconditioner="auto", max_direct_flops=2e13, require_convergence=True):
+                nev_max=None, preconditioner="auto", max_direct_flops=None, require_convergence=True):
     """Returns {local subdomain id: (k, n_s) ndarray} ready for TwoLevelSchwarz.set_coarse_basis (POU-scaled, 2-normalised, zero at
     Dirichlet DoFs).  preconditioner: "auto" (sparse Cholesky of A_neu + shift C when affordable, else ILU(0)), "ilu0", "cholesky".
     Raises if the eigensolver did not converge (require_convergence=False returns the block it has, flagged in info)."""
@@ -72,7 +72,8 @@ def geneo_basis(tl, nev=20, tol=1e-5, shift=1e-3, maxit=400, extra=4, seed=0, ve
     par.threshold = float(threshold)
     par.nev_max = int(nev_max if nev_max is not None else 2 * nev)
     par.preconditioner = {"auto": 0, "ilu0": 1, "cholesky": 2}[preconditioner]
-    par.max_direct_flops = float(max_direct_flops)
+    if max_direct_flops is not None:          # (None: the library's per-rank time / memory budget, ddm_geneo_params_default)
+        par.max_direct_flops = float(max_direct_flops)
     par.verbose = int(bool(verbose))
     kmax = max(par.nev, par.nev_max if threshold > 0 else par.nev)
     n, nsub = rl.n, len(rl.subs)

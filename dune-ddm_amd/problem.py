@@ -52,6 +52,24 @@ class Decomposition:
         return len(self.subs)
 
 
+def restrict_decomposition(dec: "Decomposition", keep) -> "Decomposition":
+    """The decomposition reduced to the subdomains `keep` (renumbered 0 .. len(keep) - 1): their matrices, masks and partitions of
+    unity as they are, the exchange pairs among them; pairs to dropped subdomains are removed.  Every per-subdomain object (local
+    solves, GenEO pencils, restriction / prolongation) is exactly what the rank owning `keep` works on in a run over several GPUs;
+    only the exchanges with the other ranks are cut.  Used to time the rank-local workload of N GPUs on one (bench.py
+    --emulate-rank-of N): NOT a solvable restriction of the global problem."""
+    from dataclasses import replace
+    keep = list(keep)
+    new_id = {s: i for i, s in enumerate(keep)}
+    subs = [replace(dec.subs[s], id=new_id[s]) for s in keep]
+
+    def pairs(d):
+        return {(new_id[a], new_id[b]): v for (a, b), v in d.items() if a in new_id and b in new_id}
+
+    return Decomposition(subs, pairs(dec.novlp_all), pairs(dec.ovlp_owner), pairs(dec.ovlp_all), dec.overlap, dec.nglobal,
+                         {"restricted_from": dec.nsub, "kept": keep})
+
+
 def _pmap(fn, items):
     """[fn(x) for x in items] on host threads: the per-subdomain matrix generation is large numpy array arithmetic, which releases
     the GIL (216^3: 34 s of the run time of bench.py were this loop, sequential).  DDM_HOST_THREADS = 1 switches it off."""

@@ -73,6 +73,12 @@ int ddm_ctx_set_rccl(ddm_ctx *ctx, int rank, int nranks, const void *id128, int 
 /* *count = number of ranks RCCL itself reports for the context's communicator (ncclCommCount), 0 without ddm_ctx_set_rccl:
  * lets a launcher check that the exchange really spans the ranks it started (bench.py prints it next to n_gpus). */
 int ddm_ctx_rccl_size(ddm_ctx *ctx, int *count);
+/* counts[3] = {all-reduces, doubles they carried, grouped halo exchanges} issued through this context so far, counted as a run over
+ * several ranks launches them (one all-reduce / one send-receive group = one RCCL launch), also on a single rank where nothing is
+ * sent: lets a benchmark report collectives per iteration.  In ddm_cg_steps the squared defect norm of an iteration rides on the
+ * coarse-defect all-reduce of the next one (K + 1 doubles, galerkin_preconditioner.hh:170-183): per CG iteration 3 all-reduces
+ * (<p, q>, <r, z>, coarse defect + norm) and 3 halo groups instead of 4 + 3. */
+int ddm_ctx_comm_counts(ddm_ctx *ctx, int64_t *counts);
 
 /* raw device memory helpers for callers that do not bring their own allocator */
 int ddm_malloc(ddm_ctx *ctx, int64_t bytes, void **dptr);
@@ -307,7 +313,8 @@ typedef struct {
   int32_t extra;           /* guard vectors iterated beyond nev (4); nev + extra <= 132 */
   int32_t seed;            /* start block */
   int32_t preconditioner;  /* 0 = sparse Cholesky of A + shift C if its flop count <= max_direct_flops, else ILU(0); 1 = ILU(0); 2 = Cholesky */
-  double max_direct_flops; /* 2e13 multiply-adds: a few seconds of the device factorisation (the host engine is only taken below 1e11) */
+  double max_direct_flops; /* default: a per-rank TIME budget (DDM_GENEO_DIRECT_SECONDS, 6 s) x the measured factorisation rate (1.1e13 multiply-adds / s);
+                            * the panels must also fit into 85 % of the free device memory */
   int32_t verbose;
   int32_t raw;             /* 1: return the eigenvectors normalised to ||v||_2 = 1 without the "v <- D v" of finalize_eigenvectors
                             * (the ring coarse spaces extend the ring eigenvectors first, coarse_spaces.hh:612-627) */

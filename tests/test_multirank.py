@@ -24,7 +24,7 @@ def test_halo_plans_across_ranks_cpu(nproc):
 @pytest.mark.gpu
 def test_two_rank_solve_shares_one_gpu():
     p = _launch("solve", 2, 29541)
-    assert p.returncode == 0 and "SOLVE_OK 2" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+    assert p.returncode == 0 and "SOLVE_OK 2" in p.stdout and "PIGGYBACK_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
 @pytest.mark.gpu
