@@ -1836,6 +1836,9 @@ static int sn_direct_create(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, con
   if (std::getenv("DDM_PIPE_VERBOSE"))
     std::fprintf(stderr, "[ddm] device supernodal %s: single-vector solve: levels 0..%d by launches, %d top levels by the persistent kernel (%d forward phases, grid %d, %s)\n",
                  lu ? "L U" : "Cholesky", S->ltop - 1, S->ntop, S->top.nph, S->top_grid, S->top_spread ? "one group over all XCDs" : "block b on XCD b % 8");
+  if (std::getenv("DDM_PIPE_VERBOSE") && S->chains_ready)
+    std::fprintf(stderr, "[ddm] device supernodal %s: the top levels as %d dense chains on %d chain levels (longest %d links; inverse triangles %.1f MB, external blocks %.1f MB%s), grid %d\n",
+                 lu ? "L U" : "Cholesky", S->ch.nchain(), S->ch.nclev, S->ch.max_links, S->ch.wtot * 8e-6, S->ch.etot * 8e-6, lu ? ", twice for L U" : "", S->chain_grid);
   if (std::getenv("DDM_PIPE_VERBOSE"))
     std::fprintf(stderr, "[ddm] device supernodal %s: %d refinement step(s) per solve, backward error of the probe %.2e -> %.2e%s\n", lu ? "L U" : "Cholesky", F->refine_steps,
                  F->refine_omega[0], omega, perturbed ? " (vanishing pivot columns replaced)" : "");

@@ -944,6 +944,18 @@ __global__ __launch_bounds__(256) void k_sn_bwd_diag(Meta M, const int32_t *__re
 #include "sn_solve1.hpp"
 namespace sn {
 
+// chains of the top levels, host side (sn_solve1.hpp: "CHAINS")
+struct ChainHost {
+  std::vector<int32_t> chain_of;                                                     // [nsn]: chain of a top supernode, -1 below the top levels
+  std::vector<int32_t> first_sn, nlinks, col0, ncol, last_sn, nE, clevel, colour, block; // [nchain]
+  std::vector<int64_t> woff, eoff;                                                   // [nchain] offsets (doubles) of the n x n triangle / the n_E x n block
+  int32_t nclev = 0, max_vec = 0, max_links = 0;
+  int64_t wtot = 0, etot = 0;
+  // setup work lists: links of all chains (scatter) and the (chain, i) pairs of every distance d (inversion)
+  std::vector<int32_t> link_sn, link_chain, link_pre, inv_chain, inv_i, inv_ptr;
+  int nchain() const { return (int)first_sn.size(); }
+};
+
 // ---- host driver -------------------------------------------------------------------------------------------------------------------
 struct Factor {
   int64_t n = 0, entries = 0;
@@ -963,6 +975,7 @@ struct Factor {
   std::vector<int32_t> phase_k;          // first position (relative to lev_ptr[l]) of every colour of every level, plus the level's end
   std::vector<int32_t> h_preU, h_preUF, h_preT; // host copies of the tile prefixes (launch bounds of a colour)
   std::vector<int32_t> h_colour;         // colour of every supernode
+  std::vector<int32_t> h_first;          // host copy of `first`
   // device
   int32_t *d_first = nullptr, *d_nrow = nullptr, *d_rows = nullptr, *d_sn_of_col = nullptr, *d_iperm = nullptr, *d_perm = nullptr;
   int64_t *d_rptr = nullptr, *d_pptr = nullptr;
@@ -990,7 +1003,17 @@ struct Factor {
   double *d_top_partial = nullptr;
   TopSync *d_top_sync = nullptr;
   unsigned long long *d_top_flags = nullptr, *d_top_stamps = nullptr; // stamps: diagnostics (DDM_SN_TOP_STAMPS)
-  int top_grid = 0, top_spread = 0;
+  int top_grid = 0, top_spread = 0, chain_grid = 0;
+  // CHAINS of the top levels (sn_solve1.hpp): a separator wider than SN_MAX_COLS is a chain of links s -> s + 1 = parent(s), each the
+  // only child of the next.  For the single-vector solves a chain is ONE dense unit with an explicitly inverted triangle.
+  ChainHost ch;
+  ChainDev chd{};
+  ChainPlan chp{};
+  const int32_t *ch_link_sn = nullptr, *ch_link_chain = nullptr, *ch_link_pre = nullptr, *ch_inv_chain = nullptr, *ch_inv_i = nullptr;
+  int32_t *d_chain_ints = nullptr;
+  int64_t *d_chain_offs = nullptr;
+  double *d_chain_w = nullptr, *d_chain_e = nullptr, *d_chain_v = nullptr, *d_chain_u = nullptr; // inverse triangles / blocks of the external rows (L; L U: also U^T)
+  bool chains_ready = false;
   int64_t *d_tptr = nullptr, *d_tmid = nullptr;  // transposed row lists (Meta::tptr / tmid / tidx)
   int32_t *d_tidx = nullptr, *d_tpos = nullptr;
   double *d_contrib = nullptr; // slots of the forward sweep: one per entry of `rows` and right-hand side
@@ -1012,13 +1035,17 @@ struct Factor {
     }
     for (void *p : {(void *)d_first, (void *)d_nrow, (void *)d_rows, (void *)d_sn_of_col, (void *)d_iperm, (void *)d_perm, (void *)d_rptr, (void *)d_pptr, (void *)d_panels,
                     (void *)d_lev_sn, (void *)d_preT, (void *)d_preU, (void *)d_big_sn, (void *)d_big_index, (void *)d_preB, (void *)d_err, (void *)d_partial,
-                    (void *)d_upanels, (void *)d_uptr, (void *)d_piv, (void *)d_preUF, (void *)d_tptr, (void *)d_tmid, (void *)d_tidx, (void *)d_tpos, (void *)d_contrib, (void *)d_top_ints, (void *)d_top_partial, (void *)d_top_sync, (void *)d_top_flags})
+                    (void *)d_upanels, (void *)d_uptr, (void *)d_piv, (void *)d_preUF, (void *)d_tptr, (void *)d_tmid, (void *)d_tidx, (void *)d_tpos, (void *)d_chain_ints, (void *)d_chain_offs, (void *)d_chain_w, (void *)d_chain_e, (void *)d_chain_v, (void *)d_chain_u, (void *)d_contrib, (void *)d_top_ints, (void *)d_top_partial, (void *)d_top_sync, (void *)d_top_flags})
       if (p) (void)hipFree(p);
     d_first = d_nrow = d_rows = d_sn_of_col = d_iperm = d_perm = d_lev_sn = d_preT = d_preU = d_big_sn = d_big_index = d_preB = nullptr;
     d_rptr = d_pptr = nullptr;
     d_panels = d_partial = d_upanels = d_contrib = nullptr;
     d_tptr = d_tmid = nullptr;
     d_tidx = d_tpos = nullptr;
+    d_chain_ints = nullptr;
+    d_chain_offs = nullptr;
+    d_chain_w = d_chain_e = d_chain_v = d_chain_u = nullptr;
+    chains_ready = false;
     d_top_ints = nullptr;
     d_top_partial = nullptr;
     d_top_sync = nullptr;
@@ -1044,7 +1071,7 @@ static inline bool up(const std::vector<T> &h, T **d)
 // of their own.  DDM_SN_TOP_MAX overrides the bound (0: level kernels only).  Needs lev_ptr; sets ltop / ntop.
 static inline void decide_top_levels(Factor &F)
 {
-  int top_max = 32;
+  int top_max = 128; // (measured: DG 512^2 1.51 / 1.46 / 1.54 / 1.75 ms per solve at 32 / 128 / 512 / 2048, elasticity 1.31 / 1.29 / 1.28 / 1.39; tools/gpu_r04_i.sh)
   if (const char *e = std::getenv("DDM_SN_TOP_MAX")) top_max = std::atoi(e);
   int32_t ltop = F.nlev;
   while (ltop > 0 && F.lev_ptr[(size_t)ltop] - F.lev_ptr[(size_t)ltop - 1] <= top_max) --ltop;
@@ -1150,19 +1177,286 @@ static inline bool build_top_plan(Factor &F, const std::vector<int32_t> &lev_sn,
   return true;
 }
 
+// Chains among the top supernodes: s -> s + 1 = parent(s) while the parent has no other child (the links a wide separator was cut
+// into).  Chain levels: a chain is one level above the highest chain hanging below it.  Colours inside a chain level: chains whose
+// external row sets intersect subtract from the same entries and run one after the other.
+static inline bool build_chains(Factor &F, int64_t n, const std::vector<int32_t> &level, const std::vector<int32_t> &first, const std::vector<int32_t> &nrow,
+                                const std::vector<int64_t> &rptr, const std::vector<int32_t> &rows, const std::vector<int32_t> &parent_g)
+{
+  ChainHost &H = F.ch;
+  H = ChainHost();
+  if (F.ntop == 0) return true;
+  if (const char *e = std::getenv("DDM_SN_CHAINS"))
+    if (e[0] == '0') return true;
+  const int32_t nsn = F.nsn;
+  std::vector<int32_t> nchild((size_t)nsn, 0);
+  for (int32_t s = 0; s < nsn; ++s)
+    if (parent_g[(size_t)s] >= 0) nchild[(size_t)parent_g[(size_t)s]]++;
+  H.chain_of.assign((size_t)nsn, -1);
+  for (int32_t s = 0; s < nsn; ++s) {
+    if (level[(size_t)s] < F.ltop || H.chain_of[(size_t)s] >= 0) continue;
+    const int32_t c = H.nchain();
+    int32_t cur = s, links = 1;
+    H.chain_of[(size_t)s] = c;
+    for (;;) {
+      const int32_t p = parent_g[(size_t)cur];
+      if (p != cur + 1 || nchild[(size_t)p] != 1 || level[(size_t)p] < F.ltop || F.sn_block[(size_t)p] != F.sn_block[(size_t)s]) break;
+      H.chain_of[(size_t)p] = c;
+      cur = p;
+      ++links;
+    }
+    H.first_sn.push_back(s);
+    H.nlinks.push_back(links);
+    H.col0.push_back(first[(size_t)s]);
+    H.ncol.push_back(first[(size_t)cur + 1] - first[(size_t)s]);
+    H.last_sn.push_back(cur);
+    H.nE.push_back(nrow[(size_t)cur]);
+    H.block.push_back(F.sn_block[(size_t)s]);
+    H.max_links = std::max(H.max_links, links);
+    H.max_vec = std::max(H.max_vec, std::max(H.ncol.back(), H.nE.back()));
+  }
+  const int nch = H.nchain();
+  H.clevel.assign((size_t)nch, 0);
+  for (int c = 0; c < nch; ++c) { // (ascending first supernode: every chain below has been seen)
+    const int32_t p = parent_g[(size_t)H.last_sn[(size_t)c]];
+    if (p >= 0 && H.chain_of[(size_t)p] >= 0) H.clevel[(size_t)H.chain_of[(size_t)p]] = std::max(H.clevel[(size_t)H.chain_of[(size_t)p]], H.clevel[(size_t)c] + 1);
+  }
+  // a chain hanging below an INNER link cannot exist (inner links have one child), but one below the first link raises the level
+  // only through the loop above: levels are final because children have smaller numbers than the first link of their parent chain
+  H.nclev = 0;
+  for (int c = 0; c < nch; ++c) H.nclev = std::max(H.nclev, H.clevel[(size_t)c] + 1);
+  H.colour.assign((size_t)nch, 0);
+  {
+    std::vector<uint64_t> rowmask((size_t)n, 0);
+    std::vector<int32_t> rowstamp((size_t)n, -1);
+    for (int32_t L = 0; L < H.nclev; ++L)
+      for (int c = 0; c < nch; ++c) {
+        if (H.clevel[(size_t)c] != L) continue;
+        const int32_t sl = H.last_sn[(size_t)c];
+        uint64_t used = 0;
+        for (int64_t q = rptr[(size_t)sl]; q < rptr[(size_t)sl + 1]; ++q)
+          if (rowstamp[(size_t)rows[(size_t)q]] == L) used |= rowmask[(size_t)rows[(size_t)q]];
+        if (~used == 0) return false;
+        const int col = __builtin_ctzll(~used);
+        H.colour[(size_t)c] = col;
+        for (int64_t q = rptr[(size_t)sl]; q < rptr[(size_t)sl + 1]; ++q) {
+          const int32_t r = rows[(size_t)q];
+          if (rowstamp[(size_t)r] != L) {
+            rowstamp[(size_t)r] = L;
+            rowmask[(size_t)r] = 0;
+          }
+          rowmask[(size_t)r] |= 1ull << col;
+        }
+      }
+  }
+  H.woff.assign((size_t)nch, 0);
+  H.eoff.assign((size_t)nch, 0);
+  for (int c = 0; c < nch; ++c) {
+    H.woff[(size_t)c] = H.wtot;
+    H.eoff[(size_t)c] = H.etot;
+    H.wtot += (int64_t)H.ncol[(size_t)c] * H.ncol[(size_t)c];
+    H.etot += (int64_t)H.nE[(size_t)c] * H.ncol[(size_t)c];
+  }
+  // setup work lists
+  H.link_pre.push_back(0);
+  for (int c = 0; c < nch; ++c)
+    for (int32_t k = 0; k < H.nlinks[(size_t)c]; ++k) {
+      const int32_t s = H.first_sn[(size_t)c] + k;
+      H.link_sn.push_back(s);
+      H.link_chain.push_back(c);
+      H.link_pre.push_back(H.link_pre.back() + (first[(size_t)s + 1] - first[(size_t)s] + nrow[(size_t)s] + TILE - 1) / TILE);
+    }
+  H.inv_ptr.assign((size_t)std::max(H.max_links, 1) + 1, 0);
+  for (int32_t d = 1; d < H.max_links; ++d) {
+    for (int c = 0; c < nch; ++c)
+      for (int32_t i = d; i < H.nlinks[(size_t)c]; ++i) {
+        H.inv_chain.push_back(c);
+        H.inv_i.push_back(i);
+      }
+    H.inv_ptr[(size_t)d + 1] = (int32_t)H.inv_chain.size();
+  }
+  if (H.max_links >= 1) H.inv_ptr[1] = 0;
+  return true;
+}
+// device side of the chains: arrays, the plan of k_sn_top_chain (one allocation of integers)
+static inline bool upload_chains(Factor &F)
+{
+  ChainHost &H = F.ch;
+  const int nch = H.nchain();
+  if (nch == 0) return true;
+  const int nclev = H.nclev;
+  // phases of the external-row updates: chain levels x colours
+  std::vector<int32_t> eph((size_t)nclev + 1, 0);
+  for (int L = 0; L < nclev; ++L) {
+    int nc = 1;
+    for (int c = 0; c < nch; ++c)
+      if (H.clevel[(size_t)c] == L) nc = std::max(nc, H.colour[(size_t)c] + 1);
+    eph[(size_t)L + 1] = eph[(size_t)L] + nc;
+  }
+  const int nph = eph[(size_t)nclev];
+  std::vector<int32_t> y_ptr((size_t)8 * nclev + 1, 0), t_ptr((size_t)8 * nclev + 1, 0), x_ptr((size_t)8 * nclev + 1, 0), e_ptr((size_t)8 * nph + 1, 0), y_items, t_items, x_items, e_items;
+  for (int cls = 0; cls < 8; ++cls)
+    for (int L = 0; L < nclev; ++L) {
+      for (int c = 0; c < nch; ++c) {
+        if (H.block[(size_t)c] % 8 != cls || H.clevel[(size_t)c] != L) continue;
+        const int nb = (H.ncol[(size_t)c] + 63) / 64;
+        for (int rb = nb - 1; rb >= 0; --rb) { // the long rows first
+          y_items.push_back(c);
+          y_items.push_back(rb);
+          // columns the rows of the block reach: up to the end of the link of the block's last row (the diagonal blocks of the L U
+          // variant are full: the row exchanges are absorbed), for Cholesky the lower triangle is cut by the kernel
+          const int32_t lastrow = H.col0[(size_t)c] + std::min(H.ncol[(size_t)c], 64 * rb + 64) - 1;
+          int32_t sl = H.first_sn[(size_t)c];
+          while (F.h_first[(size_t)sl + 1] <= lastrow) ++sl;
+          y_items.push_back(F.h_first[(size_t)sl + 1] - H.col0[(size_t)c]);
+        }
+        for (int cb = 0; cb < nb; ++cb) { // (the long columns first)
+          x_items.push_back(c);
+          x_items.push_back(cb);
+          if (H.nE[(size_t)c] > 0) {
+            t_items.push_back(c);
+            t_items.push_back(cb);
+          }
+        }
+      }
+      y_ptr[(size_t)cls * nclev + L + 1] = (int32_t)(y_items.size() / 3);
+      x_ptr[(size_t)cls * nclev + L + 1] = (int32_t)(x_items.size() / 2);
+      t_ptr[(size_t)cls * nclev + L + 1] = (int32_t)(t_items.size() / 2);
+      for (int col = 0; col < eph[(size_t)L + 1] - eph[(size_t)L]; ++col) {
+        for (int c = 0; c < nch; ++c) {
+          if (H.block[(size_t)c] % 8 != cls || H.clevel[(size_t)c] != L || H.colour[(size_t)c] != col) continue;
+          for (int t = 0; t < (H.nE[(size_t)c] + 63) / 64; ++t) {
+            e_items.push_back(c);
+            e_items.push_back(t);
+          }
+        }
+        e_ptr[(size_t)cls * nph + eph[(size_t)L] + col + 1] = (int32_t)(e_items.size() / 2);
+      }
+    }
+  std::vector<int32_t> all;
+  auto put = [&](const std::vector<int32_t> &v) {
+    const size_t o = all.size();
+    all.insert(all.end(), v.begin(), v.end());
+    return o;
+  };
+  const size_t o_c0 = put(H.col0), o_nc = put(H.ncol), o_fs = put(H.first_sn), o_nl = put(H.nlinks), o_ls = put(H.last_sn), o_ne = put(H.nE), o_yp = put(y_ptr), o_yi = put(y_items),
+               o_eh = put(eph), o_ep = put(e_ptr), o_ei = put(e_items), o_tp = put(t_ptr), o_ti = put(t_items), o_xp = put(x_ptr), o_xi = put(x_items), o_lsn = put(H.link_sn),
+               o_lch = put(H.link_chain), o_lpre = put(H.link_pre), o_ic = put(H.inv_chain), o_ii = put(H.inv_i);
+  if (!up(all, &F.d_chain_ints)) return false;
+  std::vector<int64_t> offs(H.woff);
+  offs.insert(offs.end(), H.eoff.begin(), H.eoff.end());
+  if (!up(offs, &F.d_chain_offs)) return false;
+  auto dalloc = [](double **p, int64_t cnt) { return hipMalloc((void **)p, sizeof(double) * (size_t)std::max<int64_t>(cnt, 1)) == hipSuccess; };
+  if (!dalloc(&F.d_chain_w, H.wtot) || !dalloc(&F.d_chain_e, H.etot)) return false;
+  if (F.lu && (!dalloc(&F.d_chain_v, H.wtot) || !dalloc(&F.d_chain_u, H.etot))) return false;
+  const int32_t *I = F.d_chain_ints;
+  F.chd.nchain = nch;
+  F.chd.col0 = I + o_c0;
+  F.chd.ncol = I + o_nc;
+  F.chd.first_sn = I + o_fs;
+  F.chd.nlinks = I + o_nl;
+  F.chd.last_sn = I + o_ls;
+  F.chd.nE = I + o_ne;
+  F.chd.woff = F.d_chain_offs;
+  F.chd.eoff = F.d_chain_offs + nch;
+  F.chd.W = F.d_chain_w;
+  F.chd.E = F.d_chain_e;
+  F.chd.V = F.d_chain_v;
+  F.chd.U = F.d_chain_u;
+  F.chp.nclev = nclev;
+  F.chp.nph = nph;
+  F.chp.y_ptr = I + o_yp;
+  F.chp.y_items = I + o_yi;
+  F.chp.eph = I + o_eh;
+  F.chp.e_ptr = I + o_ep;
+  F.chp.e_items = I + o_ei;
+  F.chp.t_ptr = I + o_tp;
+  F.chp.t_items = I + o_ti;
+  F.chp.x_ptr = I + o_xp;
+  F.chp.x_items = I + o_xi;
+  F.chp.g_ptr = F.top.g_ptr;
+  F.chp.g_items = F.top.g_items;
+  F.ch_link_sn = I + o_lsn;
+  F.ch_link_chain = I + o_lch;
+  F.ch_link_pre = I + o_lpre;
+  F.ch_inv_chain = I + o_ic;
+  F.ch_inv_i = I + o_ii;
+  { // the chain kernel holds one chain vector in dynamic LDS: it must fit and leave the co-resident grid of the top levels possible
+    const void *fn = F.lu ? (const void *)k_sn_top_chain<true> : (const void *)k_sn_top_chain<false>;
+    const size_t lds = (size_t)H.max_vec * 8;
+    int per_cu = 0;
+    if (lds > 150 * 1024 || hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, TOP_THREADS, lds) != hipSuccess || per_cu < 1) {
+      H = ChainHost(); // (the link-by-link kernel serves the top levels)
+      return true;
+    }
+    int dev = 0, ncu = 0;
+    (void)hipGetDevice(&dev);
+    F.chain_grid = F.top_grid;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) F.chain_grid = std::min(per_cu, 2) * (ncu / 8 * 8);
+    if (F.chain_grid > TOP_MAX_WG) F.chain_grid = F.top_grid;
+  }
+  return true;
+}
+// after the numeric factorisation: dense copies and the blocked inversion of every chain (enqueued; temporaries freed after a sync)
+static inline hipError_t chain_setup(Factor &F, hipStream_t st)
+{
+  F.chains_ready = false;
+  const ChainHost &H = F.ch;
+  if (H.nchain() == 0) return hipSuccess;
+  hipError_t e;
+  double *Ltmp = nullptr, *Utmp = nullptr;
+  if ((e = hipMalloc((void **)&Ltmp, sizeof(double) * (size_t)std::max<int64_t>(H.wtot, 1))) != hipSuccess) return e;
+  if (F.lu && (e = hipMalloc((void **)&Utmp, sizeof(double) * (size_t)std::max<int64_t>(H.wtot, 1))) != hipSuccess) {
+    (void)hipFree(Ltmp);
+    return e;
+  }
+  (void)hipMemsetAsync(Ltmp, 0, sizeof(double) * (size_t)H.wtot, st);
+  (void)hipMemsetAsync(F.d_chain_w, 0, sizeof(double) * (size_t)H.wtot, st);
+  (void)hipMemsetAsync(F.d_chain_e, 0, sizeof(double) * (size_t)std::max<int64_t>(H.etot, 1), st);
+  if (F.lu) {
+    (void)hipMemsetAsync(Utmp, 0, sizeof(double) * (size_t)H.wtot, st);
+    (void)hipMemsetAsync(F.d_chain_v, 0, sizeof(double) * (size_t)H.wtot, st);
+    (void)hipMemsetAsync(F.d_chain_u, 0, sizeof(double) * (size_t)std::max<int64_t>(H.etot, 1), st);
+  }
+  const int nlinks_total = (int)H.link_sn.size();
+  const unsigned stiles = (unsigned)H.link_pre.back();
+  if (stiles > 0) {
+    if (F.lu) hipLaunchKernelGGL(k_chain_scatter<true>, dim3(stiles), dim3(256), 0, st, F.M, F.chd, F.ch_link_sn, F.ch_link_chain, F.ch_link_pre, nlinks_total, Ltmp, Utmp);
+    else hipLaunchKernelGGL(k_chain_scatter<false>, dim3(stiles), dim3(256), 0, st, F.M, F.chd, F.ch_link_sn, F.ch_link_chain, F.ch_link_pre, nlinks_total, Ltmp, Utmp);
+  }
+  static DeviceOnce attr_once;
+  constexpr size_t inv_lds = (size_t)(SN_MAX_COLS * 64 + 32 * 64) * 8;
+  attr_once.run([]() { (void)hipFuncSetAttribute((const void *)k_chain_invert, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inv_lds); });
+  for (int32_t d = 1; d < H.max_links; ++d) {
+    const int32_t i0 = H.inv_ptr[(size_t)d], i1 = H.inv_ptr[(size_t)d + 1];
+    if (i1 <= i0) continue;
+    hipLaunchKernelGGL(k_chain_invert, dim3((unsigned)(2 * (i1 - i0))), dim3(512), inv_lds, st, F.M, F.chd, (int)d, F.ch_inv_chain + i0, F.ch_inv_i + i0, (const double *)Ltmp, F.d_chain_w);
+    if (F.lu)
+      hipLaunchKernelGGL(k_chain_invert, dim3((unsigned)(2 * (i1 - i0))), dim3(512), inv_lds, st, F.M, F.chd, (int)d, F.ch_inv_chain + i0, F.ch_inv_i + i0, (const double *)Utmp, F.d_chain_v);
+  }
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(Ltmp);
+  if (Utmp) (void)hipFree(Utmp);
+  if (e == hipSuccess) F.chains_ready = true;
+  return e;
+}
+
 // symbolic results of all blocks -> one global structure on the device.  Returns false on an allocation failure.
 static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *block_ptr, std::vector<BlockSym> &BS, bool lu = false)
 {
   F.n = n;
   F.lu = lu;
   F.nblocks = (int)nblocks;
-  std::vector<int32_t> first, nrow, rows, sn_of_col((size_t)n), iperm((size_t)n), level;
+  std::vector<int32_t> first, nrow, rows, sn_of_col((size_t)n), iperm((size_t)n), level, parent_g;
   std::vector<int64_t> rptr(1, 0), pptr(1, 0);
   F.h_perm.resize((size_t)n);
   for (int64_t b = 0; b < nblocks; ++b) {
     BlockSym &S = BS[(size_t)b];
     const int32_t off = (int32_t)block_ptr[b];
     const int32_t nsn = (int32_t)S.first.size() - 1;
+    const int32_t sn_base = (int32_t)first.size();
     for (int32_t s = 0; s < nsn; ++s) {
       const int32_t gs = (int32_t)first.size();
       first.push_back(off + S.first[(size_t)s]);
@@ -1173,6 +1467,7 @@ static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *b
       const int64_t nc = S.first[(size_t)s + 1] - S.first[(size_t)s];
       pptr.push_back(pptr.back() + nc * (nc + (r1 - r0)));
       level.push_back(S.level[(size_t)s]);
+      parent_g.push_back(S.parent[(size_t)s] < 0 ? -1 : sn_base + S.parent[(size_t)s]);
       F.sn_block.push_back((int32_t)b);
       for (int32_t c = S.first[(size_t)s]; c < S.first[(size_t)s + 1]; ++c) sn_of_col[(size_t)(off + c)] = gs;
     }
@@ -1324,6 +1619,8 @@ static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *b
     if (hipMalloc((void **)&F.d_piv, sizeof(int32_t) * (size_t)std::max<int64_t>(n, 1)) != hipSuccess) return false;
   }
   if (!build_top_plan(F, lev_sn, nrow, first)) return false;
+  F.h_first = first;
+  if (!build_chains(F, n, level, first, nrow, rptr, rows, parent_g) || !upload_chains(F)) return false;
   F.M.nsn = F.nsn;
   F.M.first = F.d_first;
   F.M.nrow = F.d_nrow;
@@ -1394,6 +1691,7 @@ static inline hipError_t factorize(Factor &F, hipStream_t st, const int64_t *d_r
   e = hipMemcpy(words, F.d_err, 16, hipMemcpyDeviceToHost);
   *bad = words[0];
   if (perturbed) *perturbed = words[2];
+  if (e == hipSuccess && words[0] == 0) e = chain_setup(F, st); // the dense inverses of the top chains (single-vector solves)
   return e;
 }
 
@@ -1435,7 +1733,11 @@ static inline void solve_t(const Factor &F, hipStream_t st, int m, double *B, in
       else if (F.lev_maxnc[(size_t)l] <= 64) hipLaunchKernelGGL((k_sn_fwd1<LU, 64>), dim3(grid), dim3(256), 0, st, F.M, lsn, preT, cnt, (const double *)B, Yvec, F.d_contrib);
       else hipLaunchKernelGGL((k_sn_fwd1<LU, 128>), dim3(grid), dim3(512), 0, st, F.M, lsn, preT, cnt, (const double *)B, Yvec, F.d_contrib);
     }
-    if (F.ntop > 0) {
+    if (F.ntop > 0 && F.chains_ready) {
+      hipLaunchKernelGGL(k_sn_top_prologue, dim3(1), dim3(64), 0, st, F.d_top_sync);
+      hipLaunchKernelGGL(k_sn_top_chain<LU>, dim3((unsigned)F.chain_grid), dim3(TOP_THREADS), (size_t)F.ch.max_vec * 8, st, F.M, F.chd, F.chp, F.nblocks, F.top_spread, B, Yvec,
+                         (const double *)F.d_contrib, F.d_top_sync, F.d_top_flags, err ? err : F.d_err + 1, F.d_top_stamps);
+    } else if (F.ntop > 0) {
       hipLaunchKernelGGL(k_sn_top_prologue, dim3(1), dim3(64), 0, st, F.d_top_sync);
       hipLaunchKernelGGL(k_sn_top1<LU>, dim3((unsigned)F.top_grid), dim3(TOP_THREADS), 0, st, F.M, F.top, F.nblocks, F.top_spread, B, Yvec, F.d_contrib, F.d_top_partial,
                          F.d_top_sync, F.d_top_flags, err ? err : F.d_err + 1, F.d_top_stamps);

@@ -648,4 +648,361 @@ __global__ __launch_bounds__(TOP_THREADS) void k_sn_top1(Meta M, TopPlan P, int 
   }
 }
 
+
+// ---- CHAINS: the separators of the top levels as dense units ------------------------------------------------------------------------
+// A separator wider than SN_MAX_COLS columns is a chain of links s -> s + 1 = parent(s), every link the only child of the next: m links
+// are m tree levels, i.e. 4 m barriers (or 3 m launches) of a few microseconds each for panels of one or two megabytes -- on the
+// elasticity problem the 20 links of the root separator and the chains below it are 1.1 of the 1.7 ms of a solve (measured, barrier
+// log of DDM_SN_TOP_STAMPS).  For the single-vector solves a chain C (columns [col0, col0 + n), links i = 0 .. m - 1, external rows E =
+// the rows of its last link) is therefore ONE unit with an explicitly inverted triangle:
+//     W = L_CC^-1 (n x n, lower; L U: the row exchanges of the links are absorbed, y_C = W b_C),   E = L_EC (n_E x n),
+//     L U only:  V = (U_CC^T)^-1 (lower, = the transpose of U_CC^-1),   U = U_CE^T (n_E x n);
+//     forward   y_C = W b_C;   b_E -= E y_C                       backward   t = y_C - (E | U)^T x_E;   x_C = (W | V)^T t
+// -- four dense matrix-vector products per chain, each spread over all workgroups of the chain's XCD, two barriers per sweep and
+// chain LEVEL (chains whose children are all done).  The blocked inversion runs once per factorisation (k_chain_scatter,
+// k_chain_invert): X_jj = M_j (the inverted diagonal blocks the factorisation already holds), X_ij = -M_i sum_{k = j}^{i-1} L_ik X_kj,
+// all blocks of one distance d = i - j in one launch.  The dense triangle has as many entries as the in-chain parts of the panels it
+// replaces in the solves: the bytes per solve do not grow.
+struct ChainDev {
+  int32_t nchain = 0;
+  const int32_t *col0 = nullptr, *ncol = nullptr, *first_sn = nullptr, *nlinks = nullptr, *last_sn = nullptr, *nE = nullptr; // [nchain]
+  const int64_t *woff = nullptr, *eoff = nullptr;                                                                        // [nchain]
+  double *W = nullptr, *E = nullptr, *V = nullptr, *U = nullptr;
+};
+// dense copies of the chain's coupling blocks: thread block = (link, 64-row tile of [diagonal block; rows below])
+template <bool LU>
+__global__ __launch_bounds__(256) void k_chain_scatter(Meta M, ChainDev C, const int32_t *__restrict__ link_sn, const int32_t *__restrict__ link_chain,
+                                                       const int32_t *__restrict__ pre, int nlinks_total, double *__restrict__ Ltmp, double *__restrict__ UTtmp)
+{
+  const int it = find_item(pre, nlinks_total, (int32_t)blockIdx.x);
+  const int32_t s = link_sn[it], c = link_chain[it];
+  const int tile = (int)blockIdx.x - pre[it];
+  const int32_t f = M.first[s], nc = M.first[s + 1] - f, nr = M.nrow[s];
+  const int64_t ld = nc + nr;
+  const int64_t n = C.ncol[c], nE = C.nE[c];
+  const int32_t col0 = C.col0[c], co = f - col0;
+  const double *P = M.panels + M.pptr[s];
+  double *W = C.W + C.woff[c], *E = C.E + C.eoff[c];
+  double *V = LU ? C.V + C.woff[c] : nullptr, *U = LU ? C.U + C.eoff[c] : nullptr;
+  double *Lt = Ltmp + C.woff[c], *Ut = LU ? UTtmp + C.woff[c] : nullptr;
+  const int32_t *erows = M.rows + M.rptr[C.last_sn[c]];
+  for (int idx = threadIdx.x; idx < TILE * nc; idx += 256) {
+    const int rr = tile * TILE + idx % TILE, j = idx / TILE; // row rr of [diag; rows], column j of the link
+    if (rr >= nc + nr) continue;
+    if (rr < nc) { // diagonal block: M_k (and, L U, M2_k = (U_kk^-1)^T) straight into the diagonal block of the result
+      const int i = rr;
+      if (!LU) {
+        if (j <= i) W[(co + i) + (int64_t)(co + j) * n] = P[i + (int64_t)j * ld];
+      } else {
+        // y = L^-1 (P b), (P b)[q] = b[piv[q]]:  M[i][piv[q]] = L^-1[i][q]  (unit diagonal implied)
+        const double linv = j < i ? P[i + (int64_t)j * ld] : (j == i ? 1.0 : 0.0);
+        if (j <= i) W[(co + i) + (int64_t)(co + M.piv[f + j]) * n] = linv;
+        if (j >= i) V[(co + j) + (int64_t)(co + i) * n] = P[i + (int64_t)j * ld]; // U^-1[i][j] -> lower triangle of the transpose
+      }
+      continue;
+    }
+    const int r = rr - nc;
+    const int32_t g = (M.rows + M.rptr[s])[r];
+    const double l = P[nc + r + (int64_t)j * ld];
+    const double u = LU ? (M.upanels + M.uptr[s])[r + (int64_t)j * nr] : 0.0;
+    if (g < col0 + (int32_t)n) { // inside the chain
+      Lt[(g - col0) + (int64_t)(co + j) * n] = l;
+      if (LU) Ut[(g - col0) + (int64_t)(co + j) * n] = u;
+    } else {
+      const int32_t e = lower_bound_i32(erows, (int32_t)nE, g);
+      E[e + (int64_t)(co + j) * nE] = l;
+      if (LU) U[e + (int64_t)(co + j) * nE] = u;
+    }
+  }
+}
+// one distance d = i - j of the blocked inversion, all chains: thread block = (chain, i, 64-column half of block j);
+// X_ij = -M_i (sum_{k = j}^{i-1} L_ik X_kj), L = Lsrc (dense copy of the in-chain coupling), X = the result array (diagonal blocks = M)
+__global__ __launch_bounds__(512) void k_chain_invert(Meta M, ChainDev C, int d, const int32_t *__restrict__ item_chain, const int32_t *__restrict__ item_i, const double *__restrict__ Lsrc,
+                                                      double *__restrict__ X)
+{
+  extern __shared__ __attribute__((aligned(16))) double sm[]; // T: 128 x 64, Xs: 32 x 64
+  double *T = sm, *Xs = sm + SN_MAX_COLS * 64;
+  const int c = item_chain[blockIdx.x >> 1], i = item_i[blockIdx.x >> 1], h = (int)blockIdx.x & 1, j = i - d;
+  const int64_t n = C.ncol[c];
+  const int32_t col0 = C.col0[c], s0 = C.first_sn[c];
+  const int co_i = M.first[s0 + i] - col0, ni = M.first[s0 + i + 1] - M.first[s0 + i];
+  const int co_j = M.first[s0 + j] - col0, nj = M.first[s0 + j + 1] - M.first[s0 + j];
+  const int K = co_i - co_j; // columns of the links j .. i - 1
+  const double *L = Lsrc + C.woff[c];
+  double *Xc = X + C.woff[c];
+  const int tid = threadIdx.x, r = tid & (SN_MAX_COLS - 1), cg = tid / SN_MAX_COLS; // row r of block i, columns 16 cg .. 16 cg + 15 of the half
+  const int cbase = 64 * h;
+  if (cbase >= nj) return;
+  double acc[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) acc[u] = 0.0;
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    __syncthreads();
+    for (int idx = tid; idx < 32 * 64; idx += 512) { // X[co_j + k0 + kk][co_j + cbase + cc]
+      const int kk = idx & 31, cc = idx >> 5;
+      Xs[kk * 64 + cc] = (k0 + kk < K && cbase + cc < nj) ? Xc[(co_j + k0 + kk) + (int64_t)(co_j + cbase + cc) * n] : 0.0;
+    }
+    __syncthreads();
+    const int kn = min(32, K - k0);
+    for (int kk = 0; kk < kn; ++kk) {
+      const double a = r < ni ? L[(co_i + r) + (int64_t)(co_j + k0 + kk) * n] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc[u] += a * Xs[kk * 64 + 16 * cg + u];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 16; ++u) T[r * 64 + 16 * cg + u] = acc[u];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 16; ++u) acc[u] = 0.0;
+  for (int q = 0; q < ni; ++q) { // -M_i T
+    const double m = r < ni ? Xc[(co_i + r) + (int64_t)(co_i + q) * n] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc[u] -= m * T[q * 64 + 16 * cg + u];
+  }
+  if (r < ni)
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (cbase + 16 * cg + u < nj) Xc[(co_i + r) + (int64_t)(co_j + cbase + 16 * cg + u) * n] = acc[u];
+}
+
+// Plan of the chain kernel (host: build_chain_plan): chain levels L = 0 .. nclev - 1, classes c = block % 8, segment (c, L) -> c nclev + L.
+// Items are (chain, piece) pairs (y_*: triples with the number of columns the rows reach): y_*: 64-row blocks of the triangle (forward product, largest first); e_*: 64-row tiles of the
+// external rows, by (class, phase) with phases = chain levels x colours (eph: first phase of a level); t_* / x_*: 64-column blocks
+// (backward).  g_*: as in TopPlan (the gather of the bottom levels' slots).
+struct ChainPlan {
+  int32_t nclev = 0, nph = 0;
+  const int32_t *y_ptr = nullptr, *y_items = nullptr;
+  const int32_t *eph = nullptr, *e_ptr = nullptr, *e_items = nullptr;
+  const int32_t *t_ptr = nullptr, *t_items = nullptr;
+  const int32_t *x_ptr = nullptr, *x_items = nullptr;
+  const int32_t *g_ptr = nullptr, *g_items = nullptr;
+};
+
+template <bool LU>
+__global__ __launch_bounds__(TOP_THREADS) void k_sn_top_chain(Meta M, ChainDev C, ChainPlan P, int nblocks, int spread, double *__restrict__ B, double *__restrict__ Y,
+                                                          const double *__restrict__ contrib, TopSync *st, unsigned long long *flags, unsigned *err, unsigned long long *stamps)
+{
+  extern __shared__ __attribute__((aligned(16))) double vec[]; // a chain's vector (max(n, n_E) doubles)
+  __shared__ double part[8 * 64];
+  __shared__ unsigned sh_xcc, sh_xt, sh_gt, sh_fail;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) {
+    const unsigned xcc = s1_xcc_id();
+    sh_xcc = xcc;
+    sh_xt = __hip_atomic_fetch_add(&st->tickets[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh_gt = __hip_atomic_fetch_add(&st->global_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&st->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned fail_ = 0;
+    for (unsigned spins = 0; __hip_atomic_load(&st->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x; ++spins) {
+      if (spins > (1u << 22)) { // the workgroups are not co-resident (another process on the GPU?)
+        __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        fail_ = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    sh_fail = fail_;
+  }
+  __syncthreads();
+  if (sh_fail) return;
+  const unsigned xcc = sh_xcc;
+  const unsigned epoch = __hip_atomic_load(&st->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned tk = lane < 8 ? __hip_atomic_load(&st->tickets[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+  const bool local_ok = !spread && __all(lane >= min(nblocks, 8) || tk >= 1u);
+  const bool wt = !local_ok;
+  const unsigned W = local_ok ? (unsigned)__builtin_amdgcn_readfirstlane((int)__shfl((int)tk, (int)xcc)) : gridDim.x;
+  const unsigned rank = local_ok ? sh_xt : sh_gt;
+  unsigned long long *gflags = flags + (size_t)(local_ok ? xcc : 8u) * TOP_MAX_WG * TOP_FLAG_STRIDE;
+  const int c_begin = local_ok ? (int)xcc : 0, c_end = local_ok ? (int)xcc + 1 : 8;
+  if (W > (unsigned)TOP_MAX_WG) {
+    if (tid == 0) __hip_atomic_store(err, 7u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  unsigned count = 0;
+  bool failed = false;
+  auto group_barrier = [&]() __attribute__((always_inline)) { // all-to-all flags among the W workgroups of the group (see k_sn_top1)
+    const unsigned long long t_arrive = stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ++count;
+    if (tid == 0) {
+      const unsigned long long want = ((unsigned long long)epoch << 32) | count;
+      if (wt) __hip_atomic_store(gflags + (size_t)rank * TOP_FLAG_STRIDE, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else {
+        gflags[(size_t)rank * TOP_FLAG_STRIDE] = want;
+        asm volatile("" ::: "memory");
+      }
+    }
+    if (tid < 64) {
+      for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+        for (unsigned j = (unsigned)lane; j < W; j += 64u) {
+          const unsigned long long v = __hip_atomic_load(gflags + (size_t)j * TOP_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = ok && (unsigned)(v >> 32) == epoch && (unsigned)v >= count;
+        }
+        if (__all(ok)) break;
+        if (spins > (1u << 22)) {
+          if (lane == 0) {
+            __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            sh_fail = 1;
+          }
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __syncthreads();
+    if (sh_fail) failed = true;
+    if (stamps && rank == 0 && xcc == 0 && tid == 0 && count < 2000) {
+      stamps[2 * count] = t_arrive;
+      stamps[2 * count + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+  };
+  // sum over the 8 wavefronts of part[w * 64 + lane] in a fixed order (valid for tid < 64 after the call's barrier)
+  auto fold8 = [&](double v) __attribute__((always_inline)) -> double {
+    part[wave * 64 + lane] = v;
+    __syncthreads();
+    double sres = 0.0;
+    if (tid < 64) sres = ((part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid])) + ((part[256 + tid] + part[320 + tid]) + (part[384 + tid] + part[448 + tid]));
+    __syncthreads();
+    return sres;
+  };
+  // rows [r0, r0 + 64) of a column-major matrix (leading dimension ldm) times vec[0 .. kmax): lane = row, the wavefronts share the
+  // k range; `tri`: only k <= row (lower triangle)
+  auto rows_times_vec = [&](const double *Mx, int64_t ldm, int nrows, int r0, int kmax, bool tri) __attribute__((always_inline)) -> double {
+    const int row = r0 + lane;
+    const int chunk = ((kmax + 63) / 64) * 8; // multiple of 8 per wavefront
+    const int ks = wave * chunk, ke = min(kmax, ks + chunk);
+    double acc = 0.0;
+    for (int k = ks; k < ke; k += 8) {
+      double w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w[u] = (row < nrows && k + u < ke && (!tri || k + u <= row)) ? Mx[row + (int64_t)(k + u) * ldm] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += w[u] * vec[min(k + u, kmax - 1)];
+    }
+    return fold8(acc);
+  };
+  // column `col` of a column-major matrix, rows [k_begin, k_end), times vec[rows]: one wavefront, lanes stride over the rows
+  auto col_times_vec = [&](const double *Mx, int64_t ldm, int col, int k_begin, int k_end) __attribute__((always_inline)) -> double {
+    double acc = 0.0;
+    const double *cp = Mx + (int64_t)col * ldm;
+    int k = k_begin + lane;
+    for (; k + 192 < k_end; k += 256) {
+      const double w0 = cp[k], w1 = cp[k + 64], w2 = cp[k + 128], w3 = cp[k + 192];
+      acc += ((w0 * vec[k] + w1 * vec[k + 64]) + (w2 * vec[k + 128] + w3 * vec[k + 192]));
+    }
+    for (; k < k_end; k += 64) acc += cp[k] * vec[k];
+    return s1_wave_sum(acc);
+  };
+  // ---- gather of the bottom levels' slots (as in k_sn_top1) ----
+  for (int c = c_begin; c < c_end; ++c)
+    for (int i = P.g_ptr[c] + (int)rank; i < P.g_ptr[c + 1]; i += (int)W) {
+      const int32_t s = P.g_items[2 * i], piece = P.g_items[2 * i + 1];
+      const int32_t f = M.first[s], nc = M.first[s + 1] - f;
+      const int k = 16 * piece + (tid >> 5), l32 = tid & 31;
+      double acc = 0.0;
+      if (k < nc) {
+        const int64_t q1 = M.tmid[f + k];
+        int64_t q = M.tptr[f + k] + l32;
+        for (; q + 96 < q1; q += 128) {
+          double v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = contrib[q + 32 * u];
+          acc += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        for (; q < q1; q += 32) acc += contrib[q];
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+      if (k < nc && l32 == 0) s1_st(B + f + k, B[f + k] - acc, wt);
+    }
+  group_barrier();
+  const int nclev = P.nclev;
+  // ---- forward ----
+  for (int L = 0; L < nclev && !failed; ++L) {
+    for (int c = c_begin; c < c_end; ++c) { // y_C = W b_C
+      const int seg = c * nclev + L;
+      for (int i = P.y_ptr[seg] + (int)rank; i < P.y_ptr[seg + 1]; i += (int)W) {
+        const int32_t ch = P.y_items[3 * i], rb = P.y_items[3 * i + 1], kmax = P.y_items[3 * i + 2]; // kmax: end of the last row's link (L U: full diagonal blocks)
+        const int n = C.ncol[ch], col0 = C.col0[ch], r0 = 64 * rb;
+        for (int k = tid; k < kmax; k += TOP_THREADS) vec[k] = s1_ld<true>(B + col0 + k);
+        __syncthreads();
+        const double y = rows_times_vec(C.W + C.woff[ch], n, n, r0, kmax, !LU);
+        if (tid < 64 && r0 + tid < n) s1_st(Y + col0 + r0 + tid, y, wt);
+        __syncthreads();
+      }
+    }
+    group_barrier();
+    if (failed) break;
+    for (int ph = P.eph[L]; ph < P.eph[L + 1] && !failed; ++ph) { // b_E -= E y_C, colour by colour
+      bool any = false;
+      for (int c = c_begin; c < c_end; ++c) {
+        const int seg = c * P.nph + ph;
+        any = any || P.e_ptr[seg + 1] > P.e_ptr[seg];
+        for (int i = P.e_ptr[seg] + (int)rank; i < P.e_ptr[seg + 1]; i += (int)W) {
+          const int32_t ch = P.e_items[2 * i], t = P.e_items[2 * i + 1];
+          const int n = C.ncol[ch], col0 = C.col0[ch], nE = C.nE[ch];
+          for (int k = tid; k < n; k += TOP_THREADS) vec[k] = s1_ld<true>(Y + col0 + k);
+          __syncthreads();
+          const double v = rows_times_vec(C.E + C.eoff[ch], nE, nE, 64 * t, n, false);
+          if (tid < 64 && 64 * t + tid < nE) {
+            double *pb = B + (M.rows + M.rptr[C.last_sn[ch]])[64 * t + tid];
+            s1_st(pb, s1_ld<true>(pb) - v, wt);
+          }
+          __syncthreads();
+        }
+      }
+      if (any) group_barrier();
+    }
+  }
+  // ---- backward ----
+  for (int L = nclev - 1; L >= 0 && !failed; --L) {
+    bool any = false;
+    for (int c = c_begin; c < c_end; ++c) { // t = y_C - (E | U)^T x_E, in place in Y
+      const int seg = c * nclev + L;
+      any = any || P.t_ptr[seg + 1] > P.t_ptr[seg];
+      for (int i = P.t_ptr[seg] + (int)rank; i < P.t_ptr[seg + 1]; i += (int)W) {
+        const int32_t ch = P.t_items[2 * i], cb = P.t_items[2 * i + 1];
+        const int n = C.ncol[ch], col0 = C.col0[ch], nE = C.nE[ch];
+        const int32_t *er = M.rows + M.rptr[C.last_sn[ch]];
+        for (int e = tid; e < nE; e += TOP_THREADS) vec[e] = s1_ld<true>(B + er[e]);
+        __syncthreads();
+        const double *Mx = (LU ? C.U : C.E) + C.eoff[ch];
+        for (int q = 0; q < 8; ++q) {
+          const int col = 64 * cb + 8 * wave + q;
+          if (col < n) {
+            const double v = col_times_vec(Mx, nE, col, 0, nE);
+            if (lane == 0) s1_st(Y + col0 + col, s1_ld<true>(Y + col0 + col) - v, wt);
+          }
+        }
+        __syncthreads();
+      }
+    }
+    if (any) group_barrier();
+    if (failed) break;
+    for (int c = c_begin; c < c_end; ++c) { // x_C = (W | V)^T t
+      const int seg = c * nclev + L;
+      for (int i = P.x_ptr[seg] + (int)rank; i < P.x_ptr[seg + 1]; i += (int)W) {
+        const int32_t ch = P.x_items[2 * i], cb = P.x_items[2 * i + 1];
+        const int n = C.ncol[ch], col0 = C.col0[ch], k0 = 64 * cb;
+        for (int k = k0 + tid; k < n; k += TOP_THREADS) vec[k] = s1_ld<true>(Y + col0 + k);
+        __syncthreads();
+        const double *Mx = (LU ? C.V : C.W) + C.woff[ch];
+        for (int q = 0; q < 8; ++q) {
+          const int col = k0 + 8 * wave + q;
+          if (col < n) {
+            const double v = col_times_vec(Mx, n, col, col, n);
+            if (lane == 0) s1_st(B + col0 + col, v, wt);
+          }
+        }
+        __syncthreads();
+      }
+    }
+    group_barrier();
+  }
+}
+
 } // namespace sn

@@ -208,17 +208,19 @@ def test_device_cholesky_64_cubed_subdomain(ddm, torch_cuda, device_engine):
 
 @pytest.mark.parametrize("parts", [(2, 2, 2), (1, 1, 1), (3, 2, 2)])
 def test_single_vector_top_kernel_matches_level_kernels(ddm, torch_cuda, device_engine, parts, monkeypatch):
-    """The persistent kernel that walks the top levels of the tree (sn_solve1.hpp; 8 blocks: one XCD per block, 1 block: all workgroups
-    one group, 12 blocks: XCDs with two blocks) against the level-by-level launches (DDM_SN_TOP_MAX=0): same solution to rounding
-    (the two paths split the backward dot products differently), each path bitwise reproducible."""
+    """The persistent kernels for the top levels of the tree (sn_solve1.hpp; 8 blocks: one XCD per block, 1 block: all workgroups one
+    group, 12 blocks: XCDs with two blocks) -- the separators as dense chains with inverted triangles (default) and link by link
+    (DDM_SN_CHAINS=0) -- against the level-by-level launches (DDM_SN_TOP_MAX=0): same solution to rounding (the paths split the
+    sums differently), each path bitwise reproducible."""
     import torch
     dec, rl = _blocks(ddm, (37, 35, 33), parts)
     n = rl.n
     rng = np.random.default_rng(23)
     d = torch.as_tensor(rng.standard_normal(n)).cuda()
     out = {}
-    for top in ("32", "0"):
+    for top, chains in (("128", "1"), ("128", "0"), ("0", "1")):     # dense chains / link by link / level launches only
         monkeypatch.setenv("DDM_SN_TOP_MAX", top)
+        monkeypatch.setenv("DDM_SN_CHAINS", chains)
         ctx = ddm.torch_context(0)
         F = ddm.Ilu0(ctx, ddm.CsrMatrix(ctx, rl.A_dir), rl.block_ptr, direct=True)
         x = torch.zeros(n, dtype=torch.float64, device="cuda")
@@ -227,11 +229,13 @@ def test_single_vector_top_kernel_matches_level_kernels(ddm, torch_cuda, device_
         F.solve(d, y)
         ctx.sync()
         assert F.status() == 0 and torch.equal(x, y)
-        out[top] = x.cpu().numpy()
+        out[(top, chains)] = x.cpu().numpy()
         ctx.close()
     M = sp.csr_matrix(rl.A_dir)
-    assert np.abs(out["32"] - out["0"]).max() <= 1e-12 * np.abs(out["0"]).max()
-    assert np.linalg.norm(M @ out["32"] - d.cpu().numpy()) <= 1e-11 * np.linalg.norm(d.cpu().numpy())
+    ref = out[("0", "1")]
+    for key in (("128", "1"), ("128", "0")):
+        assert np.abs(out[key] - ref).max() <= 1e-12 * np.abs(ref).max(), key
+        assert np.linalg.norm(M @ out[key] - d.cpu().numpy()) <= 1e-11 * np.linalg.norm(d.cpu().numpy()), key
 
 
 @pytest.mark.parametrize("case", ["dg", "pivoting"])
