@@ -873,15 +873,15 @@ __global__ __launch_bounds__(TOP_THREADS) void k_sn_top_chain(Meta M, ChainDev C
   // k range; `tri`: only k <= row (lower triangle)
   auto rows_times_vec = [&](const double *Mx, int64_t ldm, int nrows, int r0, int kmax, bool tri) __attribute__((always_inline)) -> double {
     const int row = r0 + lane;
-    const int chunk = ((kmax + 63) / 64) * 8; // multiple of 8 per wavefront
+    const int chunk = ((kmax + 127) / 128) * 16; // multiple of 16 per wavefront
     const int ks = wave * chunk, ke = min(kmax, ks + chunk);
     double acc = 0.0;
-    for (int k = ks; k < ke; k += 8) {
-      double w[8];
+    for (int k = ks; k < ke; k += 16) { // sixteen loads in flight per thread (these products stream the triangle: bandwidth-bound)
+      double w[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) w[u] = (row < nrows && k + u < ke && (!tri || k + u <= row)) ? Mx[row + (int64_t)(k + u) * ldm] : 0.0;
+      for (int u = 0; u < 16; ++u) w[u] = (row < nrows && k + u < ke && (!tri || k + u <= row)) ? Mx[row + (int64_t)(k + u) * ldm] : 0.0;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc += w[u] * vec[min(k + u, kmax - 1)];
+      for (int u = 0; u < 16; ++u) acc += w[u] * vec[min(k + u, kmax - 1)];
     }
     return fold8(acc);
   };
@@ -890,6 +890,12 @@ __global__ __launch_bounds__(TOP_THREADS) void k_sn_top_chain(Meta M, ChainDev C
     double acc = 0.0;
     const double *cp = Mx + (int64_t)col * ldm;
     int k = k_begin + lane;
+    for (; k + 448 < k_end; k += 512) {
+      double w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w[u] = cp[k + 64 * u];
+      acc += ((w[0] * vec[k] + w[1] * vec[k + 64]) + (w[2] * vec[k + 128] + w[3] * vec[k + 192])) + ((w[4] * vec[k + 256] + w[5] * vec[k + 320]) + (w[6] * vec[k + 384] + w[7] * vec[k + 448]));
+    }
     for (; k + 192 < k_end; k += 256) {
       const double w0 = cp[k], w1 = cp[k + 64], w2 = cp[k + 128], w3 = cp[k + 192];
       acc += ((w0 * vec[k] + w1 * vec[k + 64]) + (w2 * vec[k + 128] + w3 * vec[k + 192]));
