@@ -245,9 +245,9 @@ def main():
         traffic, traffic_source = None, None
         try:   # HBM bytes per launch: NOT measured in this run -- read from the committed rocprofv3 --pmc passes of this command
             #    (profiles/, separate FETCH_SIZE / WRITE_SIZE runs, gfx950-corrected: 2 x FETCH_SIZE + WRITE_SIZE); the file is named in the line
-            traffic_source = "profiles/r03_pmc_traffic_grid216_geneo.json"
+            traffic_source = "profiles/r04_pmc_traffic_grid216_geneo.json"
             if not os.path.exists(os.path.join(ROOT, traffic_source)):
-                traffic_source = "profiles/r01_h_pmc_traffic_grid216_pipe.json"
+                traffic_source = "profiles/r03_pmc_traffic_grid216_geneo.json"
             pmc = json.load(open(os.path.join(ROOT, traffic_source)))
             if G == 216 and P == 2 and engine in pmc.get("engine_kernels", {}):
                 traffic = pmc["kernels"][pmc["engine_kernels"][engine]]["hbm_bytes_per_dispatch_corrected"] / world

@@ -11,7 +11,7 @@
 // are issued before the row sums of the current step.  A check that fails there is DEFERRED: the wave computes the current
 // step first (it has the operands), then waits for the producers and issues the gathers (fetch_late) -- a consumer that
 // runs right behind its producer does not idle with work at hand.
-// PIPE_NC = 2 (built, bit-exact, not faster -- DESIGN.md section 3) lets two compute waves alternate the steps of a task:
+// PIPE_NC = 2 (built, bit-exact, not faster -- docs/HISTORY.md section 3) lets two compute waves alternate the steps of a task:
 // wave w takes steps w, w + NC, ...; only the operands flagged in the tile's late mask are read after the previous
 // step has signalled (one LDS word).
 //

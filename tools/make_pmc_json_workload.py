@@ -1,5 +1,5 @@
-"""Condenses the rocprofv3 passes of tools/gpu_prof_r03_workloads.sh for ONE workload of bench_convdiff.py into
-profiles/r03_pmc_traffic_<problem>.json: HBM bytes of one LOCAL SOLVE = sum over the single-right-hand-side triangular-solve
+"""Condenses the rocprofv3 passes of tools/gpu_prof_r0N_workloads.sh for ONE workload of bench_convdiff.py into
+profiles/r0N_pmc_traffic_<problem>.json: HBM bytes of one LOCAL SOLVE = sum over the single-right-hand-side triangular-solve
 kernels (all level launches of both sweeps) of 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, MI355X_MICROARCH.md), divided by the
 number of local solves the profiled run performed (bench_convdiff.py --profile-counts).
 usage: python tools/make_pmc_json_workload.py <problem> <dir with stats/ pmc1/ pmc2/ bench.json> <out.json>"""
@@ -17,7 +17,8 @@ nsolves = bench["local_solves_in_run"]
 def is_solve_kernel(name):
     n = name.replace("void ", "")
     if bench["roofline"].get("engine") == "supernodal":   # device engine: the single-vector kernels of sn_chol.hpp + the two permutations around them
-        return n.startswith("sn::k_sn_fwd1") or n.startswith("sn::k_sn_bwd1_") or n.startswith("ddm::k_perm_gather") or n.startswith("ddm::k_perm_scatter")
+        return (n.startswith("sn::k_sn_fwd1") or n.startswith("sn::k_sn_bwd1_") or n.startswith("sn::k_sn_top") or n.startswith("ddm::k_perm_gather")
+                or n.startswith("ddm::k_perm_scatter"))   # (round 4: + the persistent kernels of the top levels, sn_solve1.hpp)
     return (n.startswith("ddm::k_trsv_") and "multi" not in n) or n.startswith("ddm::k_pipe_permute") or n.startswith("ddm::k_w_permute")
 
 

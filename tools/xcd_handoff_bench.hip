@@ -1,4 +1,4 @@
-// Micro-benchmark behind the design of the XCD-local triangular solve:
+// Micro-benchmark behind the design of the XCD-local triangular solve (docs/HISTORY.md section 3):
 // cost of one "level" hand-off between W single-wave workgroups
 //   mode 0: the W waves of a group all sit on ONE XCD (group chosen from HW_REG_XCC_ID at run time):
 //           plain stores (stay in that XCD's L2) + per-wave flag words, sc1 polls / sc1 loads
