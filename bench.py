@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+PIPE_UNBLOCKED_STEP_US = 1.05   # unblocked in-task step of k_trsv_pipe (measured)
 
 
 def log(rank, *a):
@@ -175,6 +176,7 @@ def main():
         tl.rebuild_combined("additive")
     else:
         tl = TwoLevelSchwarz(dec, rank, world, local_rank, comm, schwarz_type="standard", mode="additive", coarse=coarse, subdomain_solver=args.local_solver)
+    tl.schwarz.wait_setup()     # the pipe schedule is built in the background (beside the GenEO iterations): its end belongs to the setup
     tl.ctx.sync()
     t_dev = time.perf_counter() - t1 - (geneo_check["seconds"] if geneo_check else 0.0)
     log(rank, "device setup phases (s): " + ", ".join(f"{k} {v:.2f}" for k, v in tl.setup_times.items()))
@@ -257,6 +259,14 @@ def main():
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
                     "launches_timed": int(local_cnt)}
+        if engine == "pipe":
+            # the engine's own floor: a task advances one dependency level per in-task step, both sweeps run back to back;
+            # the step is the UNBLOCKED step of the stamped trace at this size (p10 over 54 000 steps of tools/pipe_trace.py
+            # joined with the schedule by tools/pipe_hops.py) -- a measured constant, not timed in this run
+            lev = tl.schwarz.num_levels()
+            roofline["latency_floor_ms"] = (lev[0] + lev[1]) * PIPE_UNBLOCKED_STEP_US * 1e-3
+            roofline["latency_floor"] = {"levels_lower": lev[0], "levels_upper": lev[1], "unblocked_step_us": PIPE_UNBLOCKED_STEP_US,
+                                         "step_source": "stamped trace of round 4 (DESIGN.md section 3)", "frac_of_floor": (lev[0] + lev[1]) * PIPE_UNBLOCKED_STEP_US * 1e-3 / avg_ms}
     # whole-iteration algorithmic traffic: 12(z_o+z) + 16 k n + 56 n + 170 n_o
     k = 0 if tl.galerkin is None else max(tl.k_all)
     it_bytes = 12.0 * (tl.A.nnz + z) + 16.0 * k * n + 56.0 * n + 170.0 * tl.rl.n_o
@@ -322,6 +332,12 @@ def main():
                 cpu["parity_full_length"] = {"oracle_iterations": int(hit[0]), "hip_iterations": None if not solve_info else int(solve_info["iterations"]),
                                              "max_rel_dev_while_rk_ge_2e-3_r0": float(dev[early].max()), "max_rel_dev_common_prefix": float(dev.max()),
                                              "oracle_final_reduction": float(ho_all[int(hit[0])] / ho_all[0])}
+                # the two counts may differ by the iterate at which the smaller count stops: there one run is just below the reduction,
+                # the other just above (the only exception tests/test_gpu_fullsize.py allows at 96^3)
+                kl = min(int(hit[0]), len(gpu_hist) - 1)
+                cpu["parity_full_length"]["at_last_common_iterate"] = {
+                    "k": kl, "hip_reduction": float(gpu_hist[kl] / gpu_hist[0]), "oracle_reduction": float(ho_all[kl] / ho_all[0]), "target": red,
+                    "straddles_target": bool((gpu_hist[kl] / gpu_hist[0] <= red) != (ho_all[kl] / ho_all[0] <= red))}
             prof = ", ".join(f"k={k}: {dev[k]:.1e} (r_k/r_0 {ho[k] / ho[0]:.1e})" for k in (1, 5, 10, 20, 30, 40, 50, len(ho) - 1) if k < len(ho))
             log(rank, f"full-size parity vs oracle over {len(ho) - 1} iterations: max rel. deviation of ||r_k|| = {dev.max():.2e}; {prof}")
             if tl.galerkin is not None and getattr(tl, "a0", None) is not None:

@@ -92,6 +92,7 @@ SYMBOLS = {
     "ddm_schwarz_local_solver": (_P, [_P]),
     "ddm_ilu0_pipe_trace": (_I32, [_P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(ctypes.c_int64)]),
     "ddm_ilu0_num_levels": (_I64, [_P, _I32]),
+    "ddm_ilu0_wait": (_I32, [_P, _P]),
     "ddm_ilu0_engine": (_I32, [_P]),
     "ddm_chol_create": (_I32, [_P, _P, _I64, _P, _D, _PP]),
     "ddm_ilu0_is_direct": (_I32, [_P]),
@@ -160,6 +161,7 @@ SYMBOLS = {
     "ddm_timing_enable": (_I32, [_P, _I32]),
     "ddm_timing_get": (_I32, [_P, ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
     "ddm_timing_reset": (_I32, [_P]),
+    "ddm_synth_q1_matrix": (_I32, [_I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _I32]),
 }
 
 _lib = None
@@ -419,6 +421,10 @@ class Ilu0:
     def num_levels(self, upper=False):
         return int(self.ctx.lib.ddm_ilu0_num_levels(self.h, int(upper)))
 
+    def wait(self):
+        """joins the part of the setup that runs in the background (ddm_ilu0_wait)"""
+        self.ctx.check(self.ctx.lib.ddm_ilu0_wait(self.ctx.h, self.h))
+
     def debug_stamps(self, d, x):
         out = np.zeros(8, dtype=np.uint64)
         self.ctx.check(self.ctx.lib.ddm_ilu0_debug_stamps(self.ctx.h, self.h, _ptr(d), _ptr(x), _hp(out)))
@@ -545,6 +551,13 @@ class SchwarzPreconditioner:
         """triangular-solve engine of the local solver: 'pipe', 'xcd2' (also when pipe declined the matrix), 'levels', or 'supernodal'
         (sparse direct factor of the device engine: dense panels, csrc/sn_chol.hpp)"""
         return self.ENGINES[int(self.ctx.lib.ddm_schwarz_engine(self.h))]
+
+    def wait_setup(self):
+        """joins the local solver's background setup (the pipe engine's schedule is built while the caller goes on, e.g. into the
+        GenEO eigensolver): ddm_ilu0_wait; the first apply would wait for it otherwise"""
+        F = self.ctx.lib.ddm_schwarz_local_solver(self.h)
+        if F:
+            self.ctx.check(self.ctx.lib.ddm_ilu0_wait(self.ctx.h, ctypes.c_void_p(F)))
 
     def factor_nnz(self):
         """stored entries of the local solver's factor (roofline accounting)"""

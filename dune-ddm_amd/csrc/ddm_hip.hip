@@ -6,6 +6,7 @@
 #include "trsv_pipe.hpp"
 #include "sparse_chol_host.hpp"
 #include "sn_chol.hpp"
+#include "synth_host.hpp"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h> // types and enums only: the library is opened with dlopen when ddm_ctx_set_rccl is called
@@ -234,7 +235,7 @@ extern "C" void ddm_ctx_destroy(ddm_ctx *ctx)
 }
 extern "C" const char *ddm_last_error(const ddm_ctx *ctx)
 {
-  if (!ctx) return "no context";
+  if (!ctx) return t_last_error.empty() ? "no context" : t_last_error.c_str();   // context-free entry points: the calling thread's last failure
   static thread_local std::string copy; // (a stable pointer for the caller; ctx->err may be rewritten by a helper thread)
   std::lock_guard<std::mutex> lock(g_err_mutex);
   copy = ctx->err;
@@ -842,6 +843,11 @@ struct ddm_ilu0 {
   int64_t xnrows = 0;
   // pipe engine (mode 8): chains x tasks, see trsv_pipe_host.hpp
   int pipe_state = 0;           // 0 not built, 1 built, -1 not applicable
+  // the pipe schedule is built in the background (its own host threads + uploads; 2.6 s at 216^3, nothing of it is needed before the
+  // first single-vector solve): every reader of the pipe state joins first (ilu0_join)
+  std::thread pipe_builder;
+  int pipe_builder_rc = DDM_OK;
+  std::string pipe_builder_err;
   pipe::Group *p_groups = nullptr;
   pipe::Task *p_tasks = nullptr;
   unsigned char *p_stream = nullptr;
@@ -1329,6 +1335,14 @@ static void free_schedule(TriSchedule &S)
 }
 
 static int build_pipe_schedule(ddm_ctx *ctx, ddm_ilu0 *F);
+// waits for the background part of the setup; its failure is reported by every call that needs the result
+static int ilu0_join(ddm_ctx *ctx, ddm_ilu0 *F)
+{
+  if (F->pipe_builder.joinable()) F->pipe_builder.join();
+  if (F->pipe_builder_rc) return fail(ctx, F->pipe_builder_rc, "%s", F->pipe_builder_err.c_str());
+  return DDM_OK;
+}
+extern "C" int ddm_ilu0_wait(ddm_ctx *ctx, ddm_ilu0 *F) { return F ? ilu0_join(ctx, F) : fail(ctx, DDM_EINVAL, "ddm_ilu0_wait: bad arguments"); }
 // Level schedules, engine selection and the pipe schedule for factor values F->h_lu stored in the pattern of A.
 static int ilu0_build_engines(ddm_ctx *ctx, ddm_ilu0 *F, const ddm_csr *A, const std::vector<int64_t> &diag, int64_t nblocks, const int64_t *block_ptr,
                               bool multi_rhs_only = false)
@@ -1362,24 +1376,27 @@ static int ilu0_build_engines(ddm_ctx *ctx, ddm_ilu0 *F, const ddm_csr *A, const
   bool pipe_started = false;
   if (!F->direct) { // the two triangles of the level schedules on two host threads (each is a single pass over the factor with scattered
                     // writes: 1.3 s at 216^3), the pipe schedule (its own thread pool) beside them
-    int rcU = DDM_OK, rcP = DDM_OK;
+    int rcU = DDM_OK;
     std::thread tu([&]() {
       (void)hipSetDevice(ctx->device);
       rcU = build_schedule(ctx, A, F->h_lu, diag, true, F->U);
     });
-    std::thread tp;
     if (F->mode == 8 && F->n > 0) {
       pipe_started = true;
-      tp = std::thread([&]() {
+      F->pipe_builder = std::thread([ctx, F]() {
         (void)hipSetDevice(ctx->device);
-        rcP = build_pipe_schedule(ctx, F); // (not applicable: pipe_state < 0, see ddm_ilu0_solve)
+        F->pipe_builder_rc = build_pipe_schedule(ctx, F); // (not applicable: pipe_state < 0, see ddm_ilu0_solve)
+        if (F->pipe_builder_rc) F->pipe_builder_err = last_error_of_this_thread();
       });
     }
     rc = build_schedule(ctx, A, F->h_lu, diag, false, F->L);
     tu.join();
-    if (tp.joinable()) tp.join();
     if (!rc) rc = rcU;
-    if (!rc) rc = rcP;
+    static const bool background = !std::getenv("DDM_PIPE_ASYNC") || std::atoi(std::getenv("DDM_PIPE_ASYNC")) != 0;
+    if (!background || rc) {     // DDM_PIPE_ASYNC=0: the whole setup inside the create call, as before round 4
+      const int rcj = ilu0_join(ctx, F);
+      if (!rc) rc = rcj;
+    }
   }
   // status word of the single-launch engines in pinned, device-mapped HOST memory: a wave that gives up waiting writes its code
   // straight into it, so the host can look at it without synchronising the stream (ilu0_peek_status: every apply checks the
@@ -1436,7 +1453,7 @@ static int ilu0_create_impl(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, con
   }
   if (std::getenv("DDM_PIPE_VERBOSE"))
     std::fprintf(stderr, "[ddm] ILU(0) setup: %lld rows, factorisation (host, one thread per block) %.2f s, level schedules%s %.2f s\n", (long long)F->n, t_factor,
-                 multi_rhs_only ? "" : " + single-launch engine", since() - t_factor);
+                 multi_rhs_only ? "" : (F->pipe_builder.joinable() ? " (single-launch engine: being built in the background)" : " + single-launch engine"), since() - t_factor);
   *out = F;
   return DDM_OK;
 }
@@ -1961,6 +1978,7 @@ extern "C" int64_t ddm_ilu0_nnz(const ddm_ilu0 *F) { return F ? F->nnz : 0; }
 extern "C" void ddm_ilu0_destroy(ddm_ilu0 *F)
 {
   if (!F) return;
+  if (F->pipe_builder.joinable()) F->pipe_builder.join();
   if (F->graph) (void)hipGraphExecDestroy(F->graph);
   if (F->mgraph) (void)hipGraphExecDestroy(F->mgraph);
   (void)hipFree(F->ref_rp);
@@ -2022,6 +2040,7 @@ extern "C" int ddm_ilu0_engine(const ddm_ilu0 *F)
 {
   if (!F) return -1;
   if (F->sn) return 16; // device supernodal factor (sn_chol.hpp)
+  if (F->pipe_builder.joinable()) const_cast<ddm_ilu0 *>(F)->pipe_builder.join();   // (the answer depends on what the builder found)
   return (F->mode == 8 && F->pipe_state < 0) ? 4 : F->mode;
 }
 extern "C" int ddm_ilu0_get_factors_host(ddm_ctx *ctx, const ddm_ilu0 *F, double *lu_host)
@@ -2274,6 +2293,7 @@ extern "C" int ddm_ilu0_debug_stamps(ddm_ctx *ctx, ddm_ilu0 *F, const double *d,
   unsigned long long *st = nullptr;
   HIPCHECK(ctx, hipMalloc((void **)&st, 64));
   HIPCHECK(ctx, hipMemset(st, 0, 64));
+  DDMCHECK(ilu0_join(ctx, F));
   if (!F->xcd_built) DDMCHECK(build_xcd_schedule(ctx, F));
   hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate);
   hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(F->n)), dim3(WG), 0, ctx->stream, F->n, F->xlpos, F->xrows, d, F->xdperm);
@@ -2291,6 +2311,7 @@ extern "C" int ddm_ilu0_pipe_trace(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, d
                                    int64_t capacity_tasks, int64_t *ntasks)
 {
   if (!F || !ntasks) return fail(ctx, DDM_EINVAL, "ddm_ilu0_pipe_trace: bad arguments");
+  DDMCHECK(ilu0_join(ctx, F));
   if (F->pipe_state == 0) DDMCHECK(build_pipe_schedule(ctx, F));
   if (F->pipe_state < 0) return fail(ctx, DDM_EINVAL, "pipe engine not applicable to this matrix");
   const int64_t nt = F->p_stats.ntasks[0] + F->p_stats.ntasks[1];
@@ -2330,6 +2351,7 @@ static int ilu0_solve_epilogue(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, doubl
     F->graph = nullptr;
   }
   if (F->sn && !sn::reserve(*F->sn, 1)) return fail(ctx, DDM_EHIP, "sparse direct solver: allocation failed");
+  DDMCHECK(ilu0_join(ctx, F));
   if (F->mode == 8 && F->pipe_state == 0) DDMCHECK(build_pipe_schedule(ctx, F));
   if (F->mode == 8 && F->pipe_state < 0) F->mode = 4; // not applicable: the loader engine takes any matrix
   if (F->mode == 4 && !F->xcd_built) DDMCHECK(build_xcd_schedule(ctx, F));
@@ -3614,4 +3636,22 @@ extern "C" int ddm_dense_sym_eig_host(int n, double *V, double *w) { return dens
 extern "C" int ddm_dense_rayleigh_ritz_host(int p, const double *gA, const double *gC, int keep, double tau, double *mu, double *Y)
 {
   return dense::rayleigh_ritz(p, gA, gC, keep, tau, mu, Y);
+}
+
+// ---- input synthesis on the host (bench.py / tests: the matrices PDELab's assembler hands to the reference) ----------------------
+extern "C" int ddm_synth_q1_matrix(int dim, const int64_t *bshape, const double *ke, const int64_t *eshape, const int64_t *eoff, const double *K,
+                                   const uint8_t *inset, const int64_t *loc_of_box, int64_t n, const int64_t *box_index, const uint8_t *dmask,
+                                   const double *diag, int64_t *indptr, int32_t *indices, double *data, int nthreads)
+{
+    if ((dim != 2 && dim != 3) || !bshape || !ke || !eshape || !eoff || !K || !indptr || n < 0 || (indices && !data))
+        return fail(nullptr, DDM_EINVAL, "ddm_synth_q1_matrix: bad arguments");
+    int64_t nbox = 1;
+    for (int d = 0; d < dim; ++d) {
+        if (bshape[d] < 1 || eshape[d] < 0 || eoff[d] < 0) return fail(nullptr, DDM_EINVAL, "ddm_synth_q1_matrix: bad box");
+        nbox *= bshape[d];
+    }
+    if (nbox >= INT32_MAX || (!box_index && n != nbox)) return fail(nullptr, DDM_EINVAL, "ddm_synth_q1_matrix: box too large or row count does not match the box");
+    synth::Q1Args A{dim, bshape, ke, eshape, eoff, K, inset, loc_of_box, n, box_index, dmask, diag};
+    synth::q1_rows(A, indptr, indices, data, nthreads);
+    return DDM_OK;
 }

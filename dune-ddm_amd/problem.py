@@ -79,8 +79,13 @@ def _pmap(fn, items):
     if nt <= 1:
         return [fn(x) for x in items]
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(nt) as ex:
-        return list(ex.map(fn, items))
+    from . import synth
+    synth.INNER_THREADS = max(1, (os.cpu_count() or 1) // nt)     # the native generator's own threads: share the cores with the pool
+    try:
+        with ThreadPoolExecutor(nt) as ex:
+            return list(ex.map(fn, items))
+    finally:
+        synth.INNER_THREADS = None
 
 
 def build_structured(grid, overlap=2, pou_type="distance", shrink=0, neumann=False, second_region="overlap") -> Decomposition:

@@ -128,6 +128,56 @@ def eliminate_dirichlet(M: sp.csr_matrix, dmask: np.ndarray, diag_value=1.0) -> 
     return M
 
 
+INNER_THREADS = None     # set by problem._pmap while it runs one generator call per host thread: threads each call may start itself
+
+
+def _native():
+    """libddm_hip.so's host-side generator (csrc/synth_host.hpp) unless DDM_SYNTH_NATIVE=0 asks for the numpy passes below (kept as
+    its checker: tests/test_synth_native.py compares the two bit for bit)."""
+    import os
+    if os.environ.get("DDM_SYNTH_NATIVE", "1") == "0":
+        return None
+    from . import load_library
+    return load_library()
+
+
+def q1_matrix_native(lib, dim, bshape, ke, eoff, inset, loc_of_box, n, box_index, dmask, diag) -> sp.csr_matrix:
+    """ddm_synth_q1_matrix (include/ddm_hip.h): Q1 matrix of the node box ``bshape`` (x first) from the element coefficients ``ke``
+    (array in C order, z/y/x axes; element (0,..,0) of it is the element ``eoff`` places before box node 0), rows = the ``n`` local
+    indices, pattern restricted to ``inset``, Dirichlet-eliminated."""
+    import ctypes
+    import os
+    i64, u8, f64 = np.int64, np.uint8, np.float64
+    c = np.ascontiguousarray
+    bs = c(bshape, dtype=i64)
+    ke = c(ke, dtype=f64)
+    es = c(ke.shape[::-1], dtype=i64)
+    eo = c(eoff, dtype=i64)
+    K = c(q1_element_matrix(dim), dtype=f64)
+    inset = None if inset is None else c(inset.reshape(-1), dtype=u8)
+    loc = None if loc_of_box is None else c(loc_of_box, dtype=i64)
+    bi = None if box_index is None else c(box_index, dtype=i64)
+    dm = c(dmask, dtype=u8)
+    dg = None if diag is None else c(np.broadcast_to(np.asarray(diag, dtype=f64), (n,)))
+    P = ctypes.c_void_p
+
+    def ptr(a):
+        return None if a is None else a.ctypes.data_as(P)
+
+    nt = INNER_THREADS or int(os.environ.get("DDM_HOST_THREADS", min(8, os.cpu_count() or 1)))
+    indptr = np.empty(n + 1, dtype=i64)
+    args = [dim, ptr(bs), ptr(ke), ptr(es), ptr(eo), ptr(K), ptr(inset), ptr(loc), n, ptr(bi), ptr(dm), ptr(dg)]
+    if lib.ddm_synth_q1_matrix(*args, ptr(indptr), None, None, nt) != 0:
+        raise RuntimeError("ddm_synth_q1_matrix: " + lib.ddm_last_error(None).decode())
+    indices = np.empty(int(indptr[-1]), dtype=np.int32)
+    data = np.empty(int(indptr[-1]), dtype=f64)
+    if lib.ddm_synth_q1_matrix(*args, ptr(indptr), ptr(indices), ptr(data), nt) != 0:
+        raise RuntimeError("ddm_synth_q1_matrix: " + lib.ddm_last_error(None).decode())
+    M = sp.csr_matrix((data, indices, indptr), shape=(n, n))
+    M.has_sorted_indices = True
+    return M
+
+
 @dataclass
 class NovlpSubdomain:
     """What one MPI rank holds after make_communication + assembly (non-overlapping)."""
@@ -242,11 +292,16 @@ class StructuredPoisson:
         lo, hi = self._node_box(r)
         nsl = self._box_slices(lo, hi)
         esl = tuple(slice(lo[d], hi[d]) for d in reversed(range(dim)))
-        S = assemble_stencil(self.kappa[esl], dim)
-        A = stencil_to_csr(S, dim)
         dmask = self.dirichlet_node[nsl].reshape(-1).astype(np.uint8)
         holders = self.holders[nsl].reshape(-1)
-        A = eliminate_dirichlet(A, dmask, 1.0 / holders)
+        lib = _native()
+        if lib is not None:
+            bshape = [hi[d] - lo[d] + 1 for d in range(dim)]
+            A = q1_matrix_native(lib, dim, bshape, self.kappa[esl], [0] * dim, None, None, len(dmask), None, dmask, 1.0 / holders)
+        else:
+            S = assemble_stencil(self.kappa[esl], dim)
+            A = stencil_to_csr(S, dim)
+            A = eliminate_dirichlet(A, dmask, 1.0 / holders)
         glob = self.gid_of_node[nsl].reshape(-1).copy()
         owner = (self.owner_rank[nsl].reshape(-1) == r).astype(np.uint8)
         public = (holders > 1).astype(np.uint8)
@@ -298,6 +353,7 @@ class StructuredPoisson:
         sel = np.ones(n, dtype=bool) if region is None else region.astype(bool)
         inset[box_index[sel]] = True
         inset = inset.reshape(bshape)
+        lib = _native()
         if neumann:
             ke = self.kappa[tuple(slice(lo[d], hi[d]) for d in reversed(range(dim)))].copy()
             allin = np.ones(ke.shape, dtype=bool)
@@ -305,12 +361,21 @@ class StructuredPoisson:
                 sl = tuple(slice((a >> (dim - 1 - ax)) & 1, ((a >> (dim - 1 - ax)) & 1) + ke.shape[ax]) for ax in range(dim))
                 allin &= inset[sl]
             ke[~allin] = 0.0
+            if lib is not None:
+                loc_of_box = np.full(nbox, -1, dtype=np.int64)
+                loc_of_box[box_index] = np.arange(n)
+                return q1_matrix_native(lib, dim, bshape[::-1], ke, [0] * dim, inset, loc_of_box, n, box_index, dirichlet_ovlp, None)
             S = assemble_stencil(ke, dim)
         else:
             # one extra element layer around the node box, clipped to the mesh
             elo = [max(lo[d] - 1, 0) for d in range(dim)]
             ehi = [min(hi[d] + 1, self.N[d] - 1) for d in range(dim)]
             ke = self.kappa[tuple(slice(elo[d], ehi[d]) for d in reversed(range(dim)))]
+            if lib is not None:
+                loc_of_box = np.full(nbox, -1, dtype=np.int64)
+                loc_of_box[box_index] = np.arange(n)
+                return q1_matrix_native(lib, dim, bshape[::-1], ke, [int(lo[d] - elo[d]) for d in range(dim)], inset, loc_of_box, n, box_index,
+                                        dirichlet_ovlp, None)
             Sbig = assemble_stencil(ke, dim)
             crop = tuple(slice(lo[d] - elo[d], lo[d] - elo[d] + (hi[d] - lo[d] + 1)) for d in reversed(range(dim)))
             S = np.ascontiguousarray(Sbig[(slice(None),) + crop])

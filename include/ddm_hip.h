@@ -45,7 +45,7 @@ typedef struct ddm_combined ddm_combined;
 /* One context per process/GPU.  stream == NULL: the library creates its own stream. */
 int ddm_ctx_create(int device, void *hip_stream, ddm_ctx **out);
 void ddm_ctx_destroy(ddm_ctx *ctx);
-const char *ddm_last_error(const ddm_ctx *ctx);
+const char *ddm_last_error(const ddm_ctx *ctx); /* ctx == NULL: the calling thread's last failure of a context-free entry point */
 int ddm_ctx_sync(ddm_ctx *ctx); /* hipStreamSynchronize */
 /* the host waits for the work enqueued on the context's stream so far (event record + wait; later work is not waited for):
  * what an exchange callback of a host-driven transport (MPI) calls before it touches the packed send buffer */
@@ -142,6 +142,11 @@ int ddm_ilu0_status(ddm_ctx *ctx, const ddm_ilu0 *F, int *status);
 int ddm_ilu0_peek_status(const ddm_ilu0 *F);
 /* engine the next ddm_ilu0_solve uses: 8 = pipe, 4 = xcd2 (also when pipe declined the matrix), 0 = one launch per level */
 int ddm_ilu0_engine(const ddm_ilu0 *F);
+/* ddm_ilu0_create returns while the schedule of the single-launch engine is still being built on host threads (2.6 s at 216^3; the
+ * first ddm_ilu0_solve waits for it, so does ddm_ilu0_engine).  ddm_ilu0_wait joins that work now and returns its error, so that a
+ * caller can account the whole setup before it starts its clock.  DDM_PIPE_ASYNC=0: everything inside ddm_ilu0_create.  The matrix
+ * handed to ddm_ilu0_create must stay alive as long as the factor (it always had to: the factor borrows its pattern). */
+int ddm_ilu0_wait(ddm_ctx *ctx, ddm_ilu0 *F);
 /* diagnostic: one solve with in-kernel cycle stamps of one compute wave */
 int ddm_ilu0_debug_stamps(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, unsigned long long *out6_host);
 /* diagnostic: one solve with the stamped build of the pipe engine's kernel (DDM_TRSV_MODE=pipe, the default); per task 272
@@ -428,6 +433,17 @@ void ddm_cg_end(ddm_ctx *ctx, ddm_cg *cg);
 int ddm_timing_enable(ddm_ctx *ctx, int on);
 int ddm_timing_get(ddm_ctx *ctx, const char *name, double *total_ms, int64_t *count);
 int ddm_timing_reset(ddm_ctx *ctx);
+
+/* ---- input synthesis (host only; no ddm_ctx, no device) ------------------------------------
+ * The Q1 diffusion matrix of a structured node box restricted to a node subset, in the caller's numbering, Dirichlet rows and columns
+ * eliminated symmetrically: the matrices the reference receives from PDELab's assembler (A of make_communication,
+ * A_dir / A_neu / B_neu of examples/pdelab_helper.hh:113-436) for the synthetic benchmark problem.  Row-by-row on host threads, bit for
+ * bit what dune_ddm_amd/synth.py builds with numpy.  All shapes x first.  Two calls: indices == NULL fills indptr[n + 1] (row pointers),
+ * the second call (same arguments, indptr kept) fills indices / data.  inset, loc_of_box, box_index, diag may be NULL (all nodes,
+ * identity numbering, unit Dirichlet diagonal). */
+int ddm_synth_q1_matrix(int dim, const int64_t *bshape, const double *ke, const int64_t *eshape, const int64_t *eoff, const double *K,
+                        const uint8_t *inset, const int64_t *loc_of_box, int64_t n, const int64_t *box_index, const uint8_t *dmask,
+                        const double *diag, int64_t *indptr, int32_t *indices, double *data, int nthreads);
 
 #ifdef __cplusplus
 }
