@@ -241,9 +241,11 @@ def main():
     if local_cnt > 0:
         avg_ms = local_ms / local_cnt
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        engine = os.environ.get("DDM_TRSV_MODE", "pipe") if args.local_solver == "ilu0" else "direct"
+        engine = tl.schwarz.engine() if args.local_solver == "ilu0" else "direct"
         kname = {"levels": "k_trsv_lower_level + k_trsv_upper_level + k_trsv_small_levels (one launch per level, HIP graph)",
-                 "xcd2": "k_trsv_xcd2", "direct": "sparse direct factor (sn_chol.hpp panel solves or CSR level solves)"}.get(engine, "k_trsv_pipe (+ k_pipe_permute_out)")
+                 "xcd2": "k_trsv_xcd2", "direct": "sparse direct factor (sn_chol.hpp panel solves or CSR level solves)",
+                 "box": "k_box_sweep<lower> + k_box_sweep<upper> (structured boxes of the subdomains) + k_trsv_pipe on the overlap shell rows (nested factor) + "
+                        "k_box_shell_rhs / k_box_products / k_box_shell_out"}.get(engine, "k_trsv_pipe (+ k_pipe_permute_out)")
         traffic, traffic_source = None, None
         try:   # HBM bytes per launch: NOT measured in this run -- read from the committed rocprofv3 --pmc passes of this command
             #    (profiles/, separate FETCH_SIZE / WRITE_SIZE runs, gfx950-corrected: 2 x FETCH_SIZE + WRITE_SIZE); the file is named in the line

@@ -545,10 +545,11 @@ class SchwarzPreconditioner:
     def num_levels(self):
         return (int(self.ctx.lib.ddm_schwarz_num_levels(self.h, 0)), int(self.ctx.lib.ddm_schwarz_num_levels(self.h, 1)))
 
-    ENGINES = {8: "pipe", 4: "xcd2", 0: "levels", 16: "supernodal"}
+    ENGINES = {8: "pipe", 4: "xcd2", 0: "levels", 16: "supernodal", 32: "box"}
 
     def engine(self):
-        """triangular-solve engine of the local solver: 'pipe', 'xcd2' (also when pipe declined the matrix), 'levels', or 'supernodal'
+        """triangular-solve engine of the local solver: 'box' (structured blocks: csrc/trsv_box.hpp), 'pipe', 'xcd2' (also when pipe declined
+        the matrix), 'levels', or 'supernodal'
         (sparse direct factor of the device engine: dense panels, csrc/sn_chol.hpp)"""
         return self.ENGINES[int(self.ctx.lib.ddm_schwarz_engine(self.h))]
 

@@ -4,6 +4,7 @@
 #include "host_vec.hpp"
 #include "kernels.hpp"
 #include "trsv_pipe.hpp"
+#include "trsv_box.hpp"
 #include "sparse_chol_host.hpp"
 #include "sn_chol.hpp"
 #include "synth_host.hpp"
@@ -848,6 +849,9 @@ struct ddm_ilu0 {
   std::thread pipe_builder;
   int pipe_builder_rc = DDM_OK;
   std::string pipe_builder_err;
+  // box engine (mode 32; trsv_box_host.hpp): structured leading box of every block + a nested factor for the rows behind it
+  struct BoxEngine *box = nullptr;
+  bool allow_box = true;        // (false for the nested shell factor and with DDM_TRSV_MODE=pipe)
   pipe::Group *p_groups = nullptr;
   pipe::Task *p_tasks = nullptr;
   unsigned char *p_stream = nullptr;
@@ -1334,7 +1338,29 @@ static void free_schedule(TriSchedule &S)
   (void)hipFree(S.d_desc);
 }
 
+struct BoxEngine {
+  int nblocks = 0;
+  int64_t nshell = 0, nprod = 0;
+  box::Block *blocks = nullptr;
+  box::StepTab *steps = nullptr;
+  double *stream = nullptr;
+  unsigned long long *einfo = nullptr;
+  double *E = nullptr, *ext_val = nullptr;
+  int32_t *ext_col = nullptr;
+  double *xs = nullptr;
+  unsigned long long *prog = nullptr;
+  unsigned *queue = nullptr;
+  // shell system
+  int64_t *srp = nullptr;
+  int32_t *sci = nullptr, *srow = nullptr;
+  double *sva = nullptr, *ds = nullptr, *xsol = nullptr;
+  ddm_csr *shell_csr = nullptr;
+  ddm_ilu0 *shell = nullptr;
+  int grid = 0;
+  box::Stats stats;
+};
 static int build_pipe_schedule(ddm_ctx *ctx, ddm_ilu0 *F);
+static int build_box_engine(ddm_ctx *ctx, ddm_ilu0 *F);
 // waits for the background part of the setup; its failure is reported by every call that needs the result
 static int ilu0_join(ddm_ctx *ctx, ddm_ilu0 *F)
 {
@@ -1368,7 +1394,10 @@ static int ilu0_build_engines(ddm_ctx *ctx, ddm_ilu0 *F, const ddm_csr *A, const
     F->L.nlev = F->Lc.nlev;
     F->U.nlev = F->Uc.nlev;
   }
-  if (const char *m = std::getenv("DDM_TRSV_MODE")) F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "xcd2") ? 4 : 8);
+  if (const char *m = std::getenv("DDM_TRSV_MODE")) {
+    F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "xcd2") ? 4 : 8);
+    if (!std::strcmp(m, "pipe")) F->allow_box = false;
+  }
   if (multi_rhs_only) F->mode = 0; // only ddm_ilu0_solve_multi will be called (level kernels): no pipe schedule, no tile stream
   F->A = A;
   F->h_diag = diag;
@@ -1385,7 +1414,9 @@ static int ilu0_build_engines(ddm_ctx *ctx, ddm_ilu0 *F, const ddm_csr *A, const
       pipe_started = true;
       F->pipe_builder = std::thread([ctx, F]() {
         (void)hipSetDevice(ctx->device);
-        F->pipe_builder_rc = build_pipe_schedule(ctx, F); // (not applicable: pipe_state < 0, see ddm_ilu0_solve)
+        int rcb = DDM_OK;
+        if (F->allow_box) rcb = build_box_engine(ctx, F);   // structured blocks: mode 32 (declined: F->box stays null, pipe takes the matrix)
+        F->pipe_builder_rc = rcb ? rcb : (F->box ? DDM_OK : build_pipe_schedule(ctx, F)); // (not applicable: pipe_state < 0, see ddm_ilu0_solve)
         if (F->pipe_builder_rc) F->pipe_builder_err = last_error_of_this_thread();
       });
     }
@@ -1405,7 +1436,10 @@ static int ilu0_build_engines(ddm_ctx *ctx, ddm_ilu0 *F, const ddm_csr *A, const
     if (hipHostMalloc((void **)&F->err, 128, hipHostMallocMapped) != hipSuccess) rc = fail(ctx, DDM_EHIP, "ILU(0): allocation failed");
     else std::memset(F->err, 0, 128);
   }
-  if (!rc && F->mode == 8 && F->n > 0 && !pipe_started) rc = build_pipe_schedule(ctx, F); // part of the setup, not of the first solve
+  if (!rc && F->mode == 8 && F->n > 0 && !pipe_started) { // part of the setup, not of the first solve
+    if (F->allow_box) rc = build_box_engine(ctx, F);
+    if (!rc && !F->box) rc = build_pipe_schedule(ctx, F);
+  }
   return rc;
 }
 static int ilu0_create_impl(ddm_ctx *ctx, const ddm_csr *A, int64_t nblocks, const int64_t *block_ptr, bool multi_rhs_only, ddm_ilu0 **out);
@@ -2005,6 +2039,14 @@ extern "C" void ddm_ilu0_destroy(ddm_ilu0 *F)
   (void)hipFree(F->xstate);
   (void)hipFree(F->xdperm);
   (void)hipFree(F->xlpos);
+  if (BoxEngine *X = F->box) {
+    ddm_ilu0_destroy(X->shell);
+    ddm_csr_destroy(X->shell_csr);
+    (void)hipFree(X->blocks); (void)hipFree(X->steps); (void)hipFree(X->stream); (void)hipFree(X->einfo); (void)hipFree(X->E);
+    (void)hipFree(X->ext_val); (void)hipFree(X->ext_col); (void)hipFree(X->xs); (void)hipFree(X->prog); (void)hipFree(X->queue);
+    (void)hipFree(X->srp); (void)hipFree(X->sci); (void)hipFree(X->srow); (void)hipFree(X->sva); (void)hipFree(X->ds); (void)hipFree(X->xsol);
+    delete X;
+  }
   (void)hipFree(F->p_groups);
   (void)hipFree(F->p_tasks);
   (void)hipFree(F->p_stream);
@@ -2041,6 +2083,7 @@ extern "C" int ddm_ilu0_engine(const ddm_ilu0 *F)
   if (!F) return -1;
   if (F->sn) return 16; // device supernodal factor (sn_chol.hpp)
   if (F->pipe_builder.joinable()) const_cast<ddm_ilu0 *>(F)->pipe_builder.join();   // (the answer depends on what the builder found)
+  if (F->box) return 32;
   return (F->mode == 8 && F->pipe_state < 0) ? 4 : F->mode;
 }
 extern "C" int ddm_ilu0_get_factors_host(ddm_ctx *ctx, const ddm_ilu0 *F, double *lu_host)
@@ -2260,6 +2303,147 @@ static void enqueue_pipe(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, 
   hipLaunchKernelGGL(k_pipe_permute_out, dim3(perm_grid(ctx, F->p_nposU)), dim3(PERM_WG), 0, ctx->stream, F->p_nposU, F->p_rowU, (const double *)F->p_xpos, x, scale, add);
 }
 
+// ---- box engine (trsv_box_host.hpp / trsv_box.hpp) ----
+static int ilu0_build_engines(ddm_ctx *ctx, ddm_ilu0 *F, const ddm_csr *A, const std::vector<int64_t> &diag, int64_t nblocks, const int64_t *block_ptr, bool multi_rhs_only);
+static int build_box_engine(ddm_ctx *ctx, ddm_ilu0 *F)
+{
+  const ddm_csr *A = F->A;
+  const int nb = (int)F->h_block_ptr.size() - 1;
+  const auto t0 = std::chrono::steady_clock::now();
+  box::Schedule S;
+  if (!box::build(A->nrows, A->h_rp.data(), A->h_ci.data(), F->h_lu.data(), F->h_diag.data(), nb, F->h_block_ptr.data(), S)) {
+    if (std::getenv("DDM_PIPE_VERBOSE")) std::fprintf(stderr, "[ddm] box engine not applicable: %s\n", S.error.c_str());
+    return DDM_OK;
+  }
+  BoxEngine *X = new BoxEngine;
+  X->nblocks = nb;
+  X->nshell = (int64_t)S.srow.size();
+  X->nprod = (int64_t)S.ext_val.size();
+  X->stats = S.stats;
+  auto bail = [&](int rc) {
+    F->box = X;           // (ddm_ilu0_destroy frees what was allocated)
+    return rc;
+  };
+  int rc = upload(ctx, S.blocks.data(), (int64_t)S.blocks.size(), &X->blocks);
+  if (!rc) rc = upload(ctx, S.steps.data(), (int64_t)S.steps.size(), &X->steps);
+  if (!rc) rc = upload(ctx, S.stream.data(), (int64_t)S.stream.size(), &X->stream);
+  if (!rc) rc = upload(ctx, (const unsigned long long *)S.einfo.data(), (int64_t)S.einfo.size(), &X->einfo);
+  if (!rc) rc = upload(ctx, S.ext_val.data(), X->nprod, &X->ext_val);
+  if (!rc) rc = upload(ctx, S.ext_col.data(), X->nprod, &X->ext_col);
+  if (!rc) rc = upload(ctx, S.srp.data(), (int64_t)S.srp.size(), &X->srp);
+  if (!rc) rc = upload(ctx, S.sci.data(), (int64_t)S.sci.size(), &X->sci);
+  if (!rc) rc = upload(ctx, S.sva.data(), (int64_t)S.sva.size(), &X->sva);
+  if (!rc) rc = upload(ctx, S.srow.data(), X->nshell, &X->srow);
+  if (rc) return bail(rc);
+  auto zalloc = [&](void **p, size_t bytes) {
+    bytes = std::max<size_t>(bytes, 8);
+    if (hipMalloc(p, bytes) != hipSuccess) return fail(ctx, DDM_EHIP, "box engine: allocation failed");
+    if (hipMemset(*p, 0, bytes) != hipSuccess) return fail(ctx, DDM_EHIP, "box engine: memset failed");
+    return DDM_OK;
+  };
+  rc = zalloc((void **)&X->E, sizeof(double) * (size_t)X->nprod);
+  if (!rc) rc = zalloc((void **)&X->xs, sizeof(double) * (size_t)S.xs_len);
+  if (!rc) rc = zalloc((void **)&X->prog, sizeof(unsigned long long) * (size_t)S.prog_len);
+  if (!rc) rc = zalloc((void **)&X->queue, sizeof(unsigned) * 32 * 2 * (size_t)nb);
+  if (!rc) rc = zalloc((void **)&X->ds, sizeof(double) * (size_t)X->nshell);
+  if (!rc) rc = zalloc((void **)&X->xsol, sizeof(double) * (size_t)X->nshell);
+  if (!rc && !F->xstate) rc = zalloc((void **)&F->xstate, sizeof(XcdState));
+  if (rc) return bail(rc);
+  if (X->nshell > 0) { // the rows behind the boxes: a factor object of their own with the general engines
+    rc = csr_create_impl(ctx, X->nshell, X->nshell, S.frp.data(), S.fci.data(), S.fva.data(), /*host_only=*/true, &X->shell_csr);
+    if (rc) return bail(rc);
+    ddm_ilu0 *G = new ddm_ilu0;
+    X->shell = G;
+    G->n = X->nshell;
+    G->nnz = (int64_t)S.fci.size();
+    G->allow_box = false;
+    hvec_copy(G->h_lu, S.fva.data(), S.fva.size());
+    rc = ilu0_build_engines(ctx, G, X->shell_csr, S.fdiag, nb, S.fblock_ptr.data(), /*level kernels only=*/std::getenv("DDM_BOX_SHELL_LEVELS") != nullptr);
+    if (rc) return bail(rc);
+  }
+  X->grid = 2 * (ctx->num_cu / 8 * 8);
+  if (const char *e = std::getenv("DDM_BOX_GRID")) X->grid = std::max(8, std::atoi(e) / 8 * 8);
+  F->box = X;
+  if (std::getenv("DDM_PIPE_VERBOSE")) {
+    const box::Block &B0 = S.blocks[0];
+    std::fprintf(stderr, "[ddm] box engine: %d blocks, box rows %lld (block 0: %d x %d x %d, %d steps per plane), rows behind the boxes %lld (nested factor: %lld entries), "
+                 "streams %.1f MB (%.2f B per factor entry of the boxes), shell products %lld, grid %d, built in %.2f s\n",
+                 nb, (long long)S.stats.box_rows, B0.nx, B0.ny, B0.nz, B0.nsteps, (long long)X->nshell, (long long)S.fci.size(), S.stats.stream_bytes / 1e6,
+                 (double)S.stats.stream_bytes / (27.0 * std::max<int64_t>(S.stats.box_rows, 1)), (long long)X->nprod, X->grid,
+                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  }
+  return DDM_OK;
+}
+static int enqueue_tri(ddm_ctx *ctx, const TriSchedule &S, bool upper, const double *d, double *x);
+static int build_xcd_schedule(ddm_ctx *ctx, ddm_ilu0 *F);
+// joins the background builders and settles which engine a factor uses (the single-vector solve and the box engine's nested factor)
+static int ilu0_prepare_engine(ddm_ctx *ctx, ddm_ilu0 *F)
+{
+  DDMCHECK(ilu0_join(ctx, F));
+  if (F->box) {
+    if (F->box->shell) DDMCHECK(ilu0_prepare_engine(ctx, F->box->shell));
+    return DDM_OK;
+  }
+  if (F->mode == 8 && F->pipe_state == 0) DDMCHECK(build_pipe_schedule(ctx, F));
+  if (F->mode == 8 && F->pipe_state < 0) F->mode = 4; // not applicable: the loader engine takes any matrix
+  if (F->mode == 4 && !F->xcd_built) DDMCHECK(build_xcd_schedule(ctx, F));
+  return DDM_OK;
+}
+static int enqueue_box(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, const double *scale, const double *add)
+{
+  BoxEngine *X = F->box;
+  BoxParams P;
+  P.nblocks = X->nblocks;
+  P.blocks = X->blocks;
+  P.steps = X->steps;
+  P.stream = X->stream;
+  P.einfo = X->einfo;
+  P.E = X->E;
+  P.xs = X->xs;
+  P.prog = X->prog;
+  P.queue = X->queue;
+  P.st = F->xstate;
+  P.err = F->err;
+  P.spread = 0;
+  if (const char *e = std::getenv("DDM_BOX_SPREAD")) P.spread = std::atoi(e);
+  // forward sweep of the boxes: y into x
+  P.rhs = d;
+  P.out = x;
+  P.scale = P.add = nullptr;
+  int dbg = 0;   // diagnostic: DDM_BOX_DEBUG bit mask switches phases off (1 forward boxes, 2 nested solve, 4 products, 8 backward boxes, 16 shell rhs / out)
+  if (const char *e = std::getenv("DDM_BOX_DEBUG")) dbg = std::atoi(e);
+  hipLaunchKernelGGL(k_pipe_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate, X->queue, X->nblocks * 2);
+  if (!(dbg & 1)) hipLaunchKernelGGL((k_box_sweep<false>), dim3(X->grid), dim3(BOX_WG), 0, ctx->stream, P);
+  if (X->nshell > 0 && !(dbg & 2)) {
+    ddm_ilu0 *G = X->shell;
+    if (!(dbg & 16))
+      hipLaunchKernelGGL(k_box_shell_rhs, dim3(grid_for(X->nshell)), dim3(WG), 0, ctx->stream, X->nshell, (const int64_t *)X->srp, (const int32_t *)X->sci, (const double *)X->sva,
+                         (const int32_t *)X->srow, d, (const double *)x, X->ds);
+    if (G->mode == 8) enqueue_pipe(ctx, G, X->ds, X->xsol, nullptr);
+    else if (G->mode == 4) {
+      hipLaunchKernelGGL(k_trsv_xcd_prologue, dim3(1), dim3(64), 0, ctx->stream, G->xstate);
+      hipLaunchKernelGGL(k_w_permute_in, dim3(grid_for(G->n)), dim3(WG), 0, ctx->stream, G->n, G->xlpos, G->xrows, (const double *)X->ds, G->xdperm);
+      hipLaunchKernelGGL(k_trsv_xcd2, dim3(persistent_grid(ctx)), dim3(64 * (1 + TRSV_L_LOADERS)), sizeof(TrsvLds), ctx->stream, G->ngroups, G->xg, G->xdesc, G->xflag_off,
+                         G->xrows, G->xcols, G->xvals, G->xdinv, G->xdperm, X->xsol, G->xflags, G->xstate, F->err, (unsigned long long *)nullptr);
+    } else {
+      DDMCHECK(enqueue_tri(ctx, G->L, false, X->ds, X->xsol));
+      DDMCHECK(enqueue_tri(ctx, G->U, true, X->ds, X->xsol));
+    }
+  }
+  // products of the box rows' shell entries, then the backward sweep of the boxes (with the level's tail) and the shell rows of x
+  if (!(dbg & 4))
+    hipLaunchKernelGGL(k_box_products, dim3(grid_for(X->nprod)), dim3(WG), 0, ctx->stream, X->nprod, (const double *)X->ext_val, (const int32_t *)X->ext_col, (const double *)X->xsol, X->E);
+  P.rhs = x;
+  P.scale = scale;
+  P.add = add;
+  hipLaunchKernelGGL(k_pipe_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate, X->queue, X->nblocks * 2);
+  if (!(dbg & 8)) hipLaunchKernelGGL((k_box_sweep<true>), dim3(X->grid), dim3(BOX_WG), 0, ctx->stream, P);
+  if (X->nshell > 0 && !(dbg & 16))
+    hipLaunchKernelGGL(k_box_shell_out, dim3(grid_for(X->nshell)), dim3(WG), 0, ctx->stream, X->nshell, (const int32_t *)X->srow, (const double *)X->xsol, x, scale, add);
+  HIPCHECK(ctx, hipGetLastError());
+  return DDM_OK;
+}
+
 static int enqueue_tri(ddm_ctx *ctx, const TriSchedule &S, bool upper, const double *d, double *x)
 {
   for (const auto &p : S.plan) {
@@ -2351,10 +2535,7 @@ static int ilu0_solve_epilogue(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, doubl
     F->graph = nullptr;
   }
   if (F->sn && !sn::reserve(*F->sn, 1)) return fail(ctx, DDM_EHIP, "sparse direct solver: allocation failed");
-  DDMCHECK(ilu0_join(ctx, F));
-  if (F->mode == 8 && F->pipe_state == 0) DDMCHECK(build_pipe_schedule(ctx, F));
-  if (F->mode == 8 && F->pipe_state < 0) F->mode = 4; // not applicable: the loader engine takes any matrix
-  if (F->mode == 4 && !F->xcd_built) DDMCHECK(build_xcd_schedule(ctx, F));
+  DDMCHECK(ilu0_prepare_engine(ctx, F));
   hipGraph_t g = nullptr;
   HIPCHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
   int rc = DDM_OK;
@@ -2378,7 +2559,10 @@ static int ilu0_solve_epilogue(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, doubl
     d = F->pd;
     x = F->px;
   }
-  if (F->mode == 8) {
+  if (F->box) {
+    epilogue_done = !F->perm;
+    rc = enqueue_box(ctx, F, d, x, epilogue_done ? scale : nullptr, epilogue_done ? add : nullptr);
+  } else if (F->mode == 8) {
     epilogue_done = !F->perm;
     enqueue_pipe(ctx, F, d, x, nullptr, epilogue_done ? scale : nullptr, epilogue_done ? add : nullptr);
   } else if (F->mode == 4) {

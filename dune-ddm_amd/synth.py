@@ -318,6 +318,34 @@ class StructuredPoisson:
     def subdomains(self):
         return [self.subdomain(r) for r in range(self.nranks)]
 
+    def elements(self, r):
+        """The rank's own elements as the grid operator visits them (x fastest): (dofs, Ke) with dofs[e, a] the local index (numbering
+        of subdomain(r)) of corner a (bit d of a = offset in direction d) and Ke[e] = kappa_e K, the raw element matrix -- what
+        `mat.container() - M_before` is in examples/assemblewrapper.hh:229.  Used by neumann_assembly.py."""
+        dim = self.dim
+        lo, hi = self._node_box(r)
+        nn = [hi[d] - lo[d] + 1 for d in range(dim)]                     # nodes per direction, x first
+        ne = [n - 1 for n in nn]
+        esl = tuple(slice(lo[d], hi[d]) for d in reversed(range(dim)))
+        kap = self.kappa[esl].reshape(-1)                                # C order: x fastest
+        eidx = np.arange(int(np.prod(ne)), dtype=np.int64)
+        base = np.zeros_like(eidx)
+        stride, rem = 1, eidx
+        for d in range(dim):
+            base += (rem % ne[d]) * stride
+            rem = rem // ne[d]
+            stride *= nn[d]
+        nc = 1 << dim
+        off = np.zeros(nc, dtype=np.int64)
+        for a in range(nc):
+            stride = 1
+            for d in range(dim):
+                off[a] += ((a >> d) & 1) * stride
+                stride *= nn[d]
+        dofs = base[:, None] + off[None, :]
+        Ke = kap[:, None, None] * q1_element_matrix(dim)[None, :, :]
+        return dofs, Ke
+
     # ---- element-wise Neumann matrices on an overlapping node set -------------------------
     def node_coords(self, glob: np.ndarray) -> np.ndarray:
         """(len, dim) integer node coordinates (x,y,z order) of global ids."""

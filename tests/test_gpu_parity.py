@@ -64,9 +64,10 @@ def test_csr_mv_usmv_random_and_edge_cases(ddm, torch_cuda):
     ctx.close()
 
 
-@pytest.mark.parametrize("trsv_mode", ["pipe", "xcd2", "levels"])
+@pytest.mark.parametrize("trsv_mode", ["box", "pipe", "xcd2", "levels"])
 def test_ilu0_factor_and_solve(ddm, torch_cuda, trsv_mode, monkeypatch):
-    """the three triangular-solve engines: pipe (default), xcd2 (fallback for matrices pipe declines), one launch per level"""
+    """the four triangular-solve engines: box (default where the blocks start with a structured box), pipe (any matrix), xcd2 (fallback
+    for matrices pipe declines), one launch per level"""
     monkeypatch.setenv("DDM_TRSV_MODE", trsv_mode)
     from dune_ddm_amd import synth
     from oracle import apply_oracle as ao
