@@ -93,6 +93,7 @@ SYMBOLS = {
     "ddm_ilu0_pipe_trace": (_I32, [_P, _P, _P, _P, _P, _P, _I64, ctypes.POINTER(ctypes.c_int64)]),
     "ddm_ilu0_num_levels": (_I64, [_P, _I32]),
     "ddm_ilu0_wait": (_I32, [_P, _P]),
+    "ddm_ilu0_box_check": (_I32, [_P, _P]),
     "ddm_ilu0_engine": (_I32, [_P]),
     "ddm_chol_create": (_I32, [_P, _P, _I64, _P, _D, _PP]),
     "ddm_ilu0_is_direct": (_I32, [_P]),
@@ -420,6 +421,12 @@ class Ilu0:
 
     def num_levels(self, upper=False):
         return int(self.ctx.lib.ddm_ilu0_num_levels(self.h, int(upper)))
+
+    def box_check(self):
+        """the eight words of the box engine's address check (DDM_BOX_CHECK=1): zeros when nothing was caught"""
+        out = np.zeros(8, dtype=np.uint64)
+        self.ctx.lib.ddm_ilu0_box_check(self.h, _hp(out))
+        return out
 
     def wait(self):
         """joins the part of the setup that runs in the background (ddm_ilu0_wait)"""

@@ -1350,6 +1350,8 @@ struct BoxEngine {
   double *xs = nullptr;
   unsigned long long *prog = nullptr;
   unsigned *queue = nullptr;
+  unsigned long long *dbg = nullptr;    // DDM_BOX_CHECK: pinned host words of the kernels' address check
+  int64_t n = 0, stream_len = 0, xs_len = 0, prog_len = 0, einfo_len = 0;
   // shell system
   int64_t *srp = nullptr;
   int32_t *sci = nullptr, *srow = nullptr;
@@ -1366,6 +1368,13 @@ static int ilu0_join(ddm_ctx *ctx, ddm_ilu0 *F)
 {
   if (F->pipe_builder.joinable()) F->pipe_builder.join();
   if (F->pipe_builder_rc) return fail(ctx, F->pipe_builder_rc, "%s", F->pipe_builder_err.c_str());
+  return DDM_OK;
+}
+// diagnostic: the eight words of the box engine's address check (DDM_BOX_CHECK=1), zeros when nothing was caught
+extern "C" int ddm_ilu0_box_check(const ddm_ilu0 *F, unsigned long long *out8)
+{
+  if (!F || !out8) return DDM_EINVAL;
+  for (int k = 0; k < 8; ++k) out8[k] = (F->box && F->box->dbg) ? F->box->dbg[k] : 0ull;
   return DDM_OK;
 }
 extern "C" int ddm_ilu0_wait(ddm_ctx *ctx, ddm_ilu0 *F) { return F ? ilu0_join(ctx, F) : fail(ctx, DDM_EINVAL, "ddm_ilu0_wait: bad arguments"); }
@@ -2044,6 +2053,7 @@ extern "C" void ddm_ilu0_destroy(ddm_ilu0 *F)
     ddm_csr_destroy(X->shell_csr);
     (void)hipFree(X->blocks); (void)hipFree(X->steps); (void)hipFree(X->stream); (void)hipFree(X->einfo); (void)hipFree(X->E);
     (void)hipFree(X->ext_val); (void)hipFree(X->ext_col); (void)hipFree(X->xs); (void)hipFree(X->prog); (void)hipFree(X->queue);
+    if (X->dbg) (void)hipHostFree(X->dbg);
     (void)hipFree(X->srp); (void)hipFree(X->sci); (void)hipFree(X->srow); (void)hipFree(X->sva); (void)hipFree(X->ds); (void)hipFree(X->xsol);
     delete X;
   }
@@ -2361,6 +2371,15 @@ static int build_box_engine(ddm_ctx *ctx, ddm_ilu0 *F)
     rc = ilu0_build_engines(ctx, G, X->shell_csr, S.fdiag, nb, S.fblock_ptr.data(), /*level kernels only=*/std::getenv("DDM_BOX_SHELL_LEVELS") != nullptr);
     if (rc) return bail(rc);
   }
+  X->n = A->nrows;
+  X->stream_len = (int64_t)S.stream.size();
+  X->xs_len = S.xs_len;
+  X->prog_len = S.prog_len;
+  X->einfo_len = (int64_t)S.einfo.size();
+  if (std::getenv("DDM_BOX_CHECK")) {
+    if (hipHostMalloc((void **)&X->dbg, 64, hipHostMallocMapped) != hipSuccess) return bail(fail(ctx, DDM_EHIP, "box engine: allocation failed"));
+    std::memset(X->dbg, 0, 64);
+  }
   X->grid = 2 * (ctx->num_cu / 8 * 8);
   if (const char *e = std::getenv("DDM_BOX_GRID")) X->grid = std::max(8, std::atoi(e) / 8 * 8);
   F->box = X;
@@ -2406,6 +2425,13 @@ static int enqueue_box(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, co
   P.err = F->err;
   P.spread = 0;
   if (const char *e = std::getenv("DDM_BOX_SPREAD")) P.spread = std::atoi(e);
+  P.dbg = X->dbg;
+  P.n = X->n;
+  P.stream_len = X->stream_len;
+  P.xs_len = X->xs_len;
+  P.prog_len = X->prog_len;
+  P.einfo_len = X->einfo_len;
+  P.e_len = X->nprod;
   // forward sweep of the boxes: y into x
   P.rhs = d;
   P.out = x;

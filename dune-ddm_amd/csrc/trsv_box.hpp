@@ -43,6 +43,10 @@ struct BoxParams {
   double *out;
   const double *scale, *add; // upper sweep: x = x * scale + add (either may be null)
   int spread;
+  // diagnostic (DDM_BOX_CHECK=1): every address of the sweep kernels is checked against its array; the first violation is recorded
+  // in dbg[0..7] = {site, offset, length, lane, step, plane, block, 0} and the access is redirected to the array's first element
+  unsigned long long *dbg;
+  int64_t n, stream_len, xs_len, prog_len, einfo_len, e_len;
 };
 
 typedef double bx_d2 __attribute__((ext_vector_type(2)));
@@ -56,6 +60,44 @@ __device__ __forceinline__ void bx_st8(double *p, double v) { asm volatile("glob
 __device__ __forceinline__ void bx_st8_sc1(double *p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void bx_st8u(unsigned long long *p, unsigned long long v) { asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void bx_st8u_sc1(unsigned long long *p, unsigned long long v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+
+// (compiled in with -DDDM_BOX_CHECK_BUILD only: the extra registers of the check make the compiler copy registers of loads in flight --
+// see the Makefile target check-box-isa -- so the checked build is for hunting a wild address, not for results)
+template <class T>
+__device__ __forceinline__ const T *bx_chk(const BoxParams &P, int site, const T *p, const T *base, int64_t len, int lane, int step, int plane, int block)
+{
+#ifndef DDM_BOX_CHECK_BUILD
+  return p;
+#endif
+  if (!P.dbg) return p;
+  const int64_t off = p - base;
+  if (off >= 0 && off < len) return p;
+  if (atomicCAS(P.dbg + 7, 0ull, 1ull) == 0ull) {
+    P.dbg[0] = (unsigned long long)site;
+    P.dbg[1] = (unsigned long long)off;
+    P.dbg[2] = (unsigned long long)len;
+    P.dbg[3] = (unsigned long long)lane;
+    P.dbg[4] = (unsigned long long)(long long)step;
+    P.dbg[5] = (unsigned long long)plane;
+    P.dbg[6] = (unsigned long long)block;
+  }
+  return base;
+}
+template <class T>
+__device__ __forceinline__ T *bx_chkw(const BoxParams &P, int site, T *p, T *base, int64_t len, int lane, int step, int plane, int block)
+{
+  return const_cast<T *>(bx_chk<T>(P, site, p, base, len, lane, step, plane, block));
+}
+
+// brings the cache line of p into the L2 without a destination register (LDS-DMA into a scrap area of the workgroup)
+__device__ __forceinline__ void bx_touch16(const void *p, unsigned char *scrap)
+{
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p, (__attribute__((address_space(3))) void *)scrap, 16, 0, 0);
+}
+__device__ __forceinline__ void bx_touch4(const void *p, unsigned char *scrap)
+{
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p, (__attribute__((address_space(3))) void *)scrap, 4, 0, 0);
+}
 
 // what one step requests two steps ahead
 template <bool UPPER>
@@ -116,6 +158,9 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
   __shared__ unsigned sh_xcc, sh_xt, sh_gt, sh_fail, sh_q;
   __shared__ int sh_step;
   __shared__ box::StepTab sh_tab[BOX_MAX_STEPS + 1];
+  // the prefetch wave's loads are LDS-DMA into this scrap area: a load into registers nobody reads would land, when it returns, in
+  // registers the compiler has given to something else by then (an address of a later load: found the hard way)
+  __shared__ __attribute__((aligned(16))) unsigned char sh_scrap[1024];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   XcdState *st = P.st;
@@ -138,10 +183,12 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
   }
   __syncthreads();
   if (sh_fail) return;
+  const int dmode = P.spread >> 4;     // diagnostic (DDM_BOX_SPREAD = 16 * mode): 1 leave here, 2 tickets and tables only, 3 no compute wave, 4 no prefetch wave
+  if (dmode == 1) return;
   const unsigned xcc = sh_xcc, xt = sh_xt;
   const unsigned epoch = __hip_atomic_load(&st->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned tk = lane < 8 ? __hip_atomic_load(&st->tickets[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
-  const bool local_ok = !P.spread && __all(lane >= min(P.nblocks, 8) || tk >= 1u);
+  const bool local_ok = !(P.spread & 15) && __all(lane >= min(P.nblocks, 8) || tk >= 1u);
   const bool wt = !local_ok;
   const int gfirst = local_ok ? (int)xcc : (int)(sh_gt % (unsigned)P.nblocks);
   const int gcount = local_ok ? ((int)xcc < P.nblocks ? (P.nblocks - (int)xcc + 7) / 8 : 0) : P.nblocks;
@@ -185,7 +232,13 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
         return r0 + i + (int64_t)nx * (j + (int64_t)ny * ktrue);
       };
 
-      if (wave == 1) {
+      if (dmode == 2 || (dmode == 3 && wave == 0) || (dmode == 4 && wave == 1)) {
+        if (wave == 0 && lane == 0) {     // (the plane counts as done, so that nobody waits for it)
+          const unsigned long long w = ((unsigned long long)epoch << 32) | (unsigned)nsteps;
+          __hip_atomic_store(progK, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&sh_step, 1 << 30, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      } else if (wave == 1) {
         // ---------------- prefetch wave: brings what step s needs into the L2 ----------------
         for (int s = 0; s < nsteps; ++s) {
           unsigned spins = 0;
@@ -196,20 +249,15 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
           const box::StepTab ts = T[s];
           const double *tile = plane + (int64_t)ts.off * box::NV;
           const int tile_d = ts.nact * box::NV;       // doubles
-          bx_d2 junk;
           for (int o = 0; o < tile_d; o += 128) {     // 1 KiB per wavefront load
             const int e = min(o + 2 * lane, tile_d - 2);
-            bx_ld16(junk, tile + e);
+            bx_touch16(bx_chk(P, 1, tile + e, P.stream, P.stream_len - 1, lane, s, K, g), sh_scrap);
           }
           int J, I;
           line_of(s, J, I);
           const bool act = I >= 0 && I < nx;
-          double junk8;
-          bx_ld8(junk8, P.rhs + (act ? row_of(I, J) : r0));
-          if (UPPER) {
-            unsigned long long ju;
-            bx_ld8u(ju, einfoK + (int64_t)s * 64 + lane);
-          }
+          bx_touch4(bx_chk(P, 2, P.rhs + (act ? row_of(I, J) : r0), P.rhs, P.n, lane, s, K, g), sh_scrap);
+          if (UPPER) bx_touch4(bx_chk(P, 3, einfoK + (int64_t)s * 64 + lane, P.einfo, P.einfo_len, lane, s, K, g), sh_scrap);
           asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -222,8 +270,9 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
         auto publish = [&](int steps) __attribute__((always_inline)) {
           if (lane == 0) {
             const unsigned long long w = ((unsigned long long)epoch << 32) | (unsigned)steps;
-            if (wt) bx_st8u_sc1(progK, w);
-            else bx_st8u(progK, w);
+            unsigned long long *pk = bx_chkw(P, 4, progK, P.prog, P.prog_len, lane, steps, K, g);
+            if (wt) bx_st8u_sc1(pk, w);
+            else bx_st8u(pk, w);
           }
         };
         // requests of step s into set S (the same number of vector-memory operations whatever s is)
@@ -237,23 +286,23 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
           const double *tile = plane + (int64_t)ts.off * box::NV + 2 * a;
           const int qs = 2 * ts.nact;
 #pragma unroll
-          for (int q = 0; q < 7; ++q) bx_ld16(S.t[q], tile + q * qs);
+          for (int q = 0; q < 7; ++q) bx_ld16(S.t[q], bx_chk(P, 5, tile + q * qs, P.stream, P.stream_len - 1, lane, s, K, g));
           // previous plane: column I + 1 of the lines J - 1, J, J + 1 = its steps s - 1, s + 1, s + 3, lanes lane - 1, lane, lane + 1
           const int l0 = min(max(s - 1, 0), nsteps - 1), l1 = min(s + 1, nsteps - 1), l2 = min(s + 3, nsteps - 1);
-          bx_ld8_sc1(S.r0, xsP + (int64_t)l0 * 64 + ((lane + 63) & 63));
-          bx_ld8_sc1(S.r1, xsP + (int64_t)l1 * 64 + lane);
-          bx_ld8_sc1(S.r2, xsP + (int64_t)l2 * 64 + ((lane + 1) & 63));
-          bx_ld8(S.rh, P.rhs + (act ? row_of(I, J) : r0));
-          bx_ld8u_sc1(S.pl, progP);
+          bx_ld8_sc1(S.r0, bx_chk(P, 6, xsP + (int64_t)l0 * 64 + ((lane + 63) & 63), (const double *)P.xs, P.xs_len, lane, s, K, g));
+          bx_ld8_sc1(S.r1, bx_chk(P, 7, xsP + (int64_t)l1 * 64 + lane, (const double *)P.xs, P.xs_len, lane, s, K, g));
+          bx_ld8_sc1(S.r2, bx_chk(P, 8, xsP + (int64_t)l2 * 64 + ((lane + 1) & 63), (const double *)P.xs, P.xs_len, lane, s, K, g));
+          bx_ld8(S.rh, bx_chk(P, 9, P.rhs + (act ? row_of(I, J) : r0), P.rhs, P.n, lane, s, K, g));
+          bx_ld8u_sc1(S.pl, bx_chk(P, 10, progP, (const unsigned long long *)P.prog, P.prog_len, lane, s, K, g));
           if constexpr (UPPER) {
             const int s2 = min(s + 2, nsteps - 1);
             const unsigned ptr = (unsigned)ei_now, cnt = (unsigned)(ei_now >> 32);
-            bx_ld8u(S.ei, einfoK + (int64_t)s2 * 64 + lane);
+            bx_ld8u(S.ei, bx_chk(P, 11, einfoK + (int64_t)s2 * 64 + lane, P.einfo, P.einfo_len, lane, s, K, g));
             const int64_t rr = act ? row_of(I, J) : r0;
-            bx_ld8(S.sc, (P.scale ? P.scale : P.rhs) + rr);
-            bx_ld8(S.ad, (P.add ? P.add : P.rhs) + rr);
+            bx_ld8(S.sc, bx_chk(P, 12, (P.scale ? P.scale : P.rhs) + rr, P.scale ? P.scale : P.rhs, P.n, lane, s, K, g));
+            bx_ld8(S.ad, bx_chk(P, 13, (P.add ? P.add : P.rhs) + rr, P.add ? P.add : P.rhs, P.n, lane, s, K, g));
 #pragma unroll
-            for (int q = 0; q < BOX_NEL; ++q) bx_ld16(S.ep[q], P.E + ((unsigned)(2 * q) < cnt ? ptr + 2 * q : 0u));
+            for (int q = 0; q < BOX_NEL; ++q) bx_ld16(S.ep[q], bx_chk(P, 14, P.E + ((unsigned)(2 * q) < cnt ? ptr + 2 * q : 0u), P.E, P.e_len - 1, lane, s, K, g));
           }
         };
         // waits until the previous plane has published `need` steps (bounded)
@@ -264,7 +313,7 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
           unsigned spins = 0;
           while (have < need) {
             unsigned long long w;
-            bx_ld8u_sc1(w, progP);
+            bx_ld8u_sc1(w, bx_chk(P, 15, progP, (const unsigned long long *)P.prog, P.prog_len, lane, need, K, g));
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(w)::"memory");
             have = __builtin_amdgcn_readfirstlane(count_of(w));
             if (++spins > BOX_SPIN_LIMIT) {
@@ -311,7 +360,7 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
           xprev = xnew;
           ring[l & 1][lane] = xnew;
           // results: position-ordered for the next plane, natural order for the caller (inactive lanes store to a scratch slot)
-          double *xp = xsK + (int64_t)max(l, 0) * 64 + lane;   // (step -1 has no active row: its zeros are overwritten by step 0)
+          double *xp = bx_chkw(P, 16, xsK + (int64_t)max(l, 0) * 64 + lane, P.xs, P.xs_len, lane, l, K, g);   // (step -1 has no active row: its zeros are overwritten by step 0)
           if (wt) bx_st8_sc1(xp, xnew);
           else bx_st8(xp, xnew);
           const int64_t row = act ? row_of(I, J) : -1;
@@ -320,13 +369,13 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
             if (P.scale) o *= S.sc;
             if (P.add) o += S.ad;
           }
-          bx_st8(act ? P.out + row : xp, o);
+          bx_st8(act ? bx_chkw(P, 17, P.out + row, P.out, P.n, lane, l, K, g) : xp, o);
         };
 
         // head: the product descriptor of step 0, then the requests of steps -1 and 0
         unsigned long long e0 = 0;
         if constexpr (UPPER) {
-          bx_ld8u(e0, einfoK + lane);
+          bx_ld8u(e0, bx_chk(P, 18, einfoK + lane, P.einfo, P.einfo_len, lane, -1, K, g));
           asm volatile("s_waitcnt vmcnt(0)" : "+v"(e0)::"memory");
         }
         // the walk starts at step -1: the run-in of line 0 (column 0 of the previous plane's lines 0 and 1)

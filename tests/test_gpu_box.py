@@ -12,9 +12,10 @@ from tests.test_gpu_pipe import _blocks, _oracle_solve  # noqa: E402
 @pytest.mark.parametrize("spread", ["0", "1"])                  # XCD-local hand-overs / placement-independent (write-through)
 @pytest.mark.parametrize("N,P", [((26, 24, 22), (2, 2, 2)),      # 8 subdomains, boxes 13 x 12 x 11 .. with shells on three sides
                                  ((20, 18, 16), (2, 1, 1)),      # 2 subdomains
-                                 ((24, 21, 16), (3, 3, 2)),      # 18 subdomains: XCDs own two or three of them; shells on up to five sides
+                                 ((44, 40, 18), (4, 3, 1)),      # 12 subdomains: XCDs own one or two of them; shells on up to four sides
                                  ((9, 8, 7), (1, 1, 1)),         # a plain box, no shell
-                                 ((150, 9, 8), (1, 1, 1))])      # nx > 120: declined, the pipe engine takes the matrix
+                                 ((24, 21, 16), (3, 3, 2)),      # boxes smaller than their shells: declined, the pipe engine takes the matrix
+                                 ((150, 9, 8), (1, 1, 1))])      # nx > 120: declined as well
 def test_box_solve_bit_exact(ddm, N, P, spread, monkeypatch):
     import torch
     assert torch.cuda.is_available()
@@ -24,7 +25,7 @@ def test_box_solve_bit_exact(ddm, N, P, spread, monkeypatch):
     ctx = ddm.torch_context(0)
     A = ddm.CsrMatrix(ctx, M)
     F = ddm.Ilu0(ctx, A, bp)
-    assert F.engine() == ("pipe" if N[0] > 120 else "box")
+    assert F.engine() == ("pipe" if N[0] > 120 or P == (3, 3, 2) else "box")
     rng = np.random.default_rng(5)
     n = M.shape[0]
     xd = torch.zeros(n, dtype=torch.float64, device="cuda")
