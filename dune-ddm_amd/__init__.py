@@ -423,10 +423,11 @@ class Ilu0:
         return int(self.ctx.lib.ddm_ilu0_num_levels(self.h, int(upper)))
 
     def box_check(self):
-        """the eight words of the box engine's address check (DDM_BOX_CHECK=1): zeros when nothing was caught"""
-        out = np.zeros(8, dtype=np.uint64)
+        """stamps of the box engine's last solve (DDM_BOX_CHECK=1 at creation): [sweep][plane of block 0] = (start, end in 10 ns ticks,
+        polls of the previous plane's progress word, XCC id)"""
+        out = np.zeros(1024, dtype=np.uint64)
         self.ctx.lib.ddm_ilu0_box_check(self.h, _hp(out))
-        return out
+        return out.reshape(2, 128, 4)
 
     def wait(self):
         """joins the part of the setup that runs in the background (ddm_ilu0_wait)"""

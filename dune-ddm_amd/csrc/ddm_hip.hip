@@ -851,7 +851,7 @@ struct ddm_ilu0 {
   std::string pipe_builder_err;
   // box engine (mode 32; trsv_box_host.hpp): structured leading box of every block + a nested factor for the rows behind it
   struct BoxEngine *box = nullptr;
-  bool allow_box = true;        // (false for the nested shell factor and with DDM_TRSV_MODE=pipe)
+  bool allow_box = true;        // (false for the nested shell factor and unless DDM_TRSV_MODE=box asks for the engine)
   pipe::Group *p_groups = nullptr;
   pipe::Task *p_tasks = nullptr;
   unsigned char *p_stream = nullptr;
@@ -1370,11 +1370,12 @@ static int ilu0_join(ddm_ctx *ctx, ddm_ilu0 *F)
   if (F->pipe_builder_rc) return fail(ctx, F->pipe_builder_rc, "%s", F->pipe_builder_err.c_str());
   return DDM_OK;
 }
-// diagnostic: the eight words of the box engine's address check (DDM_BOX_CHECK=1), zeros when nothing was caught
-extern "C" int ddm_ilu0_box_check(const ddm_ilu0 *F, unsigned long long *out8)
+// diagnostic: the stamps of the box engine's last solve (DDM_BOX_CHECK=1 at creation): out[2][128][4] = per sweep and plane of block 0
+// {start, end (100 MHz clock), polls of the previous plane's progress word, XCC}; zeros without the switch
+extern "C" int ddm_ilu0_box_check(const ddm_ilu0 *F, unsigned long long *out1024)
 {
-  if (!F || !out8) return DDM_EINVAL;
-  for (int k = 0; k < 8; ++k) out8[k] = (F->box && F->box->dbg) ? F->box->dbg[k] : 0ull;
+  if (!F || !out1024) return DDM_EINVAL;
+  for (int k = 0; k < 1024; ++k) out1024[k] = (F->box && F->box->dbg) ? F->box->dbg[k] : 0ull;
   return DDM_OK;
 }
 extern "C" int ddm_ilu0_wait(ddm_ctx *ctx, ddm_ilu0 *F) { return F ? ilu0_join(ctx, F) : fail(ctx, DDM_EINVAL, "ddm_ilu0_wait: bad arguments"); }
@@ -1403,10 +1404,14 @@ static int ilu0_build_engines(ddm_ctx *ctx, ddm_ilu0 *F, const ddm_csr *A, const
     F->L.nlev = F->Lc.nlev;
     F->U.nlev = F->Uc.nlev;
   }
+  // the box engine (structured blocks, trsv_box.hpp) is opt-in: bit-exact, but at the benchmark's size still slower than pipe (4.4 against
+  // 3.25 ms per solve: DESIGN.md section 3d says what bounds it and what is missing)
+  bool want_box = false;
   if (const char *m = std::getenv("DDM_TRSV_MODE")) {
     F->mode = !std::strcmp(m, "levels") ? 0 : (!std::strcmp(m, "xcd2") ? 4 : 8);
-    if (!std::strcmp(m, "pipe")) F->allow_box = false;
+    want_box = !std::strcmp(m, "box");
   }
+  if (!want_box) F->allow_box = false;
   if (multi_rhs_only) F->mode = 0; // only ddm_ilu0_solve_multi will be called (level kernels): no pipe schedule, no tile stream
   F->A = A;
   F->h_diag = diag;
@@ -2377,8 +2382,8 @@ static int build_box_engine(ddm_ctx *ctx, ddm_ilu0 *F)
   X->prog_len = S.prog_len;
   X->einfo_len = (int64_t)S.einfo.size();
   if (std::getenv("DDM_BOX_CHECK")) {
-    if (hipHostMalloc((void **)&X->dbg, 64, hipHostMallocMapped) != hipSuccess) return bail(fail(ctx, DDM_EHIP, "box engine: allocation failed"));
-    std::memset(X->dbg, 0, 64);
+    if (hipHostMalloc((void **)&X->dbg, 8192, hipHostMallocMapped) != hipSuccess) return bail(fail(ctx, DDM_EHIP, "box engine: allocation failed"));
+    std::memset(X->dbg, 0, 8192);
   }
   X->grid = 2 * (ctx->num_cu / 8 * 8);
   if (const char *e = std::getenv("DDM_BOX_GRID")) X->grid = std::max(8, std::atoi(e) / 8 * 8);

@@ -6,9 +6,10 @@
 //     * operands of the own plane: x(I-1, J) is the lane's previous result (register); the line J-1 is the neighbour lane's line -- its
 //       newest value comes out of a two-slot LDS ring, the two older ones were read in the steps before (register window);
 //     * operands of plane K-1: three register windows (lines J-1, J, J+1), one new column per step, read from the plane's
-//       position-ordered results xs[K-1][step][lane] with sc1 loads TWO steps ahead (guarded by the plane's progress word);
+//       position-ordered results xs[K-1][step][lane] with sc1 loads THREE steps ahead (guarded by the plane's progress word);
 //     * the row's 14 stream values (7 sixteen-byte loads), its right-hand side entry, (backward) its products with the shell and the
-//       product slice of the step after next: all requested two steps ahead, every step issues the same number of vector-memory
+//       product descriptor of three steps later: all requested three steps ahead (three register sets, the step loop is unrolled
+//       three times; the products travel by LDS-DMA into a four-slot ring), every step issues the same number of vector-memory
 //       operations, so one s_waitcnt vmcnt(N) with a constant N is the hand-over between the steps (vmcnt retires in issue order);
 //     * row sum in ascending column order, every product rounded before it is subtracted (-ffp-contract=off): the sequential solve.
 //   prefetch wave: touches the stream tiles, right-hand side lines and product descriptors BOX_AHEAD steps ahead of the compute wave, so
@@ -23,7 +24,9 @@ namespace ddm {
 
 constexpr int BOX_WG = 128;
 constexpr int BOX_NEL = box::MAX_EXT / 2;   // two-double loads of products per row
-constexpr int BOX_AHEAD = 6;                // steps the prefetch wave runs ahead of the compute wave
+constexpr int BOX_AHEAD = 8;                // steps the prefetch wave runs ahead of the compute wave
+constexpr int BOX_DIST = 3;                 // steps between a request and its use (three register sets, the step loop is unrolled three times)
+constexpr int BOX_ESLOT = BOX_NEL * 1024;   // bytes of one step's products in LDS: [q][lane] 16 bytes
 constexpr unsigned BOX_SPIN_LIMIT = 1u << 24;
 constexpr int BOX_MAX_STEPS = box::MAX_STEPS;  // the block's step table sits in LDS (a table in global memory would be read with vector loads: a full drain per step)
 
@@ -43,8 +46,8 @@ struct BoxParams {
   double *out;
   const double *scale, *add; // upper sweep: x = x * scale + add (either may be null)
   int spread;
-  // diagnostic (DDM_BOX_CHECK=1): every address of the sweep kernels is checked against its array; the first violation is recorded
-  // in dbg[0..7] = {site, offset, length, lane, step, plane, block, 0} and the access is redirected to the array's first element
+  // diagnostic (DDM_BOX_CHECK=1): per plane of block 0 and sweep four words {start, end (100 MHz clock), polls of the previous
+  // plane's progress word, XCC}: dbg[(sweep * 128 + plane) * 4 ..]
   unsigned long long *dbg;
   int64_t n, stream_len, xs_len, prog_len, einfo_len, e_len;
 };
@@ -60,34 +63,22 @@ __device__ __forceinline__ void bx_st8(double *p, double v) { asm volatile("glob
 __device__ __forceinline__ void bx_st8_sc1(double *p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void bx_st8u(unsigned long long *p, unsigned long long v) { asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void bx_st8u_sc1(unsigned long long *p, unsigned long long v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
-
-// (compiled in with -DDDM_BOX_CHECK_BUILD only: the extra registers of the check make the compiler copy registers of loads in flight --
-// see the Makefile target check-box-isa -- so the checked build is for hunting a wild address, not for results)
+// the same with a wave-uniform base (SGPR pair) and a 32-bit byte offset per lane: one address register instead of two and no 64-bit
+// address arithmetic per load -- the sweep kernels hold three sets of requests in registers
 template <class T>
-__device__ __forceinline__ const T *bx_chk(const BoxParams &P, int site, const T *p, const T *base, int64_t len, int lane, int step, int plane, int block)
+__device__ __forceinline__ const T *bx_uni(const T *p)
 {
-#ifndef DDM_BOX_CHECK_BUILD
-  return p;
-#endif
-  if (!P.dbg) return p;
-  const int64_t off = p - base;
-  if (off >= 0 && off < len) return p;
-  if (atomicCAS(P.dbg + 7, 0ull, 1ull) == 0ull) {
-    P.dbg[0] = (unsigned long long)site;
-    P.dbg[1] = (unsigned long long)off;
-    P.dbg[2] = (unsigned long long)len;
-    P.dbg[3] = (unsigned long long)lane;
-    P.dbg[4] = (unsigned long long)(long long)step;
-    P.dbg[5] = (unsigned long long)plane;
-    P.dbg[6] = (unsigned long long)block;
-  }
-  return base;
+  const unsigned long long u = (unsigned long long)(uintptr_t)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+  return (const T *)(uintptr_t)(((unsigned long long)hi << 32) | lo);
 }
-template <class T>
-__device__ __forceinline__ T *bx_chkw(const BoxParams &P, int site, T *p, T *base, int64_t len, int lane, int step, int plane, int block)
-{
-  return const_cast<T *>(bx_chk<T>(P, site, p, base, len, lane, step, plane, block));
-}
+__device__ __forceinline__ void bx_ld16o(bx_d2 &v, const void *base, unsigned off) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory"); }
+__device__ __forceinline__ void bx_ld8o(double &v, const void *base, unsigned off) { asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory"); }
+__device__ __forceinline__ void bx_ld8o_sc1(double &v, const void *base, unsigned off) { asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=v"(v) : "v"(off), "s"(base) : "memory"); }
+__device__ __forceinline__ void bx_ld8uo(unsigned long long &v, const void *base, unsigned off) { asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory"); }
+__device__ __forceinline__ void bx_ld8uo_sc1(unsigned long long &v, const void *base, unsigned off) { asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=v"(v) : "v"(off), "s"(base) : "memory"); }
+__device__ __forceinline__ void bx_st8o(void *base, unsigned off, double v) { asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(off), "v"(v), "s"(base) : "memory"); }
+__device__ __forceinline__ void bx_st8o_sc1(void *base, unsigned off, double v) { asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(base) : "memory"); }
 
 // brings the cache line of p into the L2 without a destination register (LDS-DMA into a scrap area of the workgroup)
 __device__ __forceinline__ void bx_touch16(const void *p, unsigned char *scrap)
@@ -99,25 +90,29 @@ __device__ __forceinline__ void bx_touch4(const void *p, unsigned char *scrap)
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p, (__attribute__((address_space(3))) void *)scrap, 4, 0, 0);
 }
 
-// what one step requests two steps ahead
+// LDS-DMA the compiler does not know about (16 bytes per lane to lds_byte_address + 16 lane): with the builtin the compiler drains the
+// whole vector-memory queue (s_waitcnt vmcnt(0)) in front of the first LDS read that might alias the destination -- once per step
+__device__ __forceinline__ void bx_dma16(const void *base, unsigned off, unsigned lds_byte_address)
+{
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_byte_address) : "memory");   // (m0 is written here; the compiler sets it itself in front of each of its own uses)
+}
+
+// what one step requests BOX_DIST steps ahead
 template <bool UPPER>
 struct BoxSet {
   bx_d2 t[7];
   double r0, r1, r2, rh;
-  unsigned long long pl, ei;
+  unsigned long long ei;
   double sc, ad;       // backward sweep: the row's scale / add entries of the level's tail
-  bx_d2 ep[UPPER ? BOX_NEL : 1];
-};
+};   // (the row's shell products of the backward sweep travel by LDS-DMA into a ring of BOX_DIST + 1 slots: 40 registers per set less)
 // the compiler must not move uses of the registers in front of the wait that makes them valid
 template <bool UPPER>
 __device__ __forceinline__ void bx_tie(BoxSet<UPPER> &S)
 {
   asm volatile("" : "+v"(S.t[0]), "+v"(S.t[1]), "+v"(S.t[2]), "+v"(S.t[3]), "+v"(S.t[4]), "+v"(S.t[5]), "+v"(S.t[6]));
-  asm volatile("" : "+v"(S.r0), "+v"(S.r1), "+v"(S.r2), "+v"(S.rh), "+v"(S.pl), "+v"(S.ei));
+  asm volatile("" : "+v"(S.r0), "+v"(S.r1), "+v"(S.r2), "+v"(S.rh), "+v"(S.ei));
   if constexpr (UPPER) {
     asm volatile("" : "+v"(S.sc), "+v"(S.ad));
-    asm volatile("" : "+v"(S.ep[0]), "+v"(S.ep[1]), "+v"(S.ep[2]), "+v"(S.ep[3]), "+v"(S.ep[4]));
-    asm volatile("" : "+v"(S.ep[5]), "+v"(S.ep[6]), "+v"(S.ep[7]), "+v"(S.ep[8]), "+v"(S.ep[9]));
   }
 }
 
@@ -157,10 +152,12 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
   __shared__ double ring[2][64];
   __shared__ unsigned sh_xcc, sh_xt, sh_gt, sh_fail, sh_q;
   __shared__ int sh_step;
+  __shared__ int sh_prev;   // steps the previous plane has published, as last seen by the prefetch wave (the compute wave never polls memory)
   __shared__ box::StepTab sh_tab[BOX_MAX_STEPS + 1];
   // the prefetch wave's loads are LDS-DMA into this scrap area: a load into registers nobody reads would land, when it returns, in
   // registers the compiler has given to something else by then (an address of a later load: found the hard way)
   __shared__ __attribute__((aligned(16))) unsigned char sh_scrap[1024];
+  __shared__ __attribute__((aligned(16))) unsigned char sh_E[UPPER ? (BOX_DIST + 1) * BOX_ESLOT : 16];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   XcdState *st = P.st;
@@ -206,6 +203,7 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
       if (threadIdx.x == 0) {
         sh_q = __hip_atomic_fetch_add(P.queue + (size_t)(2 * g + sweep) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sh_step = -2;
+        sh_prev = 0;
       }
       __syncthreads();
       const int K = __builtin_amdgcn_readfirstlane((int)sh_q);
@@ -213,13 +211,15 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
         __syncthreads();
         break;
       }
-      const double *plane = P.stream + B->stream_off[sweep] + (int64_t)K * B->plane_len[sweep];
-      double *xsK = P.xs + B->xs_off + (int64_t)K * nsteps * 64;
-      const double *xsP = K > 0 ? xsK - (int64_t)nsteps * 64 : xsK;
-      unsigned long long *progK = P.prog + B->prog_off + (int64_t)sweep * nz + K;
+      const double *plane = bx_uni(P.stream + B->stream_off[sweep] + (int64_t)K * B->plane_len[sweep]);
+      double *xsK = const_cast<double *>(bx_uni((const double *)(P.xs + B->xs_off + (int64_t)K * (nsteps + 1) * 64)));    // [nsteps + 1][64]: the last slot takes the stores of steps without rows
+      const double *xsP = K > 0 ? xsK - (int64_t)(nsteps + 1) * 64 : xsK;
+      unsigned long long *progK = const_cast<unsigned long long *>(bx_uni((const unsigned long long *)(P.prog + B->prog_off + (int64_t)sweep * nz + K)));
       const unsigned long long *progP = K > 0 ? progK - 1 : progK;
-      const unsigned long long *einfoK = P.einfo + B->einfo_off + (int64_t)K * nsteps * 64;
+      const unsigned long long *einfoK = bx_uni(P.einfo + B->einfo_off + (int64_t)K * nsteps * 64);
       const int ktrue = UPPER ? nz - 1 - K : K;
+      const double *rhsU = bx_uni(P.rhs), *scaleU = bx_uni(P.scale ? P.scale : P.rhs), *addU = bx_uni(P.add ? P.add : P.rhs), *EU = bx_uni(P.E);
+      const unsigned sh_E_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)sh_E);
       // (J, I) of this lane at step s; I in [-3, 124] while the lane is on a line, -1000 otherwise
       auto line_of = [&](int s, int &J, int &I) __attribute__((always_inline)) {
         const int t = s + 3 - 2 * lane;
@@ -240,9 +240,20 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
         }
       } else if (wave == 1) {
         // ---------------- prefetch wave: brings what step s needs into the L2 ----------------
+        // it also watches the previous plane's progress word for the compute wave: a poll by the compute wave itself would have to drain
+        // its request queue (the newest operation of an in-order queue) -- measured: 5 to 9 such drains per step, 0.5 us each
+        auto poll_prev = [&]() __attribute__((always_inline)) {
+          if (K == 0) return;
+          unsigned long long w;
+          bx_ld8u_sc1(w, progP);
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(w)::"memory");
+          const int have = (unsigned)(w >> 32) == epoch ? (int)(unsigned)w : 0;
+          __hip_atomic_store(&sh_prev, __builtin_amdgcn_readfirstlane(have), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
         for (int s = 0; s < nsteps; ++s) {
           unsigned spins = 0;
           while (__hip_atomic_load(&sh_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < s - BOX_AHEAD) {
+            poll_prev();
             __builtin_amdgcn_s_sleep(1);
             if (++spins > BOX_SPIN_LIMIT) break;
           }
@@ -251,28 +262,32 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
           const int tile_d = ts.nact * box::NV;       // doubles
           for (int o = 0; o < tile_d; o += 128) {     // 1 KiB per wavefront load
             const int e = min(o + 2 * lane, tile_d - 2);
-            bx_touch16(bx_chk(P, 1, tile + e, P.stream, P.stream_len - 1, lane, s, K, g), sh_scrap);
+            bx_touch16(tile + e, sh_scrap);
           }
           int J, I;
           line_of(s, J, I);
           const bool act = I >= 0 && I < nx;
-          bx_touch4(bx_chk(P, 2, P.rhs + (act ? row_of(I, J) : r0), P.rhs, P.n, lane, s, K, g), sh_scrap);
-          if (UPPER) bx_touch4(bx_chk(P, 3, einfoK + (int64_t)s * 64 + lane, P.einfo, P.einfo_len, lane, s, K, g), sh_scrap);
-          asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          bx_touch4(P.rhs + (act ? row_of(I, J) : r0), sh_scrap);
+          if (UPPER) bx_touch4(einfoK + (int64_t)s * 64 + lane, sh_scrap);
+          poll_prev();
+        }
+        for (unsigned spins = 0; __hip_atomic_load(&sh_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (1 << 30) && spins < BOX_SPIN_LIMIT; ++spins) {
+          poll_prev();
+          __builtin_amdgcn_s_sleep(1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       } else {
         // ---------------- compute wave ----------------
-        BoxSet<UPPER> SA, SB;
+        BoxSet<UPPER> SA, SB, SC;
+        const unsigned long long t_begin = P.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;   // (diagnostic stamps, DDM_BOX_CHECK=1)
+        unsigned polls = 0;
         double wA0 = 0, wA1 = 0, wA2 = 0, wB0 = 0, wB1 = 0, wB2 = 0, wC0 = 0, wC1 = 0, wC2 = 0, u0 = 0, u1 = 0, u2 = 0, xprev = 0;
         unsigned failed = 0;
-        auto count_of = [&](unsigned long long w) __attribute__((always_inline)) -> int { return (unsigned)(w >> 32) == epoch ? (int)(unsigned)w : 0; };
         auto publish = [&](int steps) __attribute__((always_inline)) {
           if (lane == 0) {
             const unsigned long long w = ((unsigned long long)epoch << 32) | (unsigned)steps;
-            unsigned long long *pk = bx_chkw(P, 4, progK, P.prog, P.prog_len, lane, steps, K, g);
-            if (wt) bx_st8u_sc1(pk, w);
-            else bx_st8u(pk, w);
+            if (wt) bx_st8u_sc1(progK, w);
+            else bx_st8u(progK, w);
           }
         };
         // requests of step s into set S (the same number of vector-memory operations whatever s is)
@@ -283,44 +298,41 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
           const int sc = min(max(s, 0), nsteps - 1);
           const box::StepTab ts = T[sc];
           const int a = act ? J - ts.jlo : 0;
-          const double *tile = plane + (int64_t)ts.off * box::NV + 2 * a;
-          const int qs = 2 * ts.nact;
+          const unsigned toff = (unsigned)(ts.off * box::NV + 2 * a) * 8u, qs = (unsigned)ts.nact * 16u;     // bytes inside the plane's stream
 #pragma unroll
-          for (int q = 0; q < 7; ++q) bx_ld16(S.t[q], bx_chk(P, 5, tile + q * qs, P.stream, P.stream_len - 1, lane, s, K, g));
+          for (int q = 0; q < 7; ++q) bx_ld16o(S.t[q], plane, toff + q * qs);
           // previous plane: column I + 1 of the lines J - 1, J, J + 1 = its steps s - 1, s + 1, s + 3, lanes lane - 1, lane, lane + 1
-          const int l0 = min(max(s - 1, 0), nsteps - 1), l1 = min(s + 1, nsteps - 1), l2 = min(s + 3, nsteps - 1);
-          bx_ld8_sc1(S.r0, bx_chk(P, 6, xsP + (int64_t)l0 * 64 + ((lane + 63) & 63), (const double *)P.xs, P.xs_len, lane, s, K, g));
-          bx_ld8_sc1(S.r1, bx_chk(P, 7, xsP + (int64_t)l1 * 64 + lane, (const double *)P.xs, P.xs_len, lane, s, K, g));
-          bx_ld8_sc1(S.r2, bx_chk(P, 8, xsP + (int64_t)l2 * 64 + ((lane + 1) & 63), (const double *)P.xs, P.xs_len, lane, s, K, g));
-          bx_ld8(S.rh, bx_chk(P, 9, P.rhs + (act ? row_of(I, J) : r0), P.rhs, P.n, lane, s, K, g));
-          bx_ld8u_sc1(S.pl, bx_chk(P, 10, progP, (const unsigned long long *)P.prog, P.prog_len, lane, s, K, g));
+          const int l0 = min(max(s - 1, 0), nsteps - 1), l1 = min(max(s + 1, 0), nsteps - 1), l2 = min(s + 3, nsteps - 1);
+          bx_ld8o_sc1(S.r0, xsP, (unsigned)(l0 * 64 + ((lane + 63) & 63)) * 8u);
+          bx_ld8o_sc1(S.r1, xsP, (unsigned)(l1 * 64 + lane) * 8u);
+          bx_ld8o_sc1(S.r2, xsP, (unsigned)(l2 * 64 + ((lane + 1) & 63)) * 8u);
+          const unsigned roff = (unsigned)((act ? row_of(I, J) : r0) * 8);                                    // rank-local rows: < 2^31
+          bx_ld8o(S.rh, rhsU, roff);
           if constexpr (UPPER) {
-            const int s2 = min(s + 2, nsteps - 1);
+            const int s2 = min(s + BOX_DIST, nsteps - 1);
             const unsigned ptr = (unsigned)ei_now, cnt = (unsigned)(ei_now >> 32);
-            bx_ld8u(S.ei, bx_chk(P, 11, einfoK + (int64_t)s2 * 64 + lane, P.einfo, P.einfo_len, lane, s, K, g));
-            const int64_t rr = act ? row_of(I, J) : r0;
-            bx_ld8(S.sc, bx_chk(P, 12, (P.scale ? P.scale : P.rhs) + rr, P.scale ? P.scale : P.rhs, P.n, lane, s, K, g));
-            bx_ld8(S.ad, bx_chk(P, 13, (P.add ? P.add : P.rhs) + rr, P.add ? P.add : P.rhs, P.n, lane, s, K, g));
+            bx_ld8o(S.sc, scaleU, roff);
+            bx_ld8o(S.ad, addU, roff);
+            const unsigned slot = sh_E_addr + (unsigned)((s + 4) & 3) * BOX_ESLOT;
 #pragma unroll
-            for (int q = 0; q < BOX_NEL; ++q) bx_ld16(S.ep[q], bx_chk(P, 14, P.E + ((unsigned)(2 * q) < cnt ? ptr + 2 * q : 0u), P.E, P.e_len - 1, lane, s, K, g));
+            for (int q = 0; q < BOX_NEL; ++q) bx_dma16(EU, ((unsigned)(2 * q) < cnt ? ptr + 2 * q : 0u) * 8u, slot + q * 1024);
+            // (last: the descriptor this request was issued with is dead by now, so the new one can take its register -- with both
+            //  alive the compiler keeps them apart and copies the new one over at the loop's back edge, while its load is in flight)
+            bx_ld8uo(S.ei, einfoK, (unsigned)(s2 * 64 + lane) * 8u);
           }
         };
         // waits until the previous plane has published `need` steps (bounded)
-        auto wait_prev = [&](int need, unsigned long long seen) __attribute__((always_inline)) {
+        auto wait_prev = [&](int need) __attribute__((always_inline)) {
           if (K == 0) return;
           need = min(need, nsteps);
-          int have = __builtin_amdgcn_readfirstlane(count_of(seen));
           unsigned spins = 0;
-          while (have < need) {
-            unsigned long long w;
-            bx_ld8u_sc1(w, bx_chk(P, 15, progP, (const unsigned long long *)P.prog, P.prog_len, lane, need, K, g));
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(w)::"memory");
-            have = __builtin_amdgcn_readfirstlane(count_of(w));
+          while (__hip_atomic_load(&sh_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+            ++polls;
             if (++spins > BOX_SPIN_LIMIT) {
               failed = 1;
               break;
             }
-            if (have < need) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(1);
           }
         };
         auto step = [&](BoxSet<UPPER> &S, int l) __attribute__((always_inline)) {
@@ -349,10 +361,12 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
             v -= S.t[2].x * wC2; v -= S.t[2].y * wC1; v -= S.t[3].x * wC0;
             v -= S.t[3].y * wB2; v -= S.t[4].x * wB1; v -= S.t[4].y * wB0;
             v -= S.t[5].x * wA2; v -= S.t[5].y * wA1; v -= S.t[6].x * wA0;
+            const unsigned char *slot = sh_E + ((l + 4) & 3) * BOX_ESLOT + lane * 16;
 #pragma unroll
             for (int q = 0; q < BOX_NEL; ++q) {
-              v -= S.ep[q].x;
-              v -= S.ep[q].y;
+              const bx_d2 ep = *reinterpret_cast<const bx_d2 *>(slot + q * 1024);
+              v -= ep.x;
+              v -= ep.y;
             }
             v *= S.t[6].y;
           }
@@ -360,66 +374,72 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
           xprev = xnew;
           ring[l & 1][lane] = xnew;
           // results: position-ordered for the next plane, natural order for the caller (inactive lanes store to a scratch slot)
-          double *xp = bx_chkw(P, 16, xsK + (int64_t)max(l, 0) * 64 + lane, P.xs, P.xs_len, lane, l, K, g);   // (step -1 has no active row: its zeros are overwritten by step 0)
-          if (wt) bx_st8_sc1(xp, xnew);
-          else bx_st8(xp, xnew);
+          const unsigned xoff = (unsigned)((l < 0 || l >= nsteps ? nsteps : l) * 64 + lane) * 8u;   // (steps without rows: the spare slot)
+          double *xp = xsK + xoff / 8;
+          if (wt) bx_st8o_sc1(xsK, xoff, xnew);
+          else bx_st8o(xsK, xoff, xnew);
           const int64_t row = act ? row_of(I, J) : -1;
           double o = xnew;
           if constexpr (UPPER) {
             if (P.scale) o *= S.sc;
             if (P.add) o += S.ad;
           }
-          bx_st8(act ? bx_chkw(P, 17, P.out + row, P.out, P.n, lane, l, K, g) : xp, o);
+          bx_st8(act ? P.out + row : xp, o);
         };
 
-        // head: the product descriptor of step 0, then the requests of steps -1 and 0
-        unsigned long long e0 = 0;
+        // head: the product descriptors of steps 0 and 1, then the requests of steps -1, 0 and 1.  The walk starts at step -1: the
+        // run-in of line 0 (column 0 of the previous plane's lines 0 and 1)
+        unsigned long long e0 = 0, e1 = 0;
         if constexpr (UPPER) {
-          bx_ld8u(e0, bx_chk(P, 18, einfoK + lane, P.einfo, P.einfo_len, lane, -1, K, g));
-          asm volatile("s_waitcnt vmcnt(0)" : "+v"(e0)::"memory");
+          bx_ld8u(e0, einfoK + lane);
+          bx_ld8u(e1, einfoK + (int64_t)min(1, nsteps - 1) * 64 + lane);
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(e0), "+v"(e1)::"memory");
         }
-        // the walk starts at step -1: the run-in of line 0 (column 0 of the previous plane's lines 0 and 1)
-        wait_prev(3, 0ull);
+        wait_prev(3);
         request(SA, -1, 0ull);
-        wait_prev(4, 0ull);
+        wait_prev(4);
         request(SB, 0, e0);
+        wait_prev(5);
+        request(SC, 1, e1);
         // per step: NB requests; stores: 2 results + 1 progress word (lane 0 only: still one operation of the wave)
-        constexpr int NB = UPPER ? 15 + BOX_NEL : 12;
-        static_assert(BOX_NEL == 10, "the s_waitcnt immediates below are written for 10 product loads");
-        // the requests of step 0 are complete when only those of step 1 are outstanding (no stores in between yet)
-        if constexpr (NB == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(25)" ::: "memory");
-        for (int l = -1; l < nsteps && !failed; l += 2) {
-          // ---- set A ----
-          if constexpr (NB + 3 == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
-          bx_tie(SA);
-          publish(max(l - 1, 0));
-          {
-            const unsigned long long seen = SA.pl, ei = SA.ei;
-            step(SA, l);
-            __hip_atomic_store(&sh_step, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            wait_prev(l + 6, seen);
-            request(SA, l + 2, ei);
-          }
-          if (l + 1 >= nsteps) break;
-          // ---- set B ----
-          if constexpr (NB + 3 == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
-          bx_tie(SB);
-          publish(max(l, 0));
-          {
-            const unsigned long long seen = SB.pl, ei = SB.ei;
-            step(SB, l + 1);
-            __hip_atomic_store(&sh_step, l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            wait_prev(l + 7, seen);
-            request(SB, l + 3, ei);
-          }
+        constexpr int NB = UPPER ? 14 + BOX_NEL : 11;
+        static_assert(BOX_NEL == 10 && BOX_DIST == 3, "the s_waitcnt immediates below are written for 10 product loads and three sets");
+        // the first turns have fewer stores behind their requests than the counted wait of `turn` assumes: wait here until only the
+        // requests of step 1 are outstanding
+        if constexpr (NB == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        // one step with set S: its requests are complete when at most the operations behind them are outstanding: two steps' stores
+        // (3 each) and requests (NB each)
+        auto turn = [&](BoxSet<UPPER> &S, int l) __attribute__((always_inline)) {
+          if constexpr (NB == 11) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(54)" ::: "memory");
+          bx_tie(S);
+          publish(min(max(l - 2, 0), nsteps));      // everything issued before this step's requests has completed: the stores of the steps <= l - 3
+          const unsigned long long ei = S.ei;
+          step(S, l);
+          __hip_atomic_store(&sh_step, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          wait_prev(l + BOX_DIST + 4);
+          request(S, l + BOX_DIST, ei);
+        };
+        // (whole trips only: the one or two turns behind the last step have no active row, their stores go to the plane's spare slot
+        //  -- no exit in the middle of the body, so that every path from a request to its wait is the one the counts assume)
+        for (int l = -1; l < nsteps && !failed; l += 3) {
+          turn(SA, l);
+          turn(SB, l + 1);
+          turn(SC, l + 2);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         bx_tie(SA);
         bx_tie(SB);
+        bx_tie(SC);
         publish(nsteps);
+        if (P.dbg && g == 0 && K < 128 && lane == 0) {     // per plane of block 0: start, end (100 MHz), polls of the previous plane's word, XCC
+          unsigned long long *o = P.dbg + (size_t)(sweep * 128 + K) * 4;
+          o[0] = t_begin;
+          o[1] = __builtin_amdgcn_s_memrealtime();
+          o[2] = polls;
+          o[3] = xcc;
+        }
         __hip_atomic_store(&sh_step, 1 << 30, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (failed && lane == 0) __hip_atomic_store(P.err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }

@@ -57,7 +57,7 @@ struct Block {
   int64_t step_off;      // index of the block's step table (nsteps + 1 entries of StepTab)
   int64_t einfo_off;     // words: the block's einfo [nz][nsteps][64]
   int64_t e_begin;       // doubles: first product of the block
-  int64_t xs_off;        // doubles: start of the block's hand-over scratch [nz][nsteps][64]
+  int64_t xs_off;        // doubles: start of the block's hand-over scratch [nz][nsteps + 1][64]
   int64_t prog_off;      // words: progress words [2][nz]
 };
 struct StepTab { // per block and step (the same for every plane)
@@ -230,7 +230,7 @@ inline bool build(int64_t n, const int64_t *rp, const int32_t *ci, const double 
     B.stream_off[1] = stream_len;
     stream_len += B.plane_len[1] * nz;
     B.xs_off = S.xs_len;
-    S.xs_len += (int64_t)nz * B.nsteps * LANES;
+    S.xs_len += (int64_t)nz * (B.nsteps + 1) * LANES;      // one spare slot per plane (stores of steps without rows)
     B.prog_off = S.prog_len;
     S.prog_len += 2 * (int64_t)nz;
     // products: every box row's shell entries, padded to an even count
@@ -431,8 +431,8 @@ inline std::string emulate_lanes(const Schedule &S, int64_t n, const double *d, 
     };
     for (int K = 0; K < nz; ++K) {
       const double *plane = S.stream.data() + B.stream_off[upper] + (int64_t)K * B.plane_len[upper];
-      double *xsK = xs.data() + B.xs_off + (int64_t)K * nsteps * 64;
-      const double *xsP = K > 0 ? xsK - (int64_t)nsteps * 64 : xsK;
+      double *xsK = xs.data() + B.xs_off + (int64_t)K * (nsteps + 1) * 64;
+      const double *xsP = K > 0 ? xsK - (int64_t)(nsteps + 1) * 64 : xsK;
       const int ktrue = upper ? nz - 1 - K : K;
       double wA[64][3] = {}, wB[64][3] = {}, wC[64][3] = {}, u[64][3] = {}, xprev[64] = {}, ring[2][64] = {};
       for (int l = -1; l < nsteps; ++l) {   // step -1: the run-in of line 0 (its column 0 of the previous plane's lines)

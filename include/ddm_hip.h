@@ -147,10 +147,10 @@ int ddm_ilu0_engine(const ddm_ilu0 *F);
  * caller can account the whole setup before it starts its clock.  DDM_PIPE_ASYNC=0: everything inside ddm_ilu0_create.  The matrix
  * handed to ddm_ilu0_create must stay alive as long as the factor (it always had to: the factor borrows its pattern). */
 int ddm_ilu0_wait(ddm_ctx *ctx, ddm_ilu0 *F);
-/* Diagnostic of the box engine (structured blocks; csrc/trsv_box.hpp): with DDM_BOX_CHECK=1 in the environment at creation every address
- * its sweep kernels form is checked against its array; out8 = {site, offset, length, lane, step, plane, block, caught} of the first
- * violation (all zero: none). */
-int ddm_ilu0_box_check(const ddm_ilu0 *F, unsigned long long *out8);
+/* Diagnostic of the box engine (structured blocks; csrc/trsv_box.hpp): with DDM_BOX_CHECK=1 in the environment at creation its sweep
+ * kernels stamp every plane of block 0; out1024 = [2 sweeps][128 planes][4] = {start, end (100 MHz clock), polls of the previous plane's
+ * progress word, XCC id} of the last solve (zeros without the switch). */
+int ddm_ilu0_box_check(const ddm_ilu0 *F, unsigned long long *out1024);
 /* diagnostic: one solve with in-kernel cycle stamps of one compute wave */
 int ddm_ilu0_debug_stamps(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, unsigned long long *out6_host);
 /* diagnostic: one solve with the stamped build of the pipe engine's kernel (DDM_TRSV_MODE=pipe, the default); per task 272

@@ -19,7 +19,7 @@ from tests.test_gpu_pipe import _blocks, _oracle_solve  # noqa: E402
 def test_box_solve_bit_exact(ddm, N, P, spread, monkeypatch):
     import torch
     assert torch.cuda.is_available()
-    monkeypatch.delenv("DDM_TRSV_MODE", raising=False)
+    monkeypatch.setenv("DDM_TRSV_MODE", "box")
     monkeypatch.setenv("DDM_BOX_SPREAD", spread)
     M, bp = _blocks(ddm, N, P)
     ctx = ddm.torch_context(0)
@@ -44,7 +44,7 @@ def test_box_large_lines_and_many_planes(ddm, monkeypatch):
     """lines longer than 64 rows and more than 64 lines per plane (lanes serve two lines), high-contrast coefficient, 40 back-to-back
     solves with the previous result as input"""
     import torch
-    monkeypatch.delenv("DDM_TRSV_MODE", raising=False)
+    monkeypatch.setenv("DDM_TRSV_MODE", "box")
     from dune_ddm_amd import synth
     M, bp = _blocks(ddm, (119, 71, 21), (1, 1, 2), synth.islands_kappa((118, 70, 20), 1e3, 4, 2))
     ctx = ddm.torch_context(0)

@@ -4,10 +4,11 @@ the destination registers of such a load hold their value right after the asm st
 (v_mov, v_accvgpr_write) or re-use them before the data has arrived -- the copy then holds stale bits, and a stale address or product
 index faults (seen with an instrumented build of the backward sweep, round 4).
 
-For every inline-asm global load of k_box_sweep<false/true> the script follows the instructions up to the s_waitcnt that covers the
-load (the second-next counted wait inside the two-step loop body, the next wait in straight-line code) and reports every instruction
-that reads or writes one of its destination registers.  The loads of the bounded spin loops are followed by s_waitcnt vmcnt(0) at once
-and are skipped.  Exit code 1 on a finding.
+For every inline-asm global load (into registers) of k_box_sweep<false/true> the script follows ALL control-flow paths from the load
+to the s_waitcnt that covers it -- the third counted wait on the path (the same turn of the next trip through the three-step loop
+body), any s_waitcnt vmcnt(0), or the wait in front of the loop for the first two sets requested there -- and reports every
+instruction on the way that reads or writes one of the load's destination registers (a new request into the same registers ends the
+path).  Exit code 1 on a finding.
 
 usage: python tools/check_box_isa.py [file.s]      (without a file: compiles ddm_hip.hip to device assembly first, ~1 minute)"""
 import os
@@ -17,7 +18,8 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = {"_ZN3ddm11k_box_sweepILb0EEEvNS_9BoxParamsE": "vmcnt(15)", "_ZN3ddm11k_box_sweepILb1EEEvNS_9BoxParamsE": "vmcnt(28)"}
+# kernel: (counted wait of a turn, head wait in front of the loop, requests per step)
+KERNELS = {"_ZN3ddm11k_box_sweepILb0EEEvNS_9BoxParamsE": ("vmcnt(28)", "vmcnt(11)", 11), "_ZN3ddm11k_box_sweepILb1EEEvNS_9BoxParamsE": ("vmcnt(54)", "vmcnt(24)", 14)}
 
 
 def regs(text):
@@ -52,61 +54,60 @@ def device_asm():
 def check(path):
     s = open(path).read()
     findings = []
-    for name, wimm in KERNELS.items():
+    for name, (wimm, himm, nb) in KERNELS.items():
         i = s.index(name + ":")
         lines = [l.strip() for l in s[i:s.index(".Lfunc_end", i)].split("\n")]
-        is_asm_load = lambda k: lines[k].startswith("global_load") and k > 0 and "ASMSTART" in lines[k - 1]
-        waits = [k for k, l in enumerate(lines) if wimm in l]
-        assert len(waits) == 2, f"{name}: expected the two counted waits of the unrolled step loop, found {len(waits)}"
+        n = len(lines)
+        is_asm_load = lambda k: lines[k].startswith("global_load") and k > 0 and "ASMSTART" in lines[k - 1] and " lds" not in lines[k]
         labels = {l.split(":")[0]: k for k, l in enumerate(lines) if re.match(r"\.LBB\d+_\d+:", l)}
-        end = None
-        for k in range(waits[1], len(lines)):
-            m = re.match(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", lines[k])
-            if m and m.group(1) in labels and labels[m.group(1)] <= waits[0]:
-                end = k
-                break
-        assert end is not None, f"{name}: back edge of the step loop not found"
-        start = max(v for v in labels.values() if v <= waits[0])
 
-        def spin_load(k):          # followed by s_waitcnt vmcnt(0) within a few lines: the bounded polls
-            return any("vmcnt(0)" in lines[kk] for kk in range(k + 1, min(k + 6, len(lines))))
+        def succ(k):
+            l = lines[k]
+            m = re.match(r"s_branch\s+(\.LBB\d+_\d+)", l)
+            if m:
+                return [labels[m.group(1)]]
+            if l.startswith("s_endpgm"):
+                return []
+            out = [k + 1] if k + 1 < n else []
+            m = re.match(r"s_cbranch\S*\s+(\.LBB\d+_\d+)", l)
+            if m:
+                out.append(labels[m.group(1)])
+            return out
 
-        def touches(k, path_):
+        head = [k for k, l in enumerate(lines) if l.startswith("s_waitcnt") and himm in l]
+        assert len(head) == 1, f"{name}: head wait {himm} not found exactly once"
+        asm_loads = [k for k in range(n) if is_asm_load(k)]
+        before_head = [k for k in asm_loads if k < head[0]]
+        last_set = set(before_head[-nb:])            # the third set requested in front of the loop: covered by a counted wait, not by the head wait
+        nchecked = 0
+        for k in asm_loads:
             dst = vregs(lines[k].split()[1].rstrip(","))
-            for kk in path_:
-                ll = lines[kk]
-                if not ll or ll[0] in ";." or kk == k:
+            # paths from the load to the wait that covers it: the BOX_DIST-th counted wait, any vmcnt(0), the head wait for the first two sets
+            seen = set()
+            stack = [(kk, 0) for kk in succ(k)]
+            nchecked += 1
+            while stack:
+                kk, cnt = stack.pop()
+                if (kk, cnt) in seen:
                     continue
-                ops = ll.split(None, 1)
-                if len(ops) == 2 and vregs(ops[1].split(";")[0]) & dst:
-                    return kk
-            return None
-
-        for k in range(start, end + 1):
-            if not is_asm_load(k) or spin_load(k):
-                continue
-            if waits[0] < k < waits[1]:        # set A: valid at the first wait of the next trip
-                t = touches(k, list(range(k + 1, end + 1)) + list(range(start, waits[0])))
-            elif k > waits[1]:                 # set B: valid at the second wait of the next trip
-                t = touches(k, list(range(k + 1, end + 1)) + list(range(start, waits[1])))
-            else:
-                continue
-            if t is not None:
-                findings.append(f"{name}: registers of `{lines[k][:60]}` (line {k}) touched by `{lines[t][:70]}` (line {t}) before their wait")
-        for k in range(len(lines)):            # straight-line code in front of / behind the loop
-            if (start <= k <= end) or not is_asm_load(k) or spin_load(k):
-                continue
-            dst = vregs(lines[k].split()[1].rstrip(","))
-            for kk in range(k + 1, len(lines)):
+                seen.add((kk, cnt))
                 ll = lines[kk]
-                if (ll.startswith("s_waitcnt") and "vmcnt" in ll) or ll.startswith(("s_cbranch", "s_branch", ".LBB")):
-                    break
-                ops = ll.split(None, 1)
-                if ll and ll[0] not in ";." and len(ops) == 2 and not ll.startswith("global_load") and vregs(ops[1].split(";")[0]) & dst:
-                    findings.append(f"{name}: registers of `{lines[k][:60]}` (line {k}) touched by `{ll[:70]}` (line {kk}) before a wait")
-                    break
-        nload = sum(is_asm_load(k) for k in range(len(lines)))
-        print(f"{name}: {nload} inline-asm loads, step loop lines {start}..{end}, counted waits at {waits}")
+                if ll.startswith("s_waitcnt") and "vmcnt" in ll:
+                    if "vmcnt(0)" in ll or (himm in ll and k not in last_set and k < head[0]):
+                        continue
+                    if wimm in ll:
+                        cnt += 1
+                        if cnt >= 3:
+                            continue
+                elif ll and ll[0] not in ";." and not ll.startswith("s_"):
+                    ops = ll.split(None, 1)
+                    if len(ops) == 2 and vregs(ops[1].split(";")[0]) & dst:
+                        if is_asm_load(kk) and vregs(ll.split()[1].rstrip(",")) >= dst:
+                            continue                  # requested again: a new life of the registers
+                        findings.append(f"{name}: registers of `{lines[k][:60]}` (line {k}) touched by `{ll[:70]}` (line {kk}) before their wait")
+                        break
+                stack.extend((x, cnt) for x in succ(kk))
+        print(f"{name}: {nchecked} inline-asm loads followed to their waits")
     return findings
 
 
