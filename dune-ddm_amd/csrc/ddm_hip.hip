@@ -118,6 +118,19 @@ static inline int grid_for(int64_t n, int per_block = WG, int cap = 2048)
   return (int)g;
 }
 
+// Transfers of a BACKGROUND setup thread (the builder of the single-launch engines' schedules runs beside the caller's next setup
+// steps): a synchronous hipMemcpy / hipMemset goes through the legacy default stream, and when the caller's stream is that stream and
+// is being captured into a graph at that moment (the GenEO block solves capture theirs) the capture is invalidated ("operation failed
+// due to a previous error during capture").  The thread therefore moves its data on a non-blocking stream of its own.
+static thread_local hipStream_t t_transfer_stream = nullptr;
+struct BackgroundTransfers {
+  BackgroundTransfers() { (void)hipStreamCreateWithFlags(&t_transfer_stream, hipStreamNonBlocking); }
+  ~BackgroundTransfers()
+  {
+    if (t_transfer_stream) (void)hipStreamDestroy(t_transfer_stream);
+    t_transfer_stream = nullptr;
+  }
+};
 template <class T>
 static int upload(ddm_ctx *ctx, const T *host, int64_t n, T **dev)
 {
@@ -127,8 +140,19 @@ static int upload(ddm_ctx *ctx, const T *host, int64_t n, T **dev)
     return DDM_OK;
   }
   HIPCHECK(ctx, hipMalloc((void **)dev, sizeof(T) * (size_t)n));
-  HIPCHECK(ctx, hipMemcpy(*dev, host, sizeof(T) * (size_t)n, hipMemcpyHostToDevice));
+  if (t_transfer_stream) { // background setup thread: its own non-blocking stream (see BackgroundTransfers)
+    HIPCHECK(ctx, hipMemcpyAsync(*dev, host, sizeof(T) * (size_t)n, hipMemcpyHostToDevice, t_transfer_stream));
+    HIPCHECK(ctx, hipStreamSynchronize(t_transfer_stream));
+  } else
+    HIPCHECK(ctx, hipMemcpy(*dev, host, sizeof(T) * (size_t)n, hipMemcpyHostToDevice));
   return DDM_OK;
+}
+// hipMemset that a background setup thread may call (same reason)
+static hipError_t dev_memset(void *p, int v, size_t bytes)
+{
+  if (!t_transfer_stream) return hipMemset(p, v, bytes);
+  hipError_t e = hipMemsetAsync(p, v, bytes, t_transfer_stream);
+  return e != hipSuccess ? e : hipStreamSynchronize(t_transfer_stream);
 }
 
 // HIP-event timer on the context's stream.  Nothing synchronises while timing is on: the event
@@ -1422,12 +1446,14 @@ static int ilu0_build_engines(ddm_ctx *ctx, ddm_ilu0 *F, const ddm_csr *A, const
     int rcU = DDM_OK;
     std::thread tu([&]() {
       (void)hipSetDevice(ctx->device);
+      BackgroundTransfers own_stream;   // (this create may itself run on a background thread: the box engine's nested factor)
       rcU = build_schedule(ctx, A, F->h_lu, diag, true, F->U);
     });
     if (F->mode == 8 && F->n > 0) {
       pipe_started = true;
       F->pipe_builder = std::thread([ctx, F]() {
         (void)hipSetDevice(ctx->device);
+        BackgroundTransfers own_stream;
         int rcb = DDM_OK;
         if (F->allow_box) rcb = build_box_engine(ctx, F);   // structured blocks: mode 32 (declined: F->box stays null, pipe takes the matrix)
         F->pipe_builder_rc = rcb ? rcb : (F->box ? DDM_OK : build_pipe_schedule(ctx, F)); // (not applicable: pipe_state < 0, see ddm_ilu0_solve)
@@ -2201,9 +2227,9 @@ static int build_xcd_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
   DDMCHECK(upload(ctx, vals.data(), (int64_t)vals.size(), &F->xvals));
   DDMCHECK(upload(ctx, dinv.data(), (int64_t)dinv.size(), &F->xdinv));
   HIPCHECK(ctx, hipMalloc((void **)&F->xflags, sizeof(unsigned) * (size_t)std::max<int64_t>(nflag, 1)));
-  HIPCHECK(ctx, hipMemset(F->xflags, 0, sizeof(unsigned) * (size_t)std::max<int64_t>(nflag, 1)));
+  HIPCHECK(ctx, dev_memset(F->xflags, 0, sizeof(unsigned) * (size_t)std::max<int64_t>(nflag, 1)));
   HIPCHECK(ctx, hipMalloc((void **)&F->xstate, sizeof(XcdState)));
-  HIPCHECK(ctx, hipMemset(F->xstate, 0, sizeof(XcdState)));
+  HIPCHECK(ctx, dev_memset(F->xstate, 0, sizeof(XcdState)));
   F->xnrows = (int64_t)rows.size();
   {
     std::vector<int64_t> lpos;
@@ -2260,16 +2286,16 @@ static int build_pipe_schedule(ddm_ctx *ctx, ddm_ilu0 *F)
   }
   HIPCHECK(ctx, hipMalloc((void **)&F->p_ypos, sizeof(double) * (size_t)std::max<int64_t>(S.nposL, 1)));
   HIPCHECK(ctx, hipMalloc((void **)&F->p_xpos, sizeof(double) * (size_t)std::max<int64_t>(S.nposU, 1)));
-  HIPCHECK(ctx, hipMemset(F->p_ypos, 0, sizeof(double) * (size_t)std::max<int64_t>(S.nposL, 1)));
-  HIPCHECK(ctx, hipMemset(F->p_xpos, 0, sizeof(double) * (size_t)std::max<int64_t>(S.nposU, 1)));
+  HIPCHECK(ctx, dev_memset(F->p_ypos, 0, sizeof(double) * (size_t)std::max<int64_t>(S.nposL, 1)));
+  HIPCHECK(ctx, dev_memset(F->p_xpos, 0, sizeof(double) * (size_t)std::max<int64_t>(S.nposU, 1)));
   const size_t pbytes = sizeof(unsigned long long) * 16 * std::max<size_t>(S.tasks.size(), 1);
   HIPCHECK(ctx, hipMalloc((void **)&F->p_progress, pbytes));
-  HIPCHECK(ctx, hipMemset(F->p_progress, 0, pbytes));
+  HIPCHECK(ctx, dev_memset(F->p_progress, 0, pbytes));
   HIPCHECK(ctx, hipMalloc((void **)&F->p_queue, sizeof(unsigned) * 32 * 4 * (size_t)nb));
-  HIPCHECK(ctx, hipMemset(F->p_queue, 0, sizeof(unsigned) * 32 * 4 * (size_t)nb));
+  HIPCHECK(ctx, dev_memset(F->p_queue, 0, sizeof(unsigned) * 32 * 4 * (size_t)nb));
   if (!F->xstate) {
     HIPCHECK(ctx, hipMalloc((void **)&F->xstate, sizeof(XcdState)));
-    HIPCHECK(ctx, hipMemset(F->xstate, 0, sizeof(XcdState)));
+    HIPCHECK(ctx, dev_memset(F->xstate, 0, sizeof(XcdState)));
   }
   HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_pipe<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS_BYTES));
   HIPCHECK(ctx, hipFuncSetAttribute((const void *)k_trsv_pipe<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIPE_LDS_BYTES));
@@ -2353,7 +2379,7 @@ static int build_box_engine(ddm_ctx *ctx, ddm_ilu0 *F)
   auto zalloc = [&](void **p, size_t bytes) {
     bytes = std::max<size_t>(bytes, 8);
     if (hipMalloc(p, bytes) != hipSuccess) return fail(ctx, DDM_EHIP, "box engine: allocation failed");
-    if (hipMemset(*p, 0, bytes) != hipSuccess) return fail(ctx, DDM_EHIP, "box engine: memset failed");
+    if (dev_memset(*p, 0, bytes) != hipSuccess) return fail(ctx, DDM_EHIP, "box engine: memset failed");
     return DDM_OK;
   };
   rc = zalloc((void **)&X->E, sizeof(double) * (size_t)X->nprod);
