@@ -981,9 +981,6 @@ struct Factor {
   int64_t *d_rptr = nullptr, *d_pptr = nullptr;
   double *d_panels = nullptr;
   int32_t *d_lev_sn = nullptr;   // supernodes sorted by level
-  // the leading levels of small supernodes as subtrees (k_sn_fwd1_subtrees): sub_nl levels, one workgroup per subtree
-  int32_t sub_nl = 0, sub_count = 0;
-  int32_t *d_sub_ptr = nullptr, *d_sub_sn = nullptr;
   int32_t *d_preT = nullptr;     // per level: exclusive prefix of the row-tile counts (lev_ptr[l] + l .. : cnt + 1 entries)
   int32_t *d_preU = nullptr;     // the same for the update tiles T (T + 1) / 2
   int32_t *d_big_sn = nullptr, *d_big_index = nullptr, *d_preB = nullptr; // supernodes with more than BWD_SMALL row tiles, per level
@@ -1038,10 +1035,8 @@ struct Factor {
     }
     for (void *p : {(void *)d_first, (void *)d_nrow, (void *)d_rows, (void *)d_sn_of_col, (void *)d_iperm, (void *)d_perm, (void *)d_rptr, (void *)d_pptr, (void *)d_panels,
                     (void *)d_lev_sn, (void *)d_preT, (void *)d_preU, (void *)d_big_sn, (void *)d_big_index, (void *)d_preB, (void *)d_err, (void *)d_partial,
-                    (void *)d_upanels, (void *)d_uptr, (void *)d_piv, (void *)d_preUF, (void *)d_tptr, (void *)d_tmid, (void *)d_tidx, (void *)d_tpos, (void *)d_chain_ints, (void *)d_chain_offs, (void *)d_chain_w, (void *)d_chain_e, (void *)d_chain_v, (void *)d_chain_u, (void *)d_contrib, (void *)d_top_ints, (void *)d_top_partial, (void *)d_top_sync, (void *)d_top_flags, (void *)d_sub_ptr, (void *)d_sub_sn})
+                    (void *)d_upanels, (void *)d_uptr, (void *)d_piv, (void *)d_preUF, (void *)d_tptr, (void *)d_tmid, (void *)d_tidx, (void *)d_tpos, (void *)d_chain_ints, (void *)d_chain_offs, (void *)d_chain_w, (void *)d_chain_e, (void *)d_chain_v, (void *)d_chain_u, (void *)d_contrib, (void *)d_top_ints, (void *)d_top_partial, (void *)d_top_sync, (void *)d_top_flags})
       if (p) (void)hipFree(p);
-    d_sub_ptr = d_sub_sn = nullptr;
-    sub_nl = sub_count = 0;
     d_first = d_nrow = d_rows = d_sn_of_col = d_iperm = d_perm = d_lev_sn = d_preT = d_preU = d_big_sn = d_big_index = d_preB = nullptr;
     d_rptr = d_pptr = nullptr;
     d_panels = d_partial = d_upanels = d_contrib = nullptr;
@@ -1624,49 +1619,6 @@ static inline bool build(Factor &F, int64_t n, int64_t nblocks, const int64_t *b
     if (hipMalloc((void **)&F.d_piv, sizeof(int32_t) * (size_t)std::max<int64_t>(n, 1)) != hipSuccess) return false;
   }
   if (!build_top_plan(F, lev_sn, nrow, first)) return false;
-  { // subtrees of the leading small levels (single-vector solves: one launch per sweep instead of one per level)
-    const int32_t lbot = F.ntop > 0 ? F.ltop : nlev;
-    int32_t nl = 0;
-    while (nl < lbot && F.lev_maxnc[(size_t)nl] <= 64 && F.lev_maxnr[(size_t)nl] <= 192) ++nl;
-    F.sub_nl = 0;
-    if (nl >= 2) {
-      std::vector<int32_t> root((size_t)F.nsn, -1), rid((size_t)F.nsn, -1);
-      int32_t nroot = 0;
-      for (int32_t sidx = F.nsn - 1; sidx >= 0; --sidx) { // parents have larger numbers inside a block: roots first
-        if (level[(size_t)sidx] >= nl) continue;
-        const int32_t par = parent_g[(size_t)sidx];
-        if (par >= 0 && level[(size_t)par] < nl) root[(size_t)sidx] = root[(size_t)par];
-        else {
-          root[(size_t)sidx] = sidx;
-          rid[(size_t)sidx] = nroot++;
-        }
-      }
-      bool ok = true;
-      for (int32_t sidx = 0; sidx < F.nsn && ok; ++sidx)
-        if (level[(size_t)sidx] < nl && (root[(size_t)sidx] < 0 || rid[(size_t)root[(size_t)sidx]] < 0)) ok = false; // (a parent numbered below its child: not this tree)
-      if (ok && nroot > 0) {
-        std::vector<int32_t> sptr((size_t)nroot * (nl + 1) + 1, 0);
-        for (int32_t sidx = 0; sidx < F.nsn; ++sidx)
-          if (level[(size_t)sidx] < nl) sptr[(size_t)rid[(size_t)root[(size_t)sidx]] * (nl + 1) + level[(size_t)sidx] + 1]++;
-        // per subtree: counts per level -> offsets (global running offset)
-        std::vector<int32_t> off((size_t)nroot * (nl + 1), 0);
-        int32_t run = 0;
-        for (int32_t r = 0; r < nroot; ++r) {
-          for (int32_t l = 0; l < nl; ++l) {
-            off[(size_t)r * (nl + 1) + l] = run;
-            run += sptr[(size_t)r * (nl + 1) + l + 1];
-          }
-          off[(size_t)r * (nl + 1) + nl] = run;
-        }
-        std::vector<int32_t> ssn((size_t)std::max(run, 1)), fill(off);
-        for (int32_t sidx = 0; sidx < F.nsn; ++sidx)
-          if (level[(size_t)sidx] < nl) ssn[(size_t)fill[(size_t)rid[(size_t)root[(size_t)sidx]] * (nl + 1) + level[(size_t)sidx]]++] = sidx;
-        if (!up(off, &F.d_sub_ptr) || !up(ssn, &F.d_sub_sn)) return false;
-        F.sub_nl = nl;
-        F.sub_count = nroot;
-      }
-    }
-  }
   F.h_first = first;
   if (!build_chains(F, n, level, first, nrow, rptr, rows, parent_g) || !upload_chains(F)) return false;
   F.M.nsn = F.nsn;
@@ -1771,12 +1723,7 @@ static inline void solve_t(const Factor &F, hipStream_t st, int m, double *B, in
     const int32_t lbot = F.ntop > 0 ? F.ltop : F.nlev; // levels [0, lbot) by launches
     const char *sk = std::getenv("DDM_SN_SMALL_KERNELS");
     const bool small_kernels = !(sk && sk[0] == '0');
-    const char *sf = std::getenv("DDM_SN_SUBTREES");
-    const int32_t nfused = (small_kernels && F.sub_nl > 0 && !(sf && sf[0] == '0')) ? F.sub_nl : 0; // leading small levels: one launch per sweep
-    if (nfused > 0)
-      hipLaunchKernelGGL(k_sn_fwd1_subtrees<LU>, dim3((unsigned)F.sub_count), dim3(256), 0, st, F.M, (int)nfused, (const int32_t *)F.d_sub_ptr, (const int32_t *)F.d_sub_sn, (const double *)B, Yvec,
-                         F.d_contrib);
-    for (int32_t l = nfused; l < lbot; ++l) {
+    for (int32_t l = 0; l < lbot; ++l) {
       const int32_t cnt = F.lev_ptr[(size_t)l + 1] - F.lev_ptr[(size_t)l];
       if (cnt == 0) continue;
       const int32_t *lsn = F.d_lev_sn + F.lev_ptr[(size_t)l], *preT = F.d_preT + F.lev_ptr[(size_t)l] + l;
@@ -1795,7 +1742,7 @@ static inline void solve_t(const Factor &F, hipStream_t st, int m, double *B, in
       hipLaunchKernelGGL(k_sn_top1<LU>, dim3((unsigned)F.top_grid), dim3(TOP_THREADS), 0, st, F.M, F.top, F.nblocks, F.top_spread, B, Yvec, F.d_contrib, F.d_top_partial,
                          F.d_top_sync, F.d_top_flags, err ? err : F.d_err + 1, F.d_top_stamps);
     }
-    for (int32_t l = lbot - 1; l >= nfused; --l) {
+    for (int32_t l = lbot - 1; l >= 0; --l) {
       const int32_t cnt = F.lev_ptr[(size_t)l + 1] - F.lev_ptr[(size_t)l];
       if (cnt == 0) continue;
       const int32_t *lsn = F.d_lev_sn + F.lev_ptr[(size_t)l];
@@ -1813,8 +1760,6 @@ static inline void solve_t(const Factor &F, hipStream_t st, int m, double *B, in
       if (small) hipLaunchKernelGGL((k_sn_bwd1_diag<LU, 64>), dim3((unsigned)cnt), dim3(256), 0, st, F.M, lsn, bidx, preB, (const double *)F.d_partial, (const double *)Yvec, B);
       else hipLaunchKernelGGL((k_sn_bwd1_diag<LU, 128>), dim3((unsigned)cnt), dim3(512), 0, st, F.M, lsn, bidx, preB, (const double *)F.d_partial, (const double *)Yvec, B);
     }
-    if (nfused > 0)
-      hipLaunchKernelGGL(k_sn_bwd1_subtrees<LU>, dim3((unsigned)F.sub_count), dim3(256), 0, st, F.M, (int)nfused, (const int32_t *)F.d_sub_ptr, (const int32_t *)F.d_sub_sn, (const double *)Yvec, B);
     return;
   }
   static DeviceOnce attr_once; // (one per instantiation: LU / Cholesky)

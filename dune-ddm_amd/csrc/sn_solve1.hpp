@@ -247,10 +247,14 @@ __global__ __launch_bounds__(4 * NCMAX) void k_sn_bwd1_diag(Meta M, const int32_
 // resp. lane = row (tiles of the block below); the vector entries of the other lanes come by shuffles.  The 256-thread kernels above
 // spend a whole workgroup (and, forward, one per row tile) on ~30 columns x ~40 rows: 70-84 us per level and sweep on the DG problem
 // (22 700 leaves), measured; profiles/r04_kernel_stats_sn_solve_dg.csv.
-// one wavefront, one supernode: forward
 template <bool LU>
-__device__ __forceinline__ void s1_small_forward(const Meta &M, int32_t s, int lane, const double *__restrict__ B, double *__restrict__ Y, double *__restrict__ contrib)
+__global__ __launch_bounds__(256) void k_sn_fwd1_small(Meta M, const int32_t *__restrict__ lev_sn, int cnt, const double *__restrict__ B, double *__restrict__ Y,
+                                                       double *__restrict__ contrib)
 {
+  const int lane = threadIdx.x & 63;
+  const int it = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (it >= cnt) return; // (the whole wavefront: nothing below synchronises across wavefronts)
+  const int32_t s = lev_sn[it];
   const int32_t f = M.first[s], nc = M.first[s + 1] - f, nr = M.nrow[s];
   const int64_t ld = nc + nr;
   const double *P = M.panels + M.pptr[s];
@@ -282,10 +286,13 @@ __device__ __forceinline__ void s1_small_forward(const Meta &M, int32_t s, int l
     if (r < nr) contrib[M.tpos[M.rptr[s] + r]] = acc;
   }
 }
-// one wavefront, one supernode: backward
 template <bool LU>
-__device__ __forceinline__ void s1_small_backward(const Meta &M, int32_t s, int lane, const double *__restrict__ Y, double *__restrict__ B)
+__global__ __launch_bounds__(256) void k_sn_bwd1_small(Meta M, const int32_t *__restrict__ lev_sn, int cnt, const double *__restrict__ Y, double *__restrict__ B)
 {
+  const int lane = threadIdx.x & 63;
+  const int it = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (it >= cnt) return;
+  const int32_t s = lev_sn[it];
   const int32_t f = M.first[s], nc = M.first[s + 1] - f, nr = M.nrow[s];
   const int64_t ld = nc + nr;
   const double *P = M.panels + M.pptr[s];
@@ -316,50 +323,6 @@ __device__ __forceinline__ void s1_small_backward(const Meta &M, int32_t s, int 
     for (int u = 0; u < 8; ++u) x += w[u] * __shfl(t, k0 + u);
   }
   if (lane < nc) B[f + lane] = x;
-}
-template <bool LU>
-__global__ __launch_bounds__(256) void k_sn_fwd1_small(Meta M, const int32_t *__restrict__ lev_sn, int cnt, const double *__restrict__ B, double *__restrict__ Y,
-                                                       double *__restrict__ contrib)
-{
-  const int it = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (it >= cnt) return; // (the whole wavefront: nothing below synchronises across wavefronts)
-  s1_small_forward<LU>(M, lev_sn[it], threadIdx.x & 63, B, Y, contrib);
-}
-template <bool LU>
-__global__ __launch_bounds__(256) void k_sn_bwd1_small(Meta M, const int32_t *__restrict__ lev_sn, int cnt, const double *__restrict__ Y, double *__restrict__ B)
-{
-  const int it = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (it >= cnt) return;
-  s1_small_backward<LU>(M, lev_sn[it], threadIdx.x & 63, Y, B);
-}
-// The levels of small supernodes in ONE launch per sweep: a workgroup per SUBTREE (a supernode of those levels whose parent is above them,
-// with everything below it), its levels one after the other with a workgroup barrier in between -- what a supernode of the subtree adds
-// to rows of the subtree is written and read by wavefronts of the same workgroup (same CU, same L1: visible behind the barrier).
-// sub_ptr[(nl + 1) r + l] .. sub_ptr[(nl + 1) r + l + 1]: the supernodes of level l of subtree r in sub_sn (five launches -> one: the
-// DG problem's leaf levels, 44 + 52 us per level and sweep of mostly launch and tail).
-template <bool LU>
-__global__ __launch_bounds__(256) void k_sn_fwd1_subtrees(Meta M, int nl, const int32_t *__restrict__ sub_ptr, const int32_t *__restrict__ sub_sn, const double *__restrict__ B,
-                                                          double *__restrict__ Y, double *__restrict__ contrib)
-{
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int32_t *ptr = sub_ptr + (size_t)blockIdx.x * (nl + 1);
-  for (int l = 0; l < nl; ++l) {
-    for (int32_t k = ptr[l] + wave; k < ptr[l + 1]; k += 4) s1_small_forward<LU>(M, sub_sn[k], lane, B, Y, contrib);
-    __threadfence_block();
-    __syncthreads();
-  }
-}
-template <bool LU>
-__global__ __launch_bounds__(256) void k_sn_bwd1_subtrees(Meta M, int nl, const int32_t *__restrict__ sub_ptr, const int32_t *__restrict__ sub_sn, const double *__restrict__ Y,
-                                                          double *__restrict__ B)
-{
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int32_t *ptr = sub_ptr + (size_t)blockIdx.x * (nl + 1);
-  for (int l = nl - 1; l >= 0; --l) {
-    for (int32_t k = ptr[l] + wave; k < ptr[l + 1]; k += 4) s1_small_backward<LU>(M, sub_sn[k], lane, Y, B);
-    __threadfence_block();
-    __syncthreads();
-  }
 }
 
 // ---- the persistent kernel for the top of the tree --------------------------------------------------------------------------------

@@ -238,40 +238,6 @@ def test_single_vector_top_kernel_matches_level_kernels(ddm, torch_cuda, device_
         assert np.linalg.norm(M @ out[key] - d.cpu().numpy()) <= 1e-11 * np.linalg.norm(d.cpu().numpy()), key
 
 
-@pytest.mark.parametrize("case", ["dg", "poisson"])
-def test_subtree_launch_is_bitwise_the_level_launches(ddm, torch_cuda, device_engine, case, monkeypatch):
-    """The leading levels of small supernodes run as ONE launch per sweep (a workgroup per subtree, k_sn_fwd1_subtrees /
-    k_sn_bwd1_subtrees) or as one launch per level (DDM_SN_SUBTREES=0): the same arithmetic in the same order, so the same bits --
-    L U on the 2-D DG operator (deep trees of small supernodes) and Cholesky on 3-D Poisson blocks."""
-    import torch
-    from dune_ddm_amd import synth
-    from dune_ddm_amd.problem import RankLocal, build_structured
-    if case == "dg":
-        dec = build_structured(synth.StructuredDG2D((64, 48), (4, 2)), overlap=2)
-        rl = RankLocal(dec, 0, 1)
-        general = True
-    else:
-        dec, rl = _blocks(ddm, (29, 27, 25), (2, 2, 2))
-        general = False
-    n = rl.n
-    d = torch.as_tensor(np.random.default_rng(31).standard_normal(n)).cuda()
-    out = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("DDM_SN_SUBTREES", flag)
-        ctx = ddm.torch_context(0)
-        F = ddm.Ilu0(ctx, ddm.CsrMatrix(ctx, sp.csr_matrix(rl.A_dir)), rl.block_ptr, direct=True, general=general)
-        x = torch.zeros(n, dtype=torch.float64, device="cuda")
-        F.solve(d, x)
-        F.solve(d, x)
-        ctx.sync()
-        assert F.status() == 0
-        out.append(x.clone())
-        ctx.close()
-    assert torch.equal(out[0], out[1])
-    M = sp.csr_matrix(rl.A_dir)
-    assert np.linalg.norm(M @ out[1].cpu().numpy() - d.cpu().numpy()) <= 1e-10 * np.linalg.norm(d.cpu().numpy())
-
-
 @pytest.mark.parametrize("case", ["dg", "pivoting"])
 def test_device_lu_matches_superlu(ddm, torch_cuda, device_engine, case):
     """The L U variant of the device engine (`type = umfpack`, general = 1): non-symmetric values on the symmetric pattern, threshold
