@@ -2470,6 +2470,7 @@ static int enqueue_box(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, co
   int dbg = 0;   // diagnostic: DDM_BOX_DEBUG bit mask switches phases off (1 forward boxes, 2 nested solve, 4 products, 8 backward boxes, 16 shell rhs / out)
   if (const char *e = std::getenv("DDM_BOX_DEBUG")) dbg = std::atoi(e);
   hipLaunchKernelGGL(k_pipe_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate, X->queue, X->nblocks * 2);
+  hipLaunchKernelGGL(k_box_fill, dim3(grid_for(X->xs_len, WG, 4096)), dim3(WG), 0, ctx->stream, X->xs_len, (unsigned long long *)X->xs);   // "not written yet"
   if (!(dbg & 1)) hipLaunchKernelGGL((k_box_sweep<false>), dim3(X->grid), dim3(BOX_WG), 0, ctx->stream, P);
   if (X->nshell > 0 && !(dbg & 2)) {
     ddm_ilu0 *G = X->shell;
@@ -2494,6 +2495,7 @@ static int enqueue_box(ddm_ctx *ctx, ddm_ilu0 *F, const double *d, double *x, co
   P.scale = scale;
   P.add = add;
   hipLaunchKernelGGL(k_pipe_prologue, dim3(1), dim3(64), 0, ctx->stream, F->xstate, X->queue, X->nblocks * 2);
+  hipLaunchKernelGGL(k_box_fill, dim3(grid_for(X->xs_len, WG, 4096)), dim3(WG), 0, ctx->stream, X->xs_len, (unsigned long long *)X->xs);
   if (!(dbg & 8)) hipLaunchKernelGGL((k_box_sweep<true>), dim3(X->grid), dim3(BOX_WG), 0, ctx->stream, P);
   if (X->nshell > 0 && !(dbg & 16))
     hipLaunchKernelGGL(k_box_shell_out, dim3(grid_for(X->nshell)), dim3(WG), 0, ctx->stream, X->nshell, (const int32_t *)X->srow, (const double *)X->xsol, x, scale, add);

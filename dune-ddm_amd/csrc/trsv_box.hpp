@@ -19,6 +19,7 @@
 // (fewer XCDs with workgroups than blocks need, or P.spread) results and progress words are agent-scope stores.
 #pragma once
 #include "trsv_box_host.hpp"
+#include <type_traits>
 
 namespace ddm {
 
@@ -64,7 +65,9 @@ __device__ __forceinline__ void bx_st8_sc1(double *p, double v) { asm volatile("
 __device__ __forceinline__ void bx_st8u(unsigned long long *p, unsigned long long v) { asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void bx_st8u_sc1(unsigned long long *p, unsigned long long v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
 // the same with a wave-uniform base (SGPR pair) and a 32-bit byte offset per lane: one address register instead of two and no 64-bit
-// address arithmetic per load -- the sweep kernels hold three sets of requests in registers
+// address arithmetic per load -- the sweep kernels hold three sets of requests in registers.  The destination is a READ-WRITE operand
+// ("+v"): the request registers are loop-carried, and with a plain output the compiler is free to define a new register at every
+// request and copy it into the loop's register at the back edge -- while the load is in flight (tools/check_box_isa.py found that)
 template <class T>
 __device__ __forceinline__ const T *bx_uni(const T *p)
 {
@@ -72,11 +75,11 @@ __device__ __forceinline__ const T *bx_uni(const T *p)
   const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
   return (const T *)(uintptr_t)(((unsigned long long)hi << 32) | lo);
 }
-__device__ __forceinline__ void bx_ld16o(bx_d2 &v, const void *base, unsigned off) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory"); }
-__device__ __forceinline__ void bx_ld8o(double &v, const void *base, unsigned off) { asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory"); }
-__device__ __forceinline__ void bx_ld8o_sc1(double &v, const void *base, unsigned off) { asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=v"(v) : "v"(off), "s"(base) : "memory"); }
-__device__ __forceinline__ void bx_ld8uo(unsigned long long &v, const void *base, unsigned off) { asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory"); }
-__device__ __forceinline__ void bx_ld8uo_sc1(unsigned long long &v, const void *base, unsigned off) { asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=v"(v) : "v"(off), "s"(base) : "memory"); }
+__device__ __forceinline__ void bx_ld16o(bx_d2 &v, const void *base, unsigned off) { asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(v) : "v"(off), "s"(base) : "memory"); }
+__device__ __forceinline__ void bx_ld8o(double &v, const void *base, unsigned off) { asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(v) : "v"(off), "s"(base) : "memory"); }
+__device__ __forceinline__ void bx_ld8o_sc1(double &v, const void *base, unsigned off) { asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "+v"(v) : "v"(off), "s"(base) : "memory"); }
+__device__ __forceinline__ void bx_ld8uo(unsigned long long &v, const void *base, unsigned off) { asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(v) : "v"(off), "s"(base) : "memory"); }
+__device__ __forceinline__ void bx_ld8uo_sc1(unsigned long long &v, const void *base, unsigned off) { asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "+v"(v) : "v"(off), "s"(base) : "memory"); }
 __device__ __forceinline__ void bx_st8o(void *base, unsigned off, double v) { asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(off), "v"(v), "s"(base) : "memory"); }
 __device__ __forceinline__ void bx_st8o_sc1(void *base, unsigned off, double v) { asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(base) : "memory"); }
 
@@ -97,20 +100,28 @@ __device__ __forceinline__ void bx_dma16(const void *base, unsigned off, unsigne
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_byte_address) : "memory");   // (m0 is written here; the compiler sets it itself in front of each of its own uses)
 }
 
+// results not written yet carry this NaN pattern (k_box_fill before every sweep)
+constexpr unsigned long long BOX_UNWRITTEN = 0xFFF7BADC0FFEE000ull;
+__device__ __forceinline__ bool bx_unwritten(double v) { return (unsigned long long)__double_as_longlong(v) == BOX_UNWRITTEN; }
+__global__ void k_box_fill(int64_t n, unsigned long long *__restrict__ p)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = BOX_UNWRITTEN;
+}
+
 // what one step requests BOX_DIST steps ahead
 template <bool UPPER>
 struct BoxSet {
   bx_d2 t[7];
   double r0, r1, r2, rh;
-  unsigned long long ei;
   double sc, ad;       // backward sweep: the row's scale / add entries of the level's tail
+  unsigned ecnt;       // backward sweep: shell entries of the row (not a load: set when the request is issued)
 };   // (the row's shell products of the backward sweep travel by LDS-DMA into a ring of BOX_DIST + 1 slots: 40 registers per set less)
 // the compiler must not move uses of the registers in front of the wait that makes them valid
 template <bool UPPER>
 __device__ __forceinline__ void bx_tie(BoxSet<UPPER> &S)
 {
   asm volatile("" : "+v"(S.t[0]), "+v"(S.t[1]), "+v"(S.t[2]), "+v"(S.t[3]), "+v"(S.t[4]), "+v"(S.t[5]), "+v"(S.t[6]));
-  asm volatile("" : "+v"(S.r0), "+v"(S.r1), "+v"(S.r2), "+v"(S.rh), "+v"(S.ei));
+  asm volatile("" : "+v"(S.r0), "+v"(S.r1), "+v"(S.r2), "+v"(S.rh));
   if constexpr (UPPER) {
     asm volatile("" : "+v"(S.sc), "+v"(S.ad));
   }
@@ -152,12 +163,12 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
   __shared__ double ring[2][64];
   __shared__ unsigned sh_xcc, sh_xt, sh_gt, sh_fail, sh_q;
   __shared__ int sh_step;
-  __shared__ int sh_prev;   // steps the previous plane has published, as last seen by the prefetch wave (the compute wave never polls memory)
   __shared__ box::StepTab sh_tab[BOX_MAX_STEPS + 1];
   // the prefetch wave's loads are LDS-DMA into this scrap area: a load into registers nobody reads would land, when it returns, in
   // registers the compiler has given to something else by then (an address of a later load: found the hard way)
   __shared__ __attribute__((aligned(16))) unsigned char sh_scrap[1024];
   __shared__ __attribute__((aligned(16))) unsigned char sh_E[UPPER ? (BOX_DIST + 1) * BOX_ESLOT : 16];
+  __shared__ __attribute__((aligned(16))) unsigned char sh_I[UPPER ? (BOX_DIST + 1) * 1024 : 16];   // product descriptors of the steps in flight ([lane] 16 bytes, the first 8 used)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   XcdState *st = P.st;
@@ -180,12 +191,9 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
   }
   __syncthreads();
   if (sh_fail) return;
-  const int dmode = P.spread >> 4;     // diagnostic (DDM_BOX_SPREAD = 16 * mode): 1 leave here, 2 tickets and tables only, 3 no compute wave, 4 no prefetch wave
-  if (dmode == 1) return;
   const unsigned xcc = sh_xcc, xt = sh_xt;
-  const unsigned epoch = __hip_atomic_load(&st->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned tk = lane < 8 ? __hip_atomic_load(&st->tickets[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
-  const bool local_ok = !(P.spread & 15) && __all(lane >= min(P.nblocks, 8) || tk >= 1u);
+  const bool local_ok = !P.spread && __all(lane >= min(P.nblocks, 8) || tk >= 1u);
   const bool wt = !local_ok;
   const int gfirst = local_ok ? (int)xcc : (int)(sh_gt % (unsigned)P.nblocks);
   const int gcount = local_ok ? ((int)xcc < P.nblocks ? (P.nblocks - (int)xcc + 7) / 8 : 0) : P.nblocks;
@@ -203,7 +211,6 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
       if (threadIdx.x == 0) {
         sh_q = __hip_atomic_fetch_add(P.queue + (size_t)(2 * g + sweep) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sh_step = -2;
-        sh_prev = 0;
       }
       __syncthreads();
       const int K = __builtin_amdgcn_readfirstlane((int)sh_q);
@@ -214,12 +221,11 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
       const double *plane = bx_uni(P.stream + B->stream_off[sweep] + (int64_t)K * B->plane_len[sweep]);
       double *xsK = const_cast<double *>(bx_uni((const double *)(P.xs + B->xs_off + (int64_t)K * (nsteps + 1) * 64)));    // [nsteps + 1][64]: the last slot takes the stores of steps without rows
       const double *xsP = K > 0 ? xsK - (int64_t)(nsteps + 1) * 64 : xsK;
-      unsigned long long *progK = const_cast<unsigned long long *>(bx_uni((const unsigned long long *)(P.prog + B->prog_off + (int64_t)sweep * nz + K)));
-      const unsigned long long *progP = K > 0 ? progK - 1 : progK;
       const unsigned long long *einfoK = bx_uni(P.einfo + B->einfo_off + (int64_t)K * nsteps * 64);
       const int ktrue = UPPER ? nz - 1 - K : K;
       const double *rhsU = bx_uni(P.rhs), *scaleU = bx_uni(P.scale ? P.scale : P.rhs), *addU = bx_uni(P.add ? P.add : P.rhs), *EU = bx_uni(P.E);
       const unsigned sh_E_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)sh_E);
+      const unsigned sh_I_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)sh_I);
       // (J, I) of this lane at step s; I in [-3, 124] while the lane is on a line, -1000 otherwise
       auto line_of = [&](int s, int &J, int &I) __attribute__((always_inline)) {
         const int t = s + 3 - 2 * lane;
@@ -232,28 +238,11 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
         return r0 + i + (int64_t)nx * (j + (int64_t)ny * ktrue);
       };
 
-      if (dmode == 2 || (dmode == 3 && wave == 0) || (dmode == 4 && wave == 1)) {
-        if (wave == 0 && lane == 0) {     // (the plane counts as done, so that nobody waits for it)
-          const unsigned long long w = ((unsigned long long)epoch << 32) | (unsigned)nsteps;
-          __hip_atomic_store(progK, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(&sh_step, 1 << 30, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-      } else if (wave == 1) {
+      if (wave == 1) {
         // ---------------- prefetch wave: brings what step s needs into the L2 ----------------
-        // it also watches the previous plane's progress word for the compute wave: a poll by the compute wave itself would have to drain
-        // its request queue (the newest operation of an in-order queue) -- measured: 5 to 9 such drains per step, 0.5 us each
-        auto poll_prev = [&]() __attribute__((always_inline)) {
-          if (K == 0) return;
-          unsigned long long w;
-          bx_ld8u_sc1(w, progP);
-          asm volatile("s_waitcnt vmcnt(0)" : "+v"(w)::"memory");
-          const int have = (unsigned)(w >> 32) == epoch ? (int)(unsigned)w : 0;
-          __hip_atomic_store(&sh_prev, __builtin_amdgcn_readfirstlane(have), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        };
         for (int s = 0; s < nsteps; ++s) {
           unsigned spins = 0;
           while (__hip_atomic_load(&sh_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < s - BOX_AHEAD) {
-            poll_prev();
             __builtin_amdgcn_s_sleep(1);
             if (++spins > BOX_SPIN_LIMIT) break;
           }
@@ -269,11 +258,7 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
           const bool act = I >= 0 && I < nx;
           bx_touch4(P.rhs + (act ? row_of(I, J) : r0), sh_scrap);
           if (UPPER) bx_touch4(einfoK + (int64_t)s * 64 + lane, sh_scrap);
-          poll_prev();
-        }
-        for (unsigned spins = 0; __hip_atomic_load(&sh_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (1 << 30) && spins < BOX_SPIN_LIMIT; ++spins) {
-          poll_prev();
-          __builtin_amdgcn_s_sleep(1);
+          asm volatile("s_waitcnt vmcnt(40)" ::: "memory");   // (four to five steps of touches in flight: two would tie this wave to 2 steps per HBM round trip)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       } else {
@@ -281,15 +266,8 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
         BoxSet<UPPER> SA, SB, SC;
         const unsigned long long t_begin = P.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;   // (diagnostic stamps, DDM_BOX_CHECK=1)
         unsigned polls = 0;
-        double wA0 = 0, wA1 = 0, wA2 = 0, wB0 = 0, wB1 = 0, wB2 = 0, wC0 = 0, wC1 = 0, wC2 = 0, u0 = 0, u1 = 0, u2 = 0, xprev = 0;
+        double wA[3] = {0, 0, 0}, wB[3] = {0, 0, 0}, wC[3] = {0, 0, 0}, uu[3] = {0, 0, 0}, xprev = 0;   // windows: rotated by the unroll, not by moves
         unsigned failed = 0;
-        auto publish = [&](int steps) __attribute__((always_inline)) {
-          if (lane == 0) {
-            const unsigned long long w = ((unsigned long long)epoch << 32) | (unsigned)steps;
-            if (wt) bx_st8u_sc1(progK, w);
-            else bx_st8u(progK, w);
-          }
-        };
         // requests of step s into set S (the same number of vector-memory operations whatever s is)
         auto request = [&](BoxSet<UPPER> &S, int s, unsigned long long ei_now) __attribute__((always_inline)) {
           int J, I;
@@ -311,42 +289,54 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
           if constexpr (UPPER) {
             const int s2 = min(s + BOX_DIST, nsteps - 1);
             const unsigned ptr = (unsigned)ei_now, cnt = (unsigned)(ei_now >> 32);
+            S.ecnt = cnt;
             bx_ld8o(S.sc, scaleU, roff);
             bx_ld8o(S.ad, addU, roff);
             const unsigned slot = sh_E_addr + (unsigned)((s + 4) & 3) * BOX_ESLOT;
 #pragma unroll
             for (int q = 0; q < BOX_NEL; ++q) bx_dma16(EU, ((unsigned)(2 * q) < cnt ? ptr + 2 * q : 0u) * 8u, slot + q * 1024);
-            // (last: the descriptor this request was issued with is dead by now, so the new one can take its register -- with both
-            //  alive the compiler keeps them apart and copies the new one over at the loop's back edge, while its load is in flight)
-            bx_ld8uo(S.ei, einfoK, (unsigned)(s2 * 64 + lane) * 8u);
+            // the descriptor of step s + BOX_DIST: by LDS-DMA as well (in a register it is loop-carried through an inline-asm load, and the
+            // compiler kept finding ways to copy it while the load was in flight); 16 bytes per lane land, the first 8 are the lane's
+            bx_dma16(einfoK, (unsigned)(s2 * 64 + lane) * 8u, sh_I_addr + (unsigned)((s + 4) & 3) * 1024);
           }
         };
-        // waits until the previous plane has published `need` steps (bounded)
-        auto wait_prev = [&](int need) __attribute__((always_inline)) {
-          if (K == 0) return;
-          need = min(need, nsteps);
-          unsigned spins = 0;
-          while (__hip_atomic_load(&sh_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
-            ++polls;
-            if (++spins > BOX_SPIN_LIMIT) {
-              failed = 1;
-              break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-          }
-        };
-        auto step = [&](BoxSet<UPPER> &S, int l) __attribute__((always_inline)) {
+        auto step = [&](BoxSet<UPPER> &S, int l, auto RC) __attribute__((always_inline)) {
+          constexpr int R = decltype(RC)::value, i0 = (R + 1) % 3, i1 = (R + 2) % 3, i2 = R;   // columns I - 1, I, I + 1 of the windows in this turn
           // (the caller has waited for the requests of step l)
           int J, I;
           line_of(l, J, I);
           const bool act = I >= 0 && I < nx;
           const bool colok = I + 1 >= 0 && I + 1 < nx;          // column I + 1 exists (I = -1000 off line: false)
           const bool prev = K > 0 && colok;
-          wA0 = wA1; wA1 = wA2; wA2 = (prev && J >= 1) ? S.r0 : 0.0;
-          wB0 = wB1; wB1 = wB2; wB2 = prev ? S.r1 : 0.0;
-          wC0 = wC1; wC1 = wC2; wC2 = (prev && J + 1 < ny) ? S.r2 : 0.0;
+          // hand-over by DATA: the previous plane's results were pre-set to a NaN pattern (k_box_fill) -- a value that still shows the
+          // pattern has not been written yet.  In the steady state this never happens (every plane runs the same code at the same
+          // speed; a plane that got too close waits here once and is far enough behind from then on): no progress words, no polls
+          const bool n0 = prev && J >= 1, n1 = prev, n2 = prev && J + 1 < ny;
+          {
+            bool bad = (n0 && bx_unwritten(S.r0)) || (n1 && bx_unwritten(S.r1)) || (n2 && bx_unwritten(S.r2));
+            unsigned spins = 0;
+            while (__any(bad)) {
+              ++polls;
+              const int l0 = min(max(l - 1, 0), nsteps - 1), l1 = min(max(l + 1, 0), nsteps - 1), l2 = min(l + 3, nsteps - 1);
+              bx_ld8o_sc1(S.r0, xsP, (unsigned)(l0 * 64 + ((lane + 63) & 63)) * 8u);
+              bx_ld8o_sc1(S.r1, xsP, (unsigned)(l1 * 64 + lane) * 8u);
+              bx_ld8o_sc1(S.r2, xsP, (unsigned)(l2 * 64 + ((lane + 1) & 63)) * 8u);
+              asm volatile("s_waitcnt vmcnt(0)" : "+v"(S.r0), "+v"(S.r1), "+v"(S.r2)::"memory");
+              bad = (n0 && bx_unwritten(S.r0)) || (n1 && bx_unwritten(S.r1)) || (n2 && bx_unwritten(S.r2));
+              if (++spins > BOX_SPIN_LIMIT) {
+                failed = 1;
+                break;
+              }
+              if (__any(bad)) __builtin_amdgcn_s_sleep(1);
+            }
+          }
+          wA[i2] = n0 ? S.r0 : 0.0;      // (overwrites the column that dropped out of the window)
+          wB[i2] = n1 ? S.r1 : 0.0;
+          wC[i2] = n2 ? S.r2 : 0.0;
           const double nbv = ring[(l + 1) & 1][(lane + 63) & 63];
-          u0 = u1; u1 = u2; u2 = (colok && J >= 1) ? nbv : 0.0;
+          uu[i2] = (colok && J >= 1) ? nbv : 0.0;
+          const double wA0 = wA[i0], wA1 = wA[i1], wA2 = wA[i2], wB0 = wB[i0], wB1 = wB[i1], wB2 = wB[i2], wC0 = wC[i0], wC1 = wC[i1], wC2 = wC[i2];
+          const double u0 = uu[i0], u1 = uu[i1], u2 = uu[i2];
           if (I <= 0) xprev = 0.0;
           double v = S.rh;
           if constexpr (!UPPER) {
@@ -362,8 +352,10 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
             v -= S.t[3].y * wB2; v -= S.t[4].x * wB1; v -= S.t[4].y * wB0;
             v -= S.t[5].x * wA2; v -= S.t[5].y * wA1; v -= S.t[6].x * wA0;
             const unsigned char *slot = sh_E + ((l + 4) & 3) * BOX_ESLOT + lane * 16;
+            const unsigned mycnt = S.ecnt;
 #pragma unroll
             for (int q = 0; q < BOX_NEL; ++q) {
+              if (!__any(mycnt > (unsigned)(2 * q))) break;     // (no row of this step has that many shell entries; the skipped slots hold zeros)
               const bx_d2 ep = *reinterpret_cast<const bx_d2 *>(slot + q * 1024);
               v -= ep.x;
               v -= ep.y;
@@ -395,44 +387,40 @@ __global__ __launch_bounds__(BOX_WG) void k_box_sweep(BoxParams P)
           bx_ld8u(e1, einfoK + (int64_t)min(1, nsteps - 1) * 64 + lane);
           asm volatile("s_waitcnt vmcnt(0)" : "+v"(e0), "+v"(e1)::"memory");
         }
-        wait_prev(3);
         request(SA, -1, 0ull);
-        wait_prev(4);
         request(SB, 0, e0);
-        wait_prev(5);
         request(SC, 1, e1);
         // per step: NB requests; stores: 2 results + 1 progress word (lane 0 only: still one operation of the wave)
-        constexpr int NB = UPPER ? 14 + BOX_NEL : 11;
+        constexpr int NB = UPPER ? 14 + BOX_NEL : 11;   // requests per step; 2 result stores per step
         static_assert(BOX_NEL == 10 && BOX_DIST == 3, "the s_waitcnt immediates below are written for 10 product loads and three sets");
-        // the first turns have fewer stores behind their requests than the counted wait of `turn` assumes: wait here until only the
-        // requests of step 1 are outstanding
-        if constexpr (NB == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        // the loop is entered with all three sets complete: whatever register moves the compiler places in front of the loop then move
+        // data that has arrived (all planes start together, so this wait is not on the chain of hand-overs)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bx_tie(SA);
+        bx_tie(SB);
+        bx_tie(SC);
         // one step with set S: its requests are complete when at most the operations behind them are outstanding: two steps' stores
         // (3 each) and requests (NB each)
-        auto turn = [&](BoxSet<UPPER> &S, int l) __attribute__((always_inline)) {
-          if constexpr (NB == 11) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(54)" ::: "memory");
+        auto turn = [&](BoxSet<UPPER> &S, int l, auto RC) __attribute__((always_inline)) {
+          if constexpr (NB == 11) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(52)" ::: "memory");
           bx_tie(S);
-          publish(min(max(l - 2, 0), nsteps));      // everything issued before this step's requests has completed: the stores of the steps <= l - 3
-          const unsigned long long ei = S.ei;
-          step(S, l);
+          const unsigned long long ei = UPPER ? *reinterpret_cast<const unsigned long long *>(sh_I + ((l + 4) & 3) * 1024 + lane * 16) : 0ull;
+          step(S, l, RC);
           __hip_atomic_store(&sh_step, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          wait_prev(l + BOX_DIST + 4);
           request(S, l + BOX_DIST, ei);
         };
         // (whole trips only: the one or two turns behind the last step have no active row, their stores go to the plane's spare slot
         //  -- no exit in the middle of the body, so that every path from a request to its wait is the one the counts assume)
         for (int l = -1; l < nsteps && !failed; l += 3) {
-          turn(SA, l);
-          turn(SB, l + 1);
-          turn(SC, l + 2);
+          turn(SA, l, std::integral_constant<int, 0>{});
+          turn(SB, l + 1, std::integral_constant<int, 1>{});
+          turn(SC, l + 2, std::integral_constant<int, 2>{});
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         bx_tie(SA);
         bx_tie(SB);
         bx_tie(SC);
-        publish(nsteps);
         if (P.dbg && g == 0 && K < 128 && lane == 0) {     // per plane of block 0: start, end (100 MHz), polls of the previous plane's word, XCC
           unsigned long long *o = P.dbg + (size_t)(sweep * 128 + K) * 4;
           o[0] = t_begin;

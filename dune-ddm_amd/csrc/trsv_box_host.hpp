@@ -249,7 +249,7 @@ inline bool build(int64_t n, const int64_t *rp, const int32_t *ci, const double 
   S.stream.assign((size_t)stream_len, 0.0);
   S.ext_val.assign((size_t)eoff, 0.0);
   S.ext_col.assign((size_t)eoff, -1);
-  S.einfo.assign((size_t)einfo_len, 0);   // (index 0, count 0: the zeros)
+  S.einfo.assign((size_t)einfo_len + 2, 0);   // (index 0, count 0: the zeros; two spare words: the kernel fetches 16 bytes per lane)
   S.stats.ext_products = eoff;
   S.stats.shell_rows = nshell;
   S.stats.stream_bytes = stream_len * 8;
