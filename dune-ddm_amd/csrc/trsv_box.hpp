@@ -84,13 +84,17 @@ __device__ __forceinline__ void bx_st8o(void *base, unsigned off, double v) { as
 __device__ __forceinline__ void bx_st8o_sc1(void *base, unsigned off, double v) { asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(base) : "memory"); }
 
 // brings the cache line of p into the L2 without a destination register (LDS-DMA into a scrap area of the workgroup)
+// (inline asm, not the builtin: the compiler knows that the builtin writes LDS and puts s_waitcnt vmcnt(0) in front of the wave's next
+// LDS read -- the prefetch wave reads the compute wave's step counter from LDS every step and would drain its touches each time)
 __device__ __forceinline__ void bx_touch16(const void *p, unsigned char *scrap)
 {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p, (__attribute__((address_space(3))) void *)scrap, 16, 0, 0);
+  const unsigned a = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)scrap);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(p), "s"(a) : "memory");
 }
 __device__ __forceinline__ void bx_touch4(const void *p, unsigned char *scrap)
 {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p, (__attribute__((address_space(3))) void *)scrap, 4, 0, 0);
+  const unsigned a = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)scrap);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(p), "s"(a) : "memory");
 }
 
 // LDS-DMA the compiler does not know about (16 bytes per lane to lds_byte_address + 16 lane): with the builtin the compiler drains the
